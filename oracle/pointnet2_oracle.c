@@ -1,0 +1,315 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
+ *
+ * Plain-C CPU restatement of the nine `pointnet2._ext` ops of taolinzhang/3DVLP
+ * (reference: the .cu and .cpp files of lib/pointnet2/_ext_src/src).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY STATUS: "parity unpinned" for these nine ops.  The reference's native
+ * implementation is CUDA-only (no nvcc / no NVIDIA GPU in this image, and every
+ * host wrapper refuses CPU tensors, e.g. sampling.cpp:39,65,87) and the
+ * reference ships no golden vectors for them.  This file
+ * therefore restates the .cu kernels statement by statement — thread-strided
+ * loops become loops over an emulated thread id, the shared-memory tree
+ * reduction is replayed literally — and is cross-checked by the algebraic
+ * invariants in tests/test_oracle_invariants.py.
+ *
+ * fp32 arithmetic: the reference is built by nvcc with its default -fmad=true
+ * (setup.py:25-28 passes only -O2), so  a*a + b*b + c*c  may be contracted.
+ * `contract` selects the form (compile this file with -ffp-contract=off so
+ * that gcc itself contracts nothing):
+ *   0  no contraction      : ((a*a) + (b*b)) + (c*c)
+ *   1  LLVM/NVPTX fadd rule: fma(c,c, fma(a,a, b*b))     [default everywhere]
+ *   2  left chain          : fma(c,c, fma(b,b, a*a))
+ * Form 1 is what LLVM's DAG combiner (which NVPTX uses with aggressive FMA
+ * fusion) produces for (fadd (fadd (fmul a a) (fmul b b)) (fmul c c)):
+ * the first operand that is an fmul is fused, the other product is rounded.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TOTAL_THREADS 512 /* include/cuda_utils.h:18 */
+
+static inline float sumsq3(float a, float b, float c, int contract) {
+  if (contract == 1) return fmaf(c, c, fmaf(a, a, b * b));
+  if (contract == 2) return fmaf(c, c, fmaf(b, b, a * a));
+  float t = a * a;
+  float u = b * b;
+  float s = t + u;
+  float v = c * c;
+  return s + v;
+}
+
+/* include/cuda_utils.h:20-24 — largest power of two <= work_size, capped. */
+int orc_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int v = 1 << pow_2;
+  if (v > TOTAL_THREADS) v = TOTAL_THREADS;
+  if (v < 1) v = 1;
+  return v;
+}
+
+/* sampling_gpu.cu:13-25 (kernel), sampling.cpp:20-43 (host: zero-filled out). */
+void orc_gather_points(int b, int c, int n, int m, const float *points,
+                       const int *idx, float *out) {
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        int a = idx[i * m + j];
+        out[((size_t)i * c + l) * m + j] = points[((size_t)i * c + l) * n + a];
+      }
+}
+
+/* sampling_gpu.cu:39-52; grad_points is zero-filled by the host (sampling.cpp:56-58).
+ * atomicAdd order is unspecified in the reference; here: ascending j. */
+void orc_gather_points_grad(int b, int c, int n, int m, const float *grad_out,
+                            const int *idx, float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * n);
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        int a = idx[i * m + j];
+        grad_points[((size_t)i * c + l) * n + a] +=
+            grad_out[((size_t)i * c + l) * m + j];
+      }
+}
+
+/* sampling_gpu.cu:64-70 */
+static inline void fps_update(float *dists, int *dists_i, int idx1, int idx2) {
+  const float v1 = dists[idx1], v2 = dists[idx2];
+  const int i1 = dists_i[idx1], i2 = dists_i[idx2];
+  dists[idx1] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+  dists_i[idx1] = v2 > v1 ? i2 : i1;
+}
+
+/* sampling_gpu.cu:74-178 with the launch of :180-234 (block = opt_n_threads(n),
+ * grid = b) and the host pre-fill temp = 1e10, idxs = 0 (sampling.cpp:74-80).
+ * The block is replayed thread by thread; the LDS tree :120-173 literally. */
+void orc_furthest_point_sampling(int b, int n, int m, const float *dataset_all,
+                                 float *temp_all, int *idxs_all, int contract) {
+  if (m <= 0) return;
+  const int block_size = orc_opt_n_threads(n);
+#pragma omp parallel for schedule(static)
+  for (int bi = 0; bi < b; ++bi) {
+    const float *dataset = dataset_all + (size_t)bi * n * 3;
+    float *temp = temp_all + (size_t)bi * n;
+    int *idxs = idxs_all + (size_t)bi * m;
+    float dists[TOTAL_THREADS];
+    int dists_i[TOTAL_THREADS];
+    for (int k = 0; k < n; ++k) temp[k] = 1e10f;
+    for (int j = 0; j < m; ++j) idxs[j] = 0;
+
+    int old = 0;
+    idxs[0] = old;
+    for (int j = 1; j < m; j++) {
+      float x1 = dataset[old * 3 + 0];
+      float y1 = dataset[old * 3 + 1];
+      float z1 = dataset[old * 3 + 2];
+      for (int tid = 0; tid < block_size; ++tid) {
+        int besti = 0;
+        float best = -1;
+        for (int k = tid; k < n; k += block_size) {
+          float x2 = dataset[k * 3 + 0];
+          float y2 = dataset[k * 3 + 1];
+          float z2 = dataset[k * 3 + 2];
+          float mag = sumsq3(x2, y2, z2, contract);
+          if ((double)mag <= 1e-3) continue; /* :106, double literal */
+          float d = sumsq3(x2 - x1, y2 - y1, z2 - z1, contract);
+          float d2 = d < temp[k] ? d : temp[k]; /* min(d, temp[k]) */
+          temp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      for (int half = block_size / 2; half >= 1; half /= 2)
+        for (int tid = 0; tid < half; ++tid)
+          fps_update(dists, dists_i, tid, tid + half);
+      old = dists_i[0];
+      idxs[j] = old;
+    }
+  }
+}
+
+/* ball_query_gpu.cu:14-49; idx zero-filled by the host (ball_query.cpp:24-26). */
+void orc_ball_query(int b, int n, int m, float radius, int nsample,
+                    const float *new_xyz_all, const float *xyz_all, int *idx_all,
+                    int contract) {
+  memset(idx_all, 0, sizeof(int) * (size_t)b * m * nsample);
+  const float radius2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      const float *xyz = xyz_all + (size_t)bi * n * 3;
+      const float *new_xyz = new_xyz_all + (size_t)bi * m * 3;
+      int *idx = idx_all + (size_t)bi * m * nsample;
+      float new_x = new_xyz[j * 3 + 0];
+      float new_y = new_xyz[j * 3 + 1];
+      float new_z = new_xyz[j * 3 + 2];
+      for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) {
+        float x = xyz[k * 3 + 0];
+        float y = xyz[k * 3 + 1];
+        float z = xyz[k * 3 + 2];
+        float d2 = sumsq3(new_x - x, new_y - y, new_z - z, contract);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) idx[j * nsample + l] = k;
+          idx[j * nsample + cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+}
+
+/* group_points_gpu.cu:13-33 */
+void orc_group_points(int b, int c, int n, int npoints, int nsample,
+                      const float *points_all, const int *idx_all, float *out_all) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      const float *points = points_all + (size_t)bi * n * c;
+      const int *idx = idx_all + (size_t)bi * npoints * nsample;
+      float *out = out_all + (size_t)bi * npoints * nsample * c;
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          int ii = idx[j * nsample + k];
+          out[((size_t)l * npoints + j) * nsample + k] = points[(size_t)l * n + ii];
+        }
+    }
+}
+
+/* group_points_gpu.cu:48-69; zero-filled grad (group_points.cpp:52-54).
+ * Summation order here: ascending (j,k). */
+void orc_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                           const float *grad_out_all, const int *idx_all,
+                           float *grad_points_all) {
+  memset(grad_points_all, 0, sizeof(float) * (size_t)b * c * n);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      const float *grad_out = grad_out_all + (size_t)bi * npoints * nsample * c;
+      const int *idx = idx_all + (size_t)bi * npoints * nsample;
+      float *grad_points = grad_points_all + (size_t)bi * n * c;
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          int ii = idx[j * nsample + k];
+          grad_points[(size_t)l * n + ii] +=
+              grad_out[((size_t)l * npoints + j) * nsample + k];
+        }
+    }
+}
+
+/* interpolate_gpu.cu:14-64: best* are doubles initialised to 1e40, d is float. */
+void orc_three_nn(int b, int n, int m, const float *unknown_all,
+                  const float *known_all, float *dist2_all, int *idx_all,
+                  int contract) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < n; ++j) {
+      const float *unknown = unknown_all + (size_t)bi * n * 3;
+      const float *known = known_all + (size_t)bi * m * 3;
+      float *dist2 = dist2_all + (size_t)bi * n * 3;
+      int *idx = idx_all + (size_t)bi * n * 3;
+      float ux = unknown[j * 3 + 0];
+      float uy = unknown[j * 3 + 1];
+      float uz = unknown[j * 3 + 2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float x = known[k * 3 + 0];
+        float y = known[k * 3 + 1];
+        float z = known[k * 3 + 2];
+        float d = sumsq3(ux - x, uy - y, uz - z, contract);
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d;     besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d;     besti2 = k;
+        } else if (d < best3) {
+          best3 = d;     besti3 = k;
+        }
+      }
+      dist2[j * 3 + 0] = (float)best1;
+      dist2[j * 3 + 1] = (float)best2;
+      dist2[j * 3 + 2] = (float)best3;
+      idx[j * 3 + 0] = besti1;
+      idx[j * 3 + 1] = besti2;
+      idx[j * 3 + 2] = besti3;
+    }
+}
+
+/* interpolate_gpu.cu:77-106.  `contract`: 0 = ((p1*w1)+(p2*w2))+(p3*w3);
+ * 1 = fma(p3,w3, fma(p1,w1, p2*w2)) (same DAG rule as sumsq3). */
+static inline float blend3(float p1, float w1, float p2, float w2, float p3,
+                           float w3, int contract) {
+  if (contract == 1) return fmaf(p3, w3, fmaf(p1, w1, p2 * w2));
+  if (contract == 2) return fmaf(p3, w3, fmaf(p2, w2, p1 * w1));
+  float a = p1 * w1;
+  float bb = p2 * w2;
+  float s = a + bb;
+  float cc = p3 * w3;
+  return s + cc;
+}
+
+static void three_interpolate_impl(int b, int c, int m, int n,
+                                   const float *points_all, const int *idx_all,
+                                   const float *weight_all, float *out_all,
+                                   int contract) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *points = points_all + (size_t)bi * m * c;
+    const int *idx = idx_all + (size_t)bi * n * 3;
+    const float *weight = weight_all + (size_t)bi * n * 3;
+    float *out = out_all + (size_t)bi * n * c;
+    for (int i = 0; i < c * n; ++i) {
+      const int l = i / n;
+      const int j = i % n;
+      float w1 = weight[j * 3 + 0], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
+      int i1 = idx[j * 3 + 0], i2 = idx[j * 3 + 1], i3 = idx[j * 3 + 2];
+      out[i] = blend3(points[l * m + i1], w1, points[l * m + i2], w2,
+                      points[l * m + i3], w3, contract);
+    }
+  }
+}
+
+void orc_three_interpolate(int b, int c, int m, int n, const float *points,
+                           const int *idx, const float *weight, float *out,
+                           int contract) {
+  three_interpolate_impl(b, c, m, n, points, idx, weight, out, contract);
+}
+
+/* What interpolate_gpu.cu:121-148 (and upstream VoteNet) intend: the true
+ * adjoint of three_interpolate.  grad_points zero-filled; order: ascending (j,t). */
+void orc_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out_all,
+                                const int *idx_all, const float *weight_all,
+                                float *grad_points_all) {
+  memset(grad_points_all, 0, sizeof(float) * (size_t)b * c * m);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *grad_out = grad_out_all + (size_t)bi * n * c;
+    const int *idx = idx_all + (size_t)bi * n * 3;
+    const float *weight = weight_all + (size_t)bi * n * 3;
+    float *grad_points = grad_points_all + (size_t)bi * m * c;
+    for (int i = 0; i < c * n; ++i) {
+      const int l = i / n;
+      const int j = i % n;
+      grad_points[l * m + idx[j * 3 + 0]] += grad_out[i] * weight[j * 3 + 0];
+      grad_points[l * m + idx[j * 3 + 1]] += grad_out[i] * weight[j * 3 + 1];
+      grad_points[l * m + idx[j * 3 + 2]] += grad_out[i] * weight[j * 3 + 2];
+    }
+  }
+}
+
+/* What the reference actually executes (REFERENCE BUG, interpolate.cpp:77-104):
+ * three_interpolate_grad() calls the FORWARD wrapper with
+ *   (b, c, m := grad_out.size(2) = n, n := m, points := grad_out, idx, weight, out(B,c,m)),
+ * so idx/weight advance by m*3 per batch instead of n*3 and no scatter happens. */
+void orc_three_interpolate_grad_asshipped(int b, int c, int n, int m,
+                                          const float *grad_out, const int *idx,
+                                          const float *weight, float *out,
+                                          int contract) {
+  three_interpolate_impl(b, c, /*m=*/n, /*n=*/m, grad_out, idx, weight, out, contract);
+}
