@@ -1,0 +1,225 @@
+"""ctypes binding of libvlp3d_hip.so (C ABI declared in include/vlp3d.h).
+
+This is the Python side of the drop-in boundary: it plays the role of the reference's pybind
+module ``pointnet2._ext`` (lib/pointnet2/_ext_src/src/bindings.cpp:11-24) — same nine functions,
+same argument checks and messages (include/utils.h:10-30) — but over a plain C ABI, with outputs
+allocated here by torch (the library allocates nothing) and work enqueued on torch's current
+HIP stream.  No CPU path exists: CPU tensors raise like the reference ("CPU not supported").
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvlp3d_hip.so")
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes; every function returns int (0 ok, -22 EINVAL, >0 hipError_t)
+SIGNATURES = {
+    "vlp3d_abi_version": [],
+    "vlp3d_fp_contract": [],
+    "vlp3d_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "vlp3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_group_points_grad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_three_interpolate": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_three_interpolate_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_nn_distance": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once). Raises ImportError with build instructions when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libvlp3d_hip.so not found at %s — build it with `python 3dvlp_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+class Vlp3dError(RuntimeError):
+    pass
+
+
+def _check(status, name):
+    if status != 0:
+        what = "invalid argument" if status == -22 else "hipError_t %d" % status
+        raise Vlp3dError("%s failed: %s" % (name, what))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk_float(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(name + " must be a contiguous tensor")
+    if t.dtype != torch.float32:
+        raise RuntimeError(name + " must be a float tensor")
+
+
+def _chk_int(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(name + " must be a contiguous tensor")
+    if t.dtype != torch.int32:
+        raise RuntimeError(name + " must be an int tensor")
+
+
+def _chk_dev(ref, *others):
+    if not ref.is_cuda:
+        raise RuntimeError("CPU not supported")
+    for name, t in others:
+        if not t.is_cuda or t.device != ref.device:
+            raise RuntimeError(name + " must be a CUDA tensor")
+
+
+# ---- the nine _ext functions (same names / argument order as bindings.cpp:12-23) ----
+def furthest_point_sampling(points, nsamples):
+    _chk_float(points, "points")
+    _chk_dev(points)
+    B, N, _ = points.shape
+    out = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)
+    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _check(load().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
+               "furthest_point_sampling")
+    return out
+
+
+def gather_points(points, idx):
+    _chk_float(points, "points")
+    _chk_int(idx, "idx")
+    _chk_dev(points, ("idx", idx))
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _check(load().vlp3d_gather_points(_p(points), _p(idx), B, C, N, M, _p(out), _stream()), "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    _chk_float(grad_out, "grad_out")
+    _chk_int(idx, "idx")
+    _chk_dev(grad_out, ("idx", idx))
+    B, C, M = grad_out.shape
+    out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _check(load().vlp3d_gather_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, _p(out), _stream()),
+               "gather_points_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    _chk_float(new_xyz, "new_xyz")
+    _chk_float(xyz, "xyz")
+    _chk_dev(new_xyz, ("xyz", xyz))
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(load().vlp3d_ball_query(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(idx),
+                                       _stream()), "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    _chk_float(points, "points")
+    _chk_int(idx, "idx")
+    _chk_dev(points, ("idx", idx))
+    B, C, N = points.shape
+    _, M, S = idx.shape
+    out = torch.empty((B, C, M, S), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _check(load().vlp3d_group_points(_p(points), _p(idx), B, C, N, M, S, _p(out), _stream()), "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    _chk_float(grad_out, "grad_out")
+    _chk_int(idx, "idx")
+    _chk_dev(grad_out, ("idx", idx))
+    B, C, M, S = grad_out.shape
+    out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _check(load().vlp3d_group_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, S, _p(out), _stream()),
+               "group_points_grad")
+    return out
+
+
+def three_nn(unknowns, knows):
+    _chk_float(unknowns, "unknowns")
+    _chk_float(knows, "knows")
+    _chk_dev(unknowns, ("knows", knows))
+    B, n, _ = unknowns.shape
+    m = knows.shape[1]
+    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        _check(load().vlp3d_three_nn(_p(unknowns), _p(knows), B, n, m, _p(dist2), _p(idx), _stream()), "three_nn")
+    return dist2, idx
+
+
+def three_interpolate(points, idx, weight):
+    _chk_float(points, "points")
+    _chk_int(idx, "idx")
+    _chk_float(weight, "weight")
+    _chk_dev(points, ("idx", idx), ("weight", weight))
+    B, C, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _check(load().vlp3d_three_interpolate(_p(points), _p(idx), _p(weight), B, C, m, n, _p(out), _stream()),
+               "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    _chk_float(grad_out, "grad_out")
+    _chk_int(idx, "idx")
+    _chk_float(weight, "weight")
+    _chk_dev(grad_out, ("idx", idx), ("weight", weight))
+    B, C, n = grad_out.shape
+    out = torch.empty((B, C, m), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _check(load().vlp3d_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, int(m), _p(out),
+                                                   _stream()), "three_interpolate_grad")
+    return out
+
+
+# ---- fused ops ----
+def nn_distance(pc1, pc2, mode, delta):
+    _chk_float(pc1, "pc1")
+    _chk_float(pc2, "pc2")
+    _chk_dev(pc1, ("pc2", pc2))
+    B, N, C = pc1.shape
+    M = pc2.shape[1]
+    if C != 3 or pc2.shape[2] != 3 or pc2.shape[0] != B:
+        raise RuntimeError("nn_distance: expected (B,N,3) and (B,M,3)")
+    dist1 = torch.empty((B, N), dtype=torch.float32, device=pc1.device)
+    idx1 = torch.empty((B, N), dtype=torch.int64, device=pc1.device)
+    dist2 = torch.empty((B, M), dtype=torch.float32, device=pc1.device)
+    idx2 = torch.empty((B, M), dtype=torch.int64, device=pc1.device)
+    with torch.cuda.device(pc1.device):
+        _check(load().vlp3d_nn_distance(_p(pc1), _p(pc2), B, N, M, int(mode), float(delta), _p(dist1), _p(idx1),
+                                        _p(dist2), _p(idx2), _stream()), "nn_distance")
+    return dist1, idx1, dist2, idx2

@@ -1,0 +1,143 @@
+// three_nn / three_interpolate (+ adjoint) for gfx950 — replaces interpolate_gpu.cu:14-159.
+#include "common.h"
+
+namespace {
+
+constexpr int KNOWN_TILE = 1024;  // known points staged per LDS pass (12 KiB)
+
+// One thread per unknown point; the known set streams through LDS in tiles shared by the
+// workgroup.  Strict `<` chain in index order => lowest index wins ties (interpolate_gpu.cu:39-54).
+// The reference keeps best* as double 1e40 and stores (float)best: +inf when fewer than 3 known
+// points exist; float +inf reproduces both the comparisons and the stored value.
+__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ unknown_all,
+                                                       const float *__restrict__ known_all, int n, int m,
+                                                       float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+  __shared__ float s_known[KNOWN_TILE * 3];
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const float *__restrict__ unknown = unknown_all + (size_t)b * n * 3;
+  const float *__restrict__ known = known_all + (size_t)b * m * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (j < n) {
+    ux = unknown[j * 3 + 0];
+    uy = unknown[j * 3 + 1];
+    uz = unknown[j * 3 + 2];
+  }
+  const float inf = __builtin_inff();
+  float best1 = inf, best2 = inf, best3 = inf;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k0 = 0; k0 < m; k0 += KNOWN_TILE) {
+    const int cnt = min(KNOWN_TILE, m - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += 256) s_known[t] = known[(size_t)k0 * 3 + t];
+    __syncthreads();
+    for (int kk = 0; kk < cnt; ++kk) {
+      const float d = vlp3d_sumsq3(ux - s_known[kk * 3 + 0], uy - s_known[kk * 3 + 1], uz - s_known[kk * 3 + 2]);
+      const int k = k0 + kk;
+      if (d < best1) {
+        best3 = best2; besti3 = besti2;
+        best2 = best1; besti2 = besti1;
+        best1 = d;     besti1 = k;
+      } else if (d < best2) {
+        best3 = best2; besti3 = besti2;
+        best2 = d;     besti2 = k;
+      } else if (d < best3) {
+        best3 = d;     besti3 = k;
+      }
+    }
+  }
+  if (j < n) {
+    float *__restrict__ d2 = dist2_all + ((size_t)b * n + j) * 3;
+    int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
+    d2[0] = best1; d2[1] = best2; d2[2] = best3;
+    id[0] = besti1; id[1] = besti2; id[2] = besti3;
+  }
+}
+
+// out[b,c,j] = p[c,i1]*w1 + p[c,i2]*w2 + p[c,i3]*w3 ; thread owns j, walks a slab of channels.
+__global__ __launch_bounds__(256) void three_interpolate_kernel(const float *__restrict__ points,
+                                                                const int *__restrict__ idx,
+                                                                const float *__restrict__ weight, int C, int m,
+                                                                int n, int c_per_block, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int *__restrict__ id = idx + ((size_t)b * n + j) * 3;
+  const float *__restrict__ w = weight + ((size_t)b * n + j) * 3;
+  const int i1 = id[0], i2 = id[1], i3 = id[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int c0 = blockIdx.y * c_per_block;
+  const int c1 = min(C, c0 + c_per_block);
+  for (int c = c0; c < c1; ++c) {
+    const float *__restrict__ p = points + ((size_t)b * C + c) * m;
+    out[((size_t)b * C + c) * n + j] = vlp3d_blend3(p[i1], w1, p[i2], w2, p[i3], w3);
+  }
+}
+
+// True adjoint (what interpolate_gpu.cu:121-148 intends): grad_points[b,c,i_t] += grad_out[b,c,j]*w_t.
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight, int C, int n,
+                                                                     int m, int c_per_block,
+                                                                     float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int *__restrict__ id = idx + ((size_t)b * n + j) * 3;
+  const float *__restrict__ w = weight + ((size_t)b * n + j) * 3;
+  const int i1 = id[0], i2 = id[1], i3 = id[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int c0 = blockIdx.y * c_per_block;
+  const int c1 = min(C, c0 + c_per_block);
+  for (int c = c0; c < c1; ++c) {
+    const float g = grad_out[((size_t)b * C + c) * n + j];
+    float *__restrict__ gp = grad_points + ((size_t)b * C + c) * m;
+    atomicAdd(gp + i1, g * w1);
+    atomicAdd(gp + i2, g * w2);
+    atomicAdd(gp + i3, g * w3);
+  }
+}
+
+int pick_c_per_block(int C, long long blocks_xz) {
+  int split = (int)((2048 + blocks_xz - 1) / blocks_xz);
+  if (split < 1) split = 1;
+  if (split > C) split = C;
+  return (C + split - 1) / split;
+}
+
+}  // namespace
+
+extern "C" int vlp3d_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist2, int *idx,
+                              void *stream) {
+  if (!unknown || !known || !dist2 || !idx || B < 1 || B > 65535 || n < 1 || m < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(vlp3d_cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, unknown, known,
+                     n, m, dist2, idx);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_three_interpolate(const float *points, const int *idx, const float *weight, int B, int C, int m,
+                                       int n, float *out, void *stream) {
+  if (!points || !idx || !weight || !out || B < 1 || B > 65535 || C < 1 || m < 1 || n < 1) return VLP3D_EINVAL;
+  const int gx = vlp3d_cdiv(n, 256);
+  const int cpb = pick_c_per_block(C, (long long)gx * B);
+  hipLaunchKernelGGL(three_interpolate_kernel, dim3(gx, vlp3d_cdiv(C, cpb), B), dim3(256), 0, (hipStream_t)stream,
+                     points, idx, weight, C, m, n, cpb, out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_three_interpolate_grad(const float *grad_out, const int *idx, const float *weight, int B, int C,
+                                            int n, int m, float *grad_points, void *stream) {
+  if (!grad_out || !idx || !weight || !grad_points || B < 1 || B > 65535 || C < 1 || m < 1 || n < 1)
+    return VLP3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * m, s);
+  if (e != hipSuccess) return (int)e;
+  const int gx = vlp3d_cdiv(n, 256);
+  const int cpb = pick_c_per_block(C, (long long)gx * B);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(gx, vlp3d_cdiv(C, cpb), B), dim3(256), 0, s, grad_out, idx,
+                     weight, C, n, m, cpb, grad_points);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

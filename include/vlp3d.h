@@ -1,0 +1,101 @@
+/*
+ * vlp3d.h — C ABI of libvlp3d_hip.so, the MI355X (gfx950) implementation of the
+ * 3DVLP point-cloud + language grounding hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's pybind module
+ * `pointnet2._ext` (lib/pointnet2/_ext_src/src/bindings.cpp:11-24) binds, plus the
+ * fused ops that replace Python-level hot loops.  Conventions (all entry points):
+ *   - plain device pointers + extents, `stream` is a hipStream_t passed as void*
+ *     (NULL = the null stream); the call only ENQUEUES work, it never synchronises;
+ *   - tensors are dense row-major ("contiguous") fp32 / int32 exactly as the
+ *     reference requires (include/utils.h:15-30);
+ *   - the CALLER owns every buffer, including scratch; the library allocates nothing
+ *     and keeps no mutable global state (re-entrant from any host thread);
+ *   - return value: 0 = enqueued; VLP3D_EINVAL (-22) = bad argument (nothing
+ *     enqueued); > 0 = a hipError_t from the launch.  The library never exits or
+ *     throws (the reference's CUDA_CHECK_ERRORS exit(-1)s: cuda_utils.h:35-44).
+ *   - outputs are fully written by the kernels; callers need not zero-fill them
+ *     (the reference's host wrappers torch::zeros() them) EXCEPT where noted
+ *     ("accumulates": the *_grad scatter ops zero the buffer themselves too).
+ *
+ * Index outputs (FPS / ball query / three_nn) are bit-exact with the reference's
+ * CUDA kernels under the fp32 evaluation order documented at vlp3d_fp_contract().
+ */
+#ifndef VLP3D_H
+#define VLP3D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLP3D_OK 0
+#define VLP3D_EINVAL (-22)
+
+/* ABI version, bumped on any signature change. */
+int vlp3d_abi_version(void);
+
+/* Which fp32 contraction the distance expressions were built with:
+ *   0: ((a*a)+(b*b))+(c*c)   1: fma(c,c, fma(a,a, b*b)) [default: what NVPTX emits under
+ *   nvcc's default -fmad=true for the reference's expression]   2: fma(c,c, fma(b,b, a*a)). */
+int vlp3d_fp_contract(void);
+
+/* ---- the nine pointnet2._ext ops -------------------------------------------------- */
+
+/* replaces furthest_point_sampling — sampling.cpp:70-91 / sampling_gpu.cu:74-234.
+ * xyz (B,N,3) f32; temp (B,N) f32 scratch (contents ignored on entry, unspecified on exit);
+ * idx (B,m) i32 out.  idx[:,0] = 0.  Same skip rule (|p|^2 <= 1e-3) and the same
+ * tie order as the reference's 512-thread LDS tree. */
+int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *temp, int *idx, void *stream);
+
+/* replaces gather_points — sampling.cpp:20-43. points (B,C,N), idx (B,M) -> out (B,C,M). */
+int vlp3d_gather_points(const float *points, const int *idx, int B, int C, int N, int M, float *out, void *stream);
+
+/* replaces gather_points_grad — sampling.cpp:45-69. grad_out (B,C,M) -> grad_points (B,C,N)
+ * (zeroed by the call, then scatter-added). */
+int vlp3d_gather_points_grad(const float *grad_out, const int *idx, int B, int C, int N, int M, float *grad_points,
+                             void *stream);
+
+/* replaces ball_query — ball_query.cpp:13-37 / ball_query_gpu.cu:14-59.
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample) i32: first nsample indices k (ascending)
+ * with d2 < radius*radius, padded with the first hit; all-zero row when there is none. */
+int vlp3d_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M, float radius, int nsample,
+                     int *idx, void *stream);
+
+/* replaces group_points — group_points.cpp:17-40. points (B,C,N), idx (B,M,S) -> out (B,C,M,S). */
+int vlp3d_group_points(const float *points, const int *idx, int B, int C, int N, int M, int S, float *out,
+                       void *stream);
+
+/* replaces group_points_grad — group_points.cpp:42-65. grad_out (B,C,M,S) -> grad_points (B,C,N)
+ * (zeroed by the call, then scatter-added). */
+int vlp3d_group_points_grad(const float *grad_out, const int *idx, int B, int C, int N, int M, int S,
+                            float *grad_points, void *stream);
+
+/* replaces three_nn — interpolate.cpp:19-45. unknown (B,n,3), known (B,m,3) ->
+ * dist2 (B,n,3) f32 SQUARED distances ascending, idx (B,n,3) i32. */
+int vlp3d_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist2, int *idx,
+                   void *stream);
+
+/* replaces three_interpolate — interpolate.cpp:47-75. points (B,C,m), idx (B,n,3), weight (B,n,3)
+ * -> out (B,C,n). */
+int vlp3d_three_interpolate(const float *points, const int *idx, const float *weight, int B, int C, int m, int n,
+                            float *out, void *stream);
+
+/* replaces three_interpolate_grad — interpolate.cpp:77-104 — with the TRUE adjoint that
+ * interpolate_gpu.cu:121-148 intends (the reference host function calls the forward wrapper by
+ * mistake, interpolate.cpp:95; DESIGN.md "known deviations").  grad_out (B,C,n) -> grad_points (B,C,m)
+ * (zeroed by the call, then scatter-added). */
+int vlp3d_three_interpolate_grad(const float *grad_out, const int *idx, const float *weight, int B, int C, int n,
+                                 int m, float *grad_points, void *stream);
+
+/* ---- fused ops replacing Python-level hot loops ------------------------------------ */
+
+/* replaces utils/nn_distance.py:32-59 without the (B,N,M,C) temporaries.
+ * pc1 (B,N,3), pc2 (B,M,3); mode 0 = squared L2, 1 = L1, 2 = Huber(delta).
+ * -> dist1 (B,N) f32, idx1 (B,N) i64, dist2 (B,M) f32, idx2 (B,M) i64 (first minimum wins). */
+int vlp3d_nn_distance(const float *pc1, const float *pc2, int B, int N, int M, int mode, float delta, float *dist1,
+                      long long *idx1, float *dist2, long long *idx2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLP3D_H */
