@@ -30,6 +30,9 @@ SIGNATURES = {
     "vlp3d_three_interpolate": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_three_interpolate_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_nn_distance": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                       _vp],
 }
 
 _lib = None
@@ -223,3 +226,42 @@ def nn_distance(pc1, pc2, mode, delta):
         _check(load().vlp3d_nn_distance(_p(pc1), _p(pc2), B, N, M, int(mode), float(delta), _p(dist1), _p(idx1),
                                         _p(dist2), _p(idx2), _stream()), "nn_distance")
     return dist1, idx1, dist2, idx2
+
+
+def _opt(t):
+    return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def sdpa_fwd(q, k, v, H, bias, bias_mode, mask):
+    """q (B,nq,H*32), k/v (B,nk,H*32) -> (out (B,nq,H*32), lse (B,H,nq))."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _chk_float(t, name)
+    _chk_dev(q, ("k", k), ("v", v))
+    B, nq, HD = q.shape
+    nk = k.shape[1]
+    if bias is not None:
+        _chk_float(bias, "attention_weights")
+        if tuple(bias.shape) != (B, H, nq, nk):
+            raise RuntimeError("attention_weights must be (b_s, h, nq, nk)")
+    if mask is not None:
+        _chk_float(mask, "attention_mask")
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(load().vlp3d_sdpa_fwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), B, H, nq, nk,
+                                     HD // H, _p(out), _p(lse), _stream()), "sdpa_fwd")
+    return out, lse
+
+
+def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias):
+    B, nq, HD = q.shape
+    nk = k.shape[1]
+    _chk_float(dout, "dout")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dbias = torch.empty((B, H, nq, nk), dtype=torch.float32, device=q.device) if need_dbias else None
+    delta = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(load().vlp3d_sdpa_bwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), _p(out), _p(lse),
+                                     _p(dout), B, H, nq, nk, HD // H, _p(dq), _p(dk), _p(dv), _opt(dbias),
+                                     _p(delta), _stream()), "sdpa_bwd")
+    return dq, dk, dv, dbias

@@ -1,0 +1,310 @@
+// Fused scaled-dot-product attention (forward + backward) for gfx950 — replaces the
+// att = softmax(QK^T/sqrt(dk) [+bias | *w] [mask]) ; out = att V core of the reference's
+// models/transformer/attention.py:63-75, which materialises att (b,h,nq,nk) in fp32 (67 MB per
+// self-attention layer at the grounding shapes), re-reads it for softmax and AV and keeps it for
+// backward.  Here nothing of size nq*nk touches memory (except the optional bias gradient).
+//
+// Shapes on the path: d_k = d_v = 32, h = 4, nq = 256, nk in {49, 256}: tiny per-head problems.
+// One WAVE owns a 32-row tile of one (batch, head) and walks the other dimension in 32-wide
+// tiles; all contractions run on the matrix cores with the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) so that the result stays within fp32 round-off of the reference.
+// The products are arranged "transposed" (S^T = K Q^T, lane = query) so that
+//   * the softmax row statistics are per-lane scalars (16 registers + one cross-half exchange),
+//   * an accumulator tile is directly the B operand of the next product (no LDS, no shuffles):
+//     MFMA step s of the second product sums over the row index that accumulator register s
+//     holds, rho(s,half) = (s&3) + 8*(s>>2) + 4*half, and the A operand is read with that same
+//     permutation of the summation index.
+// The summation index of the first product is permuted too (half h of the wave covers head
+// dims 16h..16h+15) so that every lane reads 64 contiguous bytes of its row.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 32;  // head dim (d_k == d_v)
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// row index held by accumulator register r of lane-half `half` (32x32 MFMA C/D layout)
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// 16 contiguous floats of a (.., H*D) row: elements [16*half, 16*half+16) of head `h`.
+__device__ __forceinline__ void load_half_row(const float *__restrict__ base, long long row, int HD, int h, int half,
+                                              float (&dst)[16]) {
+  const float4 *p = reinterpret_cast<const float4 *>(base + row * HD + h * D + half * 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 v = p[i];
+    dst[4 * i + 0] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+  }
+}
+
+// C(32x32) += A(32x32) * B(32x32)^T-style product where lane (r = lane&31, half) supplies
+// a[kk] = A[r][16*half+kk] and b[kk] = B[r][16*half+kk]:  C[i][j] = sum_d A[i][d] * B[j][d].
+__device__ __forceinline__ f32x16 mfma_rows(const float (&a)[16], const float (&b)[16], f32x16 c) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], c, 0, 0, 0);
+  return c;
+}
+
+// bias_mode: 0 none, 1 add, 2 mul.  Returns the pre-softmax score of (query, key) given raw = q.k * scale.
+__device__ __forceinline__ float apply_bias(float raw, int bias_mode, const float *__restrict__ bias,
+                                            long long off) {
+  if (bias_mode == 1) return raw + bias[off];
+  if (bias_mode == 2) return raw * bias[off];
+  return raw;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: wave = 32 queries of one (b,h); loop over key tiles; online softmax.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                      const float *__restrict__ v, const float *__restrict__ bias,
+                                                      int bias_mode, const float *__restrict__ mask, int H, int nq,
+                                                      int nk, float scale, float *__restrict__ out,
+                                                      float *__restrict__ lse) {
+  const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D;
+  const int qi = min(q0 + r, nq - 1);
+  const long long qrow = (long long)b * nq + qi;
+
+  float qreg[16];
+  load_half_row(q, qrow, HD, h, half, qreg);
+
+  f32x16 o = zero16();
+  float m = -__builtin_inff(), l = 0.f;
+  const long long bias_row = (((long long)b * H + h) * nq + qi) * nk;
+
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    float kreg[16];
+    load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), HD, h, half, kreg);
+    f32x16 s = mfma_rows(kreg, qreg, zero16());  // s[reg] = S[query r][key k0 + acc_row(reg, half)]
+
+    float tmax = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      float x = -__builtin_inff();
+      if (key < nk) {
+        x = apply_bias(s[i] * scale, bias_mode, bias, bias_row + key);
+        if (mask != nullptr && mask[(long long)b * nk + key] == 0.f) x = -10000.f;
+      }
+      s[i] = x;
+      tmax = fmaxf(tmax, x);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(s[i] - m_new);
+      s[i] = p;
+      psum += p;
+      o[i] *= alpha;
+    }
+    l = l * alpha + psum;
+    m = m_new;
+    // O^T[dim][query] += V^T[dim][key] * P^T[key][query]; step i sums over key k0 + acc_row(i, half)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = min(k0 + acc_row(i, half), nk - 1);  // p == 0 beyond nk
+      const float vv = v[((long long)b * nk + key) * HD + h * D + r];
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[i], o, 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32);
+  if (q0 + r < nq) {
+    const float inv = 1.f / l;
+    float *__restrict__ orow = out + qrow * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = dims 8g + 4*half + 0..3
+      float4 w;
+      w.x = o[4 * g + 0] * inv; w.y = o[4 * g + 1] * inv; w.z = o[4 * g + 2] * inv; w.w = o[4 * g + 3] * inv;
+      *reinterpret_cast<float4 *>(orow + 8 * g + 4 * half) = w;
+    }
+    if (half == 0) lse[((long long)b * H + h) * nq + q0 + r] = m + __logf(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 1: wave = 32 queries; writes dQ, delta = rowsum(dO*O) and (optionally) dbias.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, float scale,
+    float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
+  const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D;
+  const int qi = min(q0 + r, nq - 1);
+  const long long qrow = (long long)b * nq + qi;
+  const bool q_ok = q0 + r < nq;
+
+  float qreg[16], doreg[16], oreg[16];
+  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(dout, qrow, HD, h, half, doreg);
+  load_half_row(out, qrow, HD, h, half, oreg);
+  float dl = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dl += doreg[i] * oreg[i];
+  dl += __shfl_xor(dl, 32);
+  const long long stat = ((long long)b * H + h) * nq + qi;
+  if (q_ok && half == 0) delta[stat] = dl;
+  const float lse_q = lse[stat];
+  const long long bias_row = stat * nk;
+
+  f32x16 dqa = zero16();
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    float kreg[16], vreg[16];
+    const long long krow = (long long)b * nk + min(k0 + r, nk - 1);
+    load_half_row(k, krow, HD, h, half, kreg);
+    load_half_row(v, krow, HD, h, half, vreg);
+    f32x16 s = mfma_rows(kreg, qreg, zero16());    // S^T  [key][query]
+    f32x16 dp = mfma_rows(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      float ds = 0.f;
+      if (key < nk) {
+        const float raw = s[i] * scale;
+        float x = apply_bias(raw, bias_mode, bias, bias_row + key);
+        const bool masked = mask != nullptr && mask[(long long)b * nk + key] == 0.f;
+        if (masked) x = -10000.f;
+        const float p = __expf(x - lse_q);
+        ds = masked ? 0.f : p * (dp[i] - dl);  // d/d(pre-softmax score); masked_fill blocks the gradient
+        if (dbias != nullptr && q_ok) dbias[bias_row + key] = bias_mode == 2 ? ds * raw : ds;
+        if (bias_mode == 2) ds *= bias[bias_row + key];
+      }
+      s[i] = ds;
+    }
+    // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = min(k0 + acc_row(i, half), nk - 1);
+      const float kk = k[((long long)b * nk + key) * HD + h * D + r];
+      dqa = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, s[i], dqa, 0, 0, 0);
+    }
+  }
+  if (q_ok) {
+    float *__restrict__ row = dq + qrow * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = dqa[4 * g + 0] * scale; w.y = dqa[4 * g + 1] * scale; w.z = dqa[4 * g + 2] * scale;
+      w.w = dqa[4 * g + 3] * scale;
+      *reinterpret_cast<float4 *>(row + 8 * g + 4 * half) = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 2: wave = 32 keys; loops over query tiles; writes dK, dV (no atomics).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
+    const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nk, float scale,
+    float *__restrict__ dk, float *__restrict__ dv) {
+  const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
+  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D;
+  const int ki = min(k0 + r, nk - 1);
+  const long long krow = (long long)b * nk + ki;
+  const bool k_ok = k0 + r < nk;
+  const bool masked = mask != nullptr && mask[(long long)b * nk + ki] == 0.f;
+
+  float kreg[16], vreg[16];
+  load_half_row(k, krow, HD, h, half, kreg);
+  load_half_row(v, krow, HD, h, half, vreg);
+
+  f32x16 dka = zero16(), dva = zero16();
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    float qreg[16], doreg[16];
+    const long long qrow = (long long)b * nq + min(q0 + r, nq - 1);
+    load_half_row(q, qrow, HD, h, half, qreg);
+    load_half_row(dout, qrow, HD, h, half, doreg);
+    f32x16 s = mfma_rows(qreg, kreg, zero16());    // S  [query][key], lane = key
+    f32x16 dp = mfma_rows(doreg, vreg, zero16());  // dP [query][key]
+    f32x16 p;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = q0 + acc_row(i, half);
+      float pv = 0.f, ds = 0.f;
+      if (qq < nq && k_ok) {
+        const long long stat = ((long long)b * H + h) * nq + qq;
+        const float raw = s[i] * scale;
+        float x = apply_bias(raw, bias_mode, bias, stat * nk + ki);
+        if (masked) x = -10000.f;
+        pv = __expf(x - lse[stat]);
+        ds = masked ? 0.f : pv * (dp[i] - delta[stat]);
+        if (bias_mode == 2) ds *= bias[stat * nk + ki];
+      }
+      p[i] = pv;
+      s[i] = ds;
+    }
+    // dV^T[dim][key] += dO^T[dim][query] * P[query][key];  dK^T[dim][key] += Q^T[dim][query] * dS[query][key]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long row = ((long long)b * nq + min(q0 + acc_row(i, half), nq - 1)) * HD + h * D + r;
+      dva = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[row], p[i], dva, 0, 0, 0);
+      dka = __builtin_amdgcn_mfma_f32_32x32x2f32(q[row], s[i], dka, 0, 0, 0);
+    }
+  }
+  if (k_ok) {
+    float *__restrict__ rk = dk + krow * HD + h * D;
+    float *__restrict__ rv = dv + krow * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 a, c;
+      a.x = dka[4 * g + 0] * scale; a.y = dka[4 * g + 1] * scale; a.z = dka[4 * g + 2] * scale;
+      a.w = dka[4 * g + 3] * scale;
+      c.x = dva[4 * g + 0]; c.y = dva[4 * g + 1]; c.z = dva[4 * g + 2]; c.w = dva[4 * g + 3];
+      *reinterpret_cast<float4 *>(rk + 8 * g + 4 * half) = a;
+      *reinterpret_cast<float4 *>(rv + 8 * g + 4 * half) = c;
+    }
+  }
+}
+
+bool bad(int B, int H, int nq, int nk, int Dh, int bias_mode) {
+  return B < 1 || B > 65535 || H < 1 || H > 65535 || nq < 1 || nk < 1 || Dh != D || bias_mode < 0 || bias_mode > 2;
+}
+
+}  // namespace
+
+extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
+                              const float *mask, int B, int H, int nq, int nk, int Dh, float *out, float *lse,
+                              void *stream) {
+  if (!q || !k || !v || !out || !lse || bad(B, H, nq, nk, Dh, bias_mode) || (bias_mode != 0 && !bias))
+    return VLP3D_EINVAL;
+  const float scale = 1.0f / sqrtf((float)Dh);
+  hipLaunchKernelGGL(sdpa_fwd_kernel, dim3(vlp3d_cdiv(nq, 32), H, B), dim3(64), 0, (hipStream_t)stream, q, k, v, bias,
+                     bias_mode, mask, H, nq, nk, scale, out, lse);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
+                              const float *mask, const float *out, const float *lse, const float *dout, int B, int H,
+                              int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
+                              void *stream) {
+  if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta || bad(B, H, nq, nk, Dh, bias_mode) ||
+      (bias_mode != 0 && !bias))
+    return VLP3D_EINVAL;
+  const float scale = 1.0f / sqrtf((float)Dh);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3(vlp3d_cdiv(nq, 32), H, B), dim3(64), 0, s, q, k, v, bias, bias_mode, mask,
+                     out, lse, dout, H, nq, nk, scale, dq, dbias, delta);
+  hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3(vlp3d_cdiv(nk, 32), H, B), dim3(64), 0, s, q, k, v, bias, bias_mode,
+                     mask, lse, dout, delta, H, nq, nk, scale, dk, dv);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

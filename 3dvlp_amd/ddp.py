@@ -1,0 +1,47 @@
+"""Scene-level data parallelism: one process per GPU, ONE flat gradient all-reduce per step.
+
+The reference only has single-process nn.DataParallel (scripts/joint_scripts/train_3dvlp.py:124-126).
+Here every rank runs its own shard of scenes; gradients live as views into a single pre-zeroed flat
+fp32 buffer (so parameters that receive no gradient in a step — many do, SURVEY.md §5 — contribute
+zeros without any bookkeeping) and are summed with one RCCL all-reduce over xGMI (≈6 M elements =
+24 MB: latency-bound, so one bucket instead of many).  BatchNorm statistics stay per rank, exactly
+like the reference's DataParallel replicas.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    def __init__(self, module, process_group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.group = process_group
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the view
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self):
+        """Sum over ranks then average. No-op without an initialised process group."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(dist.get_world_size(self.group))
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """One-time parameter + buffer broadcast from rank `src` so that all replicas start identical."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=process_group)
+
+
+def shard_range(num_scenes, rank, world_size):
+    """Contiguous shard of scene ids for this rank (global batch = per-rank batch * world_size)."""
+    per = num_scenes // world_size
+    return rank * per, (rank + 1) * per

@@ -1,0 +1,280 @@
+"""Detection half of the grounding path: backbone, voting, vote clustering + ROI heads, relation module.
+
+Interfaces, shapes and state_dict keys follow the reference so that its callers (jointnet.py /
+refnet.py) and checkpoints work unchanged:
+  Pointnet2Backbone  — models/base_module/backbone_module.py:11-135
+  VotingModule       — models/base_module/voting_module.py:11-60
+  StandardROIHeads   — models/proposal_module/ROI_heads/roi_heads.py:15-147
+  ProposalModule     — models/proposal_module/proposal_module_fcos.py:21-144
+  RelationModule     — models/proposal_module/relation_module.py:9-139
+Differences that are deliberate: the box decode stays on the device (the reference
+round-trips through numpy inside forward, proposal_module_fcos.py:127-130), and the relation
+module's pairwise tensors are built by broadcasting instead of .repeat().
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from .transformer import MultiHeadAttention
+
+
+class Pointnet2Backbone(nn.Module):
+    """4 set-abstraction + 2 feature-propagation layers; reads/writes the reference's data_dict keys."""
+
+    def __init__(self, input_feature_dim=0):
+        super().__init__()
+        self.input_feature_dim = input_feature_dim
+        self.sa1 = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[input_feature_dim, 64, 64, 128],
+                                         use_xyz=True, normalize_xyz=True)
+        self.sa2 = PointnetSAModuleVotes(npoint=1024, radius=0.4, nsample=32, mlp=[128, 128, 128, 256],
+                                         use_xyz=True, normalize_xyz=True)
+        self.sa3 = PointnetSAModuleVotes(npoint=512, radius=0.8, nsample=16, mlp=[256, 128, 128, 256],
+                                         use_xyz=True, normalize_xyz=True)
+        self.sa4 = PointnetSAModuleVotes(npoint=256, radius=1.2, nsample=16, mlp=[256, 128, 128, 256],
+                                         use_xyz=True, normalize_xyz=True)
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., :3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, data_dict):
+        xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        xyz, features, fps_inds = self.sa1(xyz, features)
+        data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
+        xyz, features, fps_inds = self.sa2(xyz, features)
+        data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
+        xyz, features, fps_inds = self.sa3(xyz, features)
+        data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
+        xyz, features, fps_inds = self.sa4(xyz, features)
+        data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
+
+        features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
+                            data_dict["sa4_features"])
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+        data_dict["fp2_features"] = features
+        data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
+        num_seed = data_dict["fp2_xyz"].shape[1]
+        data_dict["fp2_inds"] = data_dict["sa1_inds"][:, 0:num_seed]  # indices into the input cloud
+        return data_dict
+
+
+class VotingModule(nn.Module):
+    """seed (xyz, features) -> vote (xyz + offset, features + residual)."""
+
+    def __init__(self, vote_factor, seed_feature_dim):
+        super().__init__()
+        self.vote_factor = vote_factor
+        self.in_dim = seed_feature_dim
+        self.out_dim = self.in_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv3 = nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+
+    def forward(self, seed_xyz, seed_features):
+        B, num_seed = seed_xyz.shape[:2]
+        num_vote = num_seed * self.vote_factor
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net).transpose(2, 1).reshape(B, num_seed, self.vote_factor, 3 + self.out_dim)
+        vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, num_vote, 3)
+        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
+        vote_features = vote_features.reshape(B, num_vote, self.out_dim).transpose(2, 1).contiguous()
+        return vote_xyz, vote_features
+
+
+class StandardROIHeads(nn.Module):
+    """2x (Conv1d 128 + BN + ReLU) then objectness / box / class / heading predictors."""
+
+    def __init__(self, num_heading_bin, num_class, seed_feat_dim=256, use_kl_loss=False):
+        super().__init__()
+        self.num_heading_bin = num_heading_bin
+        self.num_class = num_class
+        self.use_kl_loss = use_kl_loss
+        convs = [nn.Conv1d(128, 128, kernel_size=1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                 nn.Conv1d(128, 128, kernel_size=1), nn.BatchNorm1d(128), nn.ReLU(inplace=True)]
+        self.convs = nn.Sequential(*convs)
+        self.objectness_predictor = nn.Conv1d(128, 2, kernel_size=1)
+        if self.use_kl_loss:
+            self.alpha_predictor = nn.Conv1d(128, 6, kernel_size=1)
+            self.alpha_activation = nn.Sigmoid()
+        self.box_predictor = nn.Conv1d(128, 6, kernel_size=1)
+        if self.num_class:
+            self.sem_cls_predictor = nn.Conv1d(128, num_class, kernel_size=1)
+        self.heading_cls_predictor = nn.Conv1d(128, num_heading_bin, kernel_size=1)
+        self.heading_reg_predictor = nn.Conv1d(128, num_heading_bin, kernel_size=1)
+        for layer in convs:
+            if isinstance(layer, nn.Conv1d):
+                nn.init.kaiming_normal_(layer.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(layer.bias, 0)
+        for predictor in (self.objectness_predictor, self.box_predictor):
+            nn.init.normal_(predictor.weight, std=0.001)
+            nn.init.constant_(predictor.bias, 0)
+
+    def forward(self, ROI_features, data_dict):
+        x = self.convs(ROI_features)
+        if self.use_kl_loss:
+            data_dict["alpha"] = self.alpha_activation(self.alpha_predictor(x).permute(0, 2, 1)) * 0.1 - 0.05
+        heading_reg = self.heading_reg_predictor(x).permute(0, 2, 1)
+        if self.num_class:
+            data_dict["sem_cls_scores"] = self.sem_cls_predictor(x).permute(0, 2, 1)
+        data_dict["heading_scores"] = self.heading_cls_predictor(x).permute(0, 2, 1)
+        data_dict["heading_residuals_normalized"] = heading_reg
+        data_dict["heading_residuals"] = heading_reg * (np.pi / self.num_heading_bin)
+        data_dict["rois"] = self.box_predictor(x).permute(0, 2, 1).exp()  # distances to the 6 faces
+        data_dict["objectness_scores"] = self.objectness_predictor(x).permute(0, 2, 1)
+        data_dict["bbox_mask"] = data_dict["objectness_scores"].argmax(-1)
+        return data_dict
+
+
+# corner signs of utils/box_util.py:361-385 (get_3d_box_batch): x = +-l/2, y = +-w/2, z = +-h/2
+_CORNER_SIGNS = ((1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1), (1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1))
+
+
+def box_corners(box_size, heading, center):
+    """Device restatement of get_3d_box_batch (utils/box_util.py:361-385), which rotates with
+    roty_batch (:324-338): corners = (signs * size/2) @ R^T + center, R = [[c,0,s],[0,1,0],[-s,0,c]].
+    box_size (...,3), heading (...), center (...,3) -> (...,8,3)."""
+    signs = torch.tensor(_CORNER_SIGNS, dtype=box_size.dtype, device=box_size.device)
+    local = signs * (box_size.unsqueeze(-2) * 0.5)  # (...,8,3)
+    c, s = torch.cos(heading).unsqueeze(-1), torch.sin(heading).unsqueeze(-1)
+    x, y, z = local[..., 0], local[..., 1], local[..., 2]
+    rotated = torch.stack([c * x + s * z, y, -s * x + c * z], dim=-1)
+    return rotated + center.unsqueeze(-2)
+
+
+class ProposalModule(nn.Module):
+    """Vote clustering (an SA layer on the votes) + ROI heads + box decode."""
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal, sampling,
+                 seed_feat_dim=256, mask_box=False, use_kl_loss=False, use_vote_weight=False):
+        super().__init__()
+        self.num_class, self.num_heading_bin, self.num_size_cluster = num_class, num_heading_bin, num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_proposal, self.sampling, self.seed_feat_dim = num_proposal, sampling, seed_feat_dim
+        self.mask_box, self.use_kl_loss, self.use_vote_weight = mask_box, use_kl_loss, use_vote_weight
+        self.vote_aggregation = PointnetSAModuleVotes(npoint=self.num_proposal, radius=0.3, nsample=16,
+                                                      mlp=[self.seed_feat_dim, 128, 128, 128], use_xyz=True,
+                                                      normalize_xyz=True)
+        self.proposal = StandardROIHeads(num_heading_bin=num_heading_bin, num_class=num_class, seed_feat_dim=256,
+                                         use_kl_loss=self.use_kl_loss)
+        if self.use_vote_weight:
+            self.votes_weight_predictor = nn.Sequential(nn.Conv1d(256, 128, kernel_size=1), nn.BatchNorm1d(128),
+                                                        nn.PReLU(), nn.Conv1d(128, 1, kernel_size=1), nn.Sigmoid())
+
+    def forward(self, xyz, features, data_dict):
+        if self.use_vote_weight:
+            data_dict["vote_weights"] = self.votes_weight_predictor(features)
+            features = features * data_dict["vote_weights"]
+        xyz, features, fps_inds = self.vote_aggregation(xyz, features)
+        data_dict["aggregated_vote_xyz"] = xyz
+        data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
+        data_dict["aggregated_vote_inds"] = fps_inds
+        data_dict = self.proposal(features, data_dict)
+        return self.decode_scores(data_dict)
+
+    def decode_pred_box(self, data_dict):
+        agg_xyz = data_dict["aggregated_vote_xyz"]
+        heading_class = torch.argmax(data_dict["heading_scores"], -1)
+        heading_residual = torch.gather(data_dict["heading_residuals"], 2, heading_class.unsqueeze(-1))
+        rois = data_dict["rois"]
+        pred_heading = heading_class.float() * (2.0 * np.pi / self.num_heading_bin) + heading_residual[..., 0]
+        data_dict["pred_heading"] = pred_heading
+        pred_box_size = rois[:, :, 0:3] + rois[:, :, 3:6]
+        # centre = vote - rotz(heading)-rotated half-difference of the face distances (:113-120):
+        # row-vector v @ R with R = [[c,-s,0],[s,c,0],[0,0,1]]
+        half = (rois[:, :, 0:3] - rois[:, :, 3:6]) / 2
+        c, s = torch.cos(pred_heading), torch.sin(pred_heading)
+        off = torch.stack([half[..., 0] * c + half[..., 1] * s, -half[..., 0] * s + half[..., 1] * c, half[..., 2]], -1)
+        pred_center = agg_xyz - off
+        if self.mask_box and self.training:
+            pred_center, pred_box_size = self.mask(pred_center, pred_box_size)
+        data_dict["pred_size"] = pred_box_size
+        data_dict["pred_center"] = pred_center
+        data_dict["pred_bbox_corner"] = box_corners(pred_box_size.detach(), pred_heading.detach(),
+                                                    pred_center.detach())
+        return data_dict
+
+    def decode_scores(self, data_dict):
+        data_dict = self.decode_pred_box(data_dict)
+        data_dict["pred_bbox_feature"] = data_dict["aggregated_vote_features"]
+        data_dict["pred_bbox_mask"] = data_dict["objectness_scores"].argmax(-1)
+        data_dict["pred_bbox_sems"] = data_dict["sem_cls_scores"].argmax(-1)
+        return data_dict
+
+    def mask(self, pred_center, pred_box_size):
+        """Randomly replace 30 % of the boxes (:146-165); train-time augmentation, off by default."""
+        B, K, _ = pred_center.shape
+        dev = pred_center.device
+        m = torch.bernoulli(torch.full([B, K], 0.3, device=dev)).bool()[:, :, None]
+        rc = torch.randn([B, K, 3], device=dev) / 2
+        rs = 1 + torch.randn([B, K, 3], device=dev)
+        return torch.where(m, rc, pred_center), torch.where(m, rs, pred_box_size)
+
+
+class RelationModule(nn.Module):
+    """2 layers of proposal self-attention with an additive pairwise-geometry bias."""
+
+    def __init__(self, num_proposals=256, hidden_size=128, lang_num_size=300, det_channel=128, head=4, depth=2):
+        super().__init__()
+        self.use_box_embedding = True
+        self.use_dist_weight_matrix = True
+        self.use_obj_embedding = True
+        self.num_proposals, self.hidden_size, self.depth = num_proposals, hidden_size, depth
+        self.features_concat = nn.Sequential(nn.Conv1d(det_channel, hidden_size, 1), nn.BatchNorm1d(hidden_size),
+                                             nn.PReLU(hidden_size), nn.Conv1d(hidden_size, hidden_size, 1))
+        self.self_attn_fc = nn.ModuleList(
+            nn.Sequential(nn.Linear(4, 32), nn.ReLU(), nn.LayerNorm(32), nn.Linear(32, 32), nn.ReLU(),
+                          nn.LayerNorm(32), nn.Linear(32, 4)) for _ in range(depth))
+        self.self_attn = nn.ModuleList(
+            MultiHeadAttention(d_model=hidden_size, d_k=hidden_size // head, d_v=hidden_size // head, h=head)
+            for _ in range(depth))
+        self.bbox_embedding = nn.ModuleList(nn.Linear(27, hidden_size) for _ in range(depth))
+        self.obj_embedding = nn.ModuleList(nn.Linear(128, hidden_size) for _ in range(depth))
+
+    def forward(self, data_dict):
+        features = self.features_concat(data_dict["pred_bbox_feature"].permute(0, 2, 1)).permute(0, 2, 1)
+        B, K = features.shape[:2]
+        corners = data_dict["pred_bbox_corner"]
+
+        # pairwise geometry (layer-independent): delta[b,i,j] = centre_j - centre_i, plus its norm
+        centre = corners.mean(dim=-2)
+        delta = centre[:, None, :, :] - centre[:, :, None, :]
+        pair = torch.cat([delta, delta.pow(2).sum(-1, keepdim=True).sqrt()], dim=-1).detach()  # (B,K,K,4)
+
+        # "multiview feature of the proposal's source point" (:98-113).  REFERENCE QUIRK, reproduced
+        # exactly because trained checkpoints depend on it: the reference offsets the per-batch point
+        # ids by b*128 (obj_feat.shape[1] AFTER its permute = the channel count, not N) and takes ROWS OF
+        # 128 CONSECUTIVE ELEMENTS of the channel-major (B,128,N) copy, so "row id" is the flat element
+        # range [id*128, id*128+128) of that layout.  Same values here, without the 164 MB copy.
+        pc = data_dict["point_clouds"]
+        N = pc.shape[1]
+        seed_inds = data_dict["seed_inds"].long()
+        src = torch.gather(seed_inds, 1, data_dict["aggregated_vote_inds"].long())  # (B,K)
+        row_id = src + torch.arange(B, device=src.device)[:, None] * 128
+        flat = row_id.unsqueeze(-1) * 128 + torch.arange(128, device=src.device)  # (B,K,128) into (B,128,N)
+        fb, rem = flat // (128 * N), flat % (128 * N)
+        obj_feat = pc[fb, rem % N, 6 + rem // N]
+
+        cmin, cmax = corners.min(dim=2)[0], corners.max(dim=2)[0]
+        box_centre = (cmin + cmax) / 2
+        manual_bbox_feat = torch.cat([box_centre, (corners - box_centre[:, :, None, :]).reshape(B, K, -1)], -1).float()
+
+        dist_weights = None
+        for i in range(self.depth):
+            dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)  # (B,4,K,K) additive bias
+            features = features + self.obj_embedding[i](obj_feat) * 0.1
+            features = features + self.bbox_embedding[i](manual_bbox_feat)
+            features = self.self_attn[i](features, features, features, attention_weights=dist_weights, way="add")
+
+        data_dict["dist_weights"] = dist_weights
+        data_dict["attention_matrix_way"] = "add"
+        data_dict["bbox_feature"] = features
+        return data_dict

@@ -1,0 +1,181 @@
+"""Language-grounding half of the path: proposal<->token matching and the OCC/OSC contrastive losses.
+
+  MatchModule    — models/refnet/match_module.py:10-170 (2x CrossAttentionDecoderLayer + match MLP)
+  ContrastModule — models/constrast_module/constrast_module.py:9-131 (NCELoss :24-37)
+State-dict keys follow the reference (unused sub-modules such as lang_emb_proj / box_con_proj are kept
+for checkpoint compatibility).
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
+
+
+class MatchModule(nn.Module):
+    def __init__(self, num_proposals=256, lang_size=256, hidden_size=128, lang_num_size=300, det_channel=128, head=4,
+                 use_lang_emb=False, use_pc_encoder=False, use_match_con_loss=False, depth=2, use_reg_head=False):
+        super().__init__()
+        self.num_proposals, self.lang_size, self.hidden_size = num_proposals, lang_size, hidden_size
+        self.use_lang_emb, self.use_pc_encoder, self.depth = use_lang_emb, use_pc_encoder, depth
+        self.use_reg_head = use_reg_head
+        self.match = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.GELU(), nn.Dropout(p=0.5, inplace=False),
+                                   nn.Linear(hidden_size, hidden_size), nn.GELU(), nn.Dropout(p=0.5, inplace=False),
+                                   nn.Linear(hidden_size, 1))
+        if self.use_reg_head:
+            self.reg_head = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.GELU(),
+                                          nn.Linear(hidden_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.GELU(),
+                                          nn.Linear(hidden_size, 6), nn.Sigmoid())
+        self.lang_emb_proj = nn.Sequential(nn.Conv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size),
+                                           nn.PReLU(), nn.Conv1d(hidden_size, hidden_size, 1),
+                                           nn.BatchNorm1d(hidden_size), nn.PReLU(),
+                                           nn.Conv1d(hidden_size, num_proposals, 1))
+        self.grounding_cross_attn = nn.ModuleList(
+            CrossAttentionDecoderLayer(hidden_size=hidden_size) for _ in range(self.depth))
+        self.lang_emb_cross_attn = MultiHeadAttention(d_model=hidden_size, d_k=hidden_size // head,
+                                                      d_v=hidden_size // head, h=head)
+        self.loss_fn = nn.CrossEntropyLoss()
+        self.box_con_proj = nn.Linear(hidden_size, hidden_size)
+        self.lang_con_proj = nn.Linear(hidden_size, hidden_size)
+        self.temp = nn.Parameter(torch.ones([]) * 0.07)
+        self.use_match_con_loss = use_match_con_loss
+
+    @staticmethod
+    def _copy_paste(features, objectness_masks):
+        """Train-time augmentation (:97-121): background proposals of scene i are overwritten with
+        object features taken from the (twice repeated) batch-wide list of object proposals, starting
+        after scene i's own objects.  Host-driven (data-dependent sizes), as in the reference."""
+        B, K = features.shape[:2]
+        feature0 = features.clone()
+        obj_masks = objectness_masks.bool().squeeze(2)
+        obj_lens = obj_masks.sum(1).tolist()
+        pool = features.reshape(B * K, -1)[obj_masks.reshape(-1)].repeat(2, 1)
+        total_len = int(sum(obj_lens))
+        j = 0
+        for i in range(B):
+            bg = torch.where(~obj_masks[i])[0]
+            j += obj_lens[i]
+            take = min(bg.shape[0], total_len - obj_lens[i])
+            feature0[i, bg[:take], :] = pool[j:j + take, :]
+        return feature0
+
+    def forward(self, data_dict):
+        objectness_masks = data_dict["objectness_scores"].max(2)[1].float().unsqueeze(2)
+        features = data_dict["bbox_feature"]  # (B, K, hidden)
+        B, K = features.shape[:2]
+        L = data_dict["input_ids"].shape[1]
+        data_dict["random"] = random.random()
+
+        feature0 = features.clone()
+        if data_dict["istrain"][0] == 1 and data_dict["random"] < 0.5:
+            feature0 = self._copy_paste(features, objectness_masks)
+
+        feature1 = feature0[:, None, :, :].expand(B, L, K, feature0.shape[-1]).reshape(B * L, K, -1)
+        lang_fea = data_dict["lang_fea"][:, 1:]  # K/V = the tokens after [CLS]
+
+        for layer in self.grounding_cross_attn:
+            feature1 = layer(feature1, lang_fea, lang_fea)  # (B*L, K, hidden)
+        data_dict["cross_box_feature"] = feature1
+
+        feature1_agg = feature1.reshape(B * L * K, -1)
+        confidence = self.match(feature1_agg).squeeze(1).view(B * L, K)
+
+        if self.use_lang_emb:
+            lang_emb = data_dict["lang_emb"]
+            lang_num_max = lang_emb.shape[0] // B
+            lang_emb_feature = self.lang_emb_cross_attn(lang_emb.view(B, lang_num_max, -1), feature0, feature0)
+            lang_emb_feature = lang_emb_feature.view(B * lang_num_max, -1, 1).contiguous()
+            confidence = confidence + self.lang_emb_proj(lang_emb_feature).squeeze(2)
+        data_dict["cluster_ref"] = confidence
+
+        if self.use_reg_head:
+            box_reg = (self.reg_head(feature1_agg) * 0.1 - 0.05).view(B, L, K, 6)
+            data_dict["pred_center_reg"], data_dict["pred_size_reg"] = box_reg[..., 0:3], box_reg[..., 3:6]
+        return data_dict
+
+
+def axis_aligned_iou(center1, size1, center2, size2):
+    """Closed-form IoU of axis-aligned boxes, broadcasting over leading dims.  Stands in for
+    pytorch3d.ops.box3d_overlap (constrast_module.py:105) whose inputs are always axis aligned
+    (create_box_batch :9-15); value-identical to the `iou` of utils/box_util.py:488-529."""
+    lo = torch.max(center1 - size1 / 2, center2 - size2 / 2)
+    hi = torch.min(center1 + size1 / 2, center2 + size2 / 2)
+    inter = torch.clamp(hi - lo, min=0).prod(-1)
+    return inter / (size1.prod(-1) + size2.prod(-1) - inter)
+
+
+class NCELoss(nn.Module):
+    """Holds the (unused, :32-33 commented out) temperature so that checkpoints load."""
+
+    def __init__(self, init_tau=0.07, clamp=4.6051):
+        super().__init__()
+        self.tau = nn.Parameter(torch.tensor([np.log(1.0 / init_tau)], dtype=torch.float32))
+        self.clamp = clamp
+
+
+class ContrastModule(nn.Module):
+    """OCC (sentence vs proposals) and OSC (proposal vs proposal) InfoNCE, all (scene, sentence) pairs
+    at once instead of the reference's Python double loop with host syncs.
+
+    Semantics copied literally (SURVEY.md §7 hard part 4): no temperature; SoftCrossEntropy is the MEAN
+    over all elements of -log_softmax * target (:18-21); for OCC the (1,P) logits make the transposed
+    term vanish, so OCC = loss_v / 2; for OSC the logits are symmetric so loss_t == loss_v; targets are
+    hard IoU > 0.25 masks against the GT box grown by 1e-2; only proposals whose objectness argmax is 1
+    take part; sums over sentences are divided by batch_size; a no-op before epoch 50.
+    `config` supplies mean_size_arr (decode of the GT size, model_util_scannet.py:183-190).
+    """
+
+    def __init__(self, config, hidden=128):
+        super().__init__()
+        self.pc_proj = nn.Linear(hidden, hidden, bias=False)
+        self.text_proj = nn.Linear(hidden, hidden, bias=False)
+        self.nce_loss = NCELoss()
+        self.config = config
+        self.bce_loss = nn.BCEWithLogitsLoss()
+        self.pc_proj_iou = nn.Sequential(nn.Linear(hidden, hidden, bias=False))
+
+    def forward(self, data_dict):
+        if data_dict["epoch"] < 50:
+            data_dict["con_loss"] = torch.zeros(1)
+            return data_dict
+        pred_center = data_dict["pred_center"].detach()
+        pred_size = data_dict["pred_size"].detach()
+        features = data_dict["bbox_feature"]  # (B,K,hidden)
+        B, K = features.shape[:2]
+        gt_center = data_dict["ref_center_label_list"].detach()[..., 0:3]  # (B,L,3)
+        L = gt_center.shape[1]
+        mean_size = torch.as_tensor(self.config.mean_size_arr, dtype=torch.float32, device=features.device)
+        gt_size = mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
+        lang_emb = data_dict["lang_emb"].view(B, -1, data_dict["lang_emb"].shape[-1])[:, :L]
+        obj = data_dict["objectness_scores"].max(2)[1].float()  # (B,K) 1 = takes part
+        P = obj.sum(1)  # (B,) proposals taking part
+        lang_ok = (torch.arange(L, device=features.device)[None, :] < data_dict["lang_num"][:, None]).float()
+        lang_ok = lang_ok * (P > 0).float()[:, None]  # the reference's try/except skips empty scenes
+
+        ious = axis_aligned_iou(gt_center[:, :, None, :], gt_size[:, :, None, :] + 1e-2, pred_center[:, None, :, :],
+                                pred_size[:, None, :, :])  # (B,L,K)
+        target = (ious > 0.25).float() * obj[:, None, :]
+        neg_inf = -1e30  # excluded columns; their log-probabilities are zeroed before use (0 * -inf = NaN)
+        Psafe = P.clamp(min=1)
+
+        # OCC: sim (B,L,K) over the participating proposals
+        text = F.normalize(self.text_proj(lang_emb), dim=-1)
+        box = F.normalize(self.pc_proj(features), dim=-1)
+        sim = torch.einsum("bld,bkd->blk", text, box).masked_fill(obj[:, None, :] == 0, neg_inf)
+        logp = F.log_softmax(sim, dim=-1).masked_fill(obj[:, None, :] == 0, 0.0)
+        loss_v = -(logp * target).sum(-1) / Psafe[:, None]  # mean over the (1,P) row
+        lang_con_loss = (0.5 * loss_v * lang_ok).sum() / B
+
+        # OSC: sim (B,K,K) among participating proposals, target = outer(mask, mask)
+        boxi = F.normalize(self.pc_proj_iou(features), dim=-1)
+        simi = torch.einsum("bkd,bjd->bkj", boxi, boxi).masked_fill(obj[:, None, :] == 0, neg_inf)
+        nls = -F.log_softmax(simi, dim=-1).masked_fill(obj[:, None, :] == 0, 0.0)  # excluded columns -> 0
+        quad = torch.einsum("blk,bkj,blj->bl", target, nls, target) / (Psafe * Psafe)[:, None]
+        iou_con_loss = (quad * lang_ok).sum() / B
+
+        data_dict["lang_con_loss"] = lang_con_loss
+        data_dict["iou_con_loss"] = iou_con_loss
+        return data_dict

@@ -1,0 +1,164 @@
+"""The grounding hot path end to end: network graph, reduced loss, one optimisation step.
+
+GroundingNet is the hot-path subset of the reference's JointNet (models/jointnet/jointnet.py:112-220):
+backbone -> voting (+L2 norm) -> proposal (vote clustering, ROI heads, decode) -> relation -> match
+(proposal<->token cross-attention) -> contrast (OCC/OSC).  Sub-module attribute names equal JointNet's
+(backbone_net, vgen, proposal, relation, match, constrast) so that a reference checkpoint's keys map
+1:1.  The frozen BERT encoder (`lang`, out of scope) is replaced by its outputs `lang_fea`/`lang_emb`
+in the data_dict.
+
+`grounding_loss` is a REDUCED form of lib/loss_helper/loss_joint.py:26-227 (the full detection +
+grounding loss stack is the "next" row §8f-1): vote loss and objectness loss as in
+loss_detection.py:24-110 (both consume nn_distance), a centre/size regression of the assigned
+proposals, the reference cross-entropy over cluster_ref, and 0.5*OCC + 2.5*OSC (loss_joint.py:208).
+"""
+import importlib
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import synth
+from .ddp import FlatGradBucket
+from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
+from .grounding import ContrastModule, MatchModule
+from .nn_distance import huber_loss, nn_distance
+
+FAR_THRESHOLD = 0.6   # loss_detection.py:19-23
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3
+OBJECTNESS_CLS_WEIGHTS = (0.2, 0.8)
+
+
+class GroundingNet(nn.Module):
+    def __init__(self, num_class=18, num_heading_bin=1, num_size_cluster=18, mean_size_arr=None,
+                 input_feature_dim=132, num_proposal=256, vote_factor=1, sampling="vote_fps", use_con=True):
+        super().__init__()
+        mean_size_arr = synth.mean_size_arr() if mean_size_arr is None else mean_size_arr
+        assert mean_size_arr.shape[0] == num_size_cluster
+        self.num_class, self.num_heading_bin, self.num_size_cluster = num_class, num_heading_bin, num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.dataset_config = SimpleNamespace(mean_size_arr=mean_size_arr, num_heading_bin=num_heading_bin,
+                                              num_size_cluster=num_size_cluster, num_class=num_class)
+        self.use_con = use_con
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=input_feature_dim)
+        self.vgen = VotingModule(vote_factor, 256)
+        self.proposal = ProposalModule(num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal,
+                                       sampling)
+        self.relation = RelationModule(num_proposals=num_proposal, det_channel=128)
+        if use_con:
+            self.constrast = ContrastModule(config=self.dataset_config)
+        self.match = MatchModule(num_proposals=num_proposal, lang_size=256, det_channel=128)
+
+    def forward(self, data_dict):
+        data_dict = self.backbone_net(data_dict)
+        xyz, features = data_dict["fp2_xyz"], data_dict["fp2_features"]
+        data_dict["seed_inds"], data_dict["seed_xyz"], data_dict["seed_features"] = data_dict["fp2_inds"], xyz, features
+        xyz, features = self.vgen(xyz, features)
+        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        data_dict["vote_xyz"], data_dict["vote_features"] = xyz, features
+        data_dict = self.proposal(xyz, features, data_dict)
+        data_dict = self.relation(data_dict)
+        data_dict = self.match(data_dict)
+        if self.use_con:
+            data_dict = self.constrast(data_dict)
+        return data_dict
+
+
+def compute_vote_loss(d):
+    """loss_detection.py:24-72."""
+    B, S = d["seed_xyz"].shape[:2]
+    seed_inds = d["seed_inds"].long()
+    mask = torch.gather(d["vote_label_mask"], 1, seed_inds).float()
+    gt_votes = torch.gather(d["vote_label"], 1, seed_inds.unsqueeze(-1).expand(-1, -1, 3 * GT_VOTE_FACTOR))
+    gt_votes = gt_votes + d["seed_xyz"].repeat(1, 1, 3)
+    _, _, dist2, _ = nn_distance(d["vote_xyz"].reshape(B * S, -1, 3), gt_votes.reshape(B * S, GT_VOTE_FACTOR, 3),
+                                 l1=True)
+    votes_dist = dist2.min(dim=1)[0].view(B, S)
+    return torch.sum(votes_dist * mask) / (torch.sum(mask) + 1e-6)
+
+
+def compute_objectness_loss(d):
+    """loss_detection.py:74-110."""
+    agg = d["aggregated_vote_xyz"]
+    gt_center = d["center_label"][:, :, 0:3]
+    dist1, ind1, _, _ = nn_distance(agg, gt_center)
+    euc = torch.sqrt(dist1 + 1e-6)
+    label = (euc < NEAR_THRESHOLD).long()
+    mask = ((euc < NEAR_THRESHOLD) | (euc > FAR_THRESHOLD)).float()
+    w = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=agg.device)
+    ce = F.cross_entropy(d["objectness_scores"].float().transpose(2, 1), label, weight=w, reduction="none")
+    return torch.sum(ce * mask) / (torch.sum(mask) + 1e-6), label, mask, ind1
+
+
+def grounding_loss(d, mean_size_arr):
+    vote_loss = compute_vote_loss(d)
+    obj_loss, obj_label, _, assign = compute_objectness_loss(d)
+    B, K = obj_label.shape
+    # regression of the assigned GT centre (proposals near an object only)
+    gt_center = torch.gather(d["center_label"][:, :, 0:3], 1, assign.unsqueeze(-1).expand(-1, -1, 3))
+    pos = obj_label.float()
+    center_loss = (huber_loss(d["pred_center"] - gt_center, 0.15).sum(-1) * pos).sum() / (pos.sum() + 1e-6)
+    size_loss = (d["pred_size"].mean(-1) * 0.0).sum()  # keeps the size head in the graph
+    # reference loss: the proposal nearest to the referred GT centre is the target of cluster_ref
+    L = d["ref_center_label_list"].shape[1]
+    ref_c = d["ref_center_label_list"][..., 0:3]  # (B,L,3)
+    dist = ((d["pred_center"].detach()[:, None, :, :] - ref_c[:, :, None, :]) ** 2).sum(-1)  # (B,L,K)
+    target = dist.argmin(-1).reshape(B * L)
+    ref_loss = F.cross_entropy(d["cluster_ref"].float(), target)
+    loss = vote_loss + 0.1 * obj_loss + center_loss + size_loss + 0.3 * ref_loss
+    if "lang_con_loss" in d:
+        loss = loss + 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]  # loss_joint.py:208
+    d["loss"] = loss
+    return loss
+
+
+def batch_to_device(batch, device):
+    out = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
+    out["istrain"] = [1]
+    return out
+
+
+class GroundingStep:
+    """Owns model + optimiser + flat gradient bucket; `run(batch)` = fwd + loss + bwd + all-reduce + AdamW."""
+
+    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0):
+        torch.manual_seed(seed)
+        self.device = device
+        self.model = GroundingNet().to(device)
+        self.model.train()
+        self.bucket = FlatGradBucket(self.model)
+        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
+        self.epoch = epoch
+        self.autocast_dtype = autocast_dtype
+
+    def forward_loss(self, batch):
+        d = dict(batch)
+        d["epoch"] = self.epoch
+        if self.autocast_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+                d = self.model(d)
+        else:
+            d = self.model(d)
+        return grounding_loss(d, self.model.mean_size_arr), d
+
+    def run(self, batch):
+        self.bucket.zero()
+        loss, d = self.forward_loss(batch)
+        loss.backward()
+        self.bucket.all_reduce()
+        self.opt.step()
+        return loss
+
+
+def smoke_step():
+    """One tiny forward+backward of the whole path on cuda:0 (called by __graft_entry__.smoke)."""
+    dev = torch.device("cuda:0")
+    step = GroundingStep(dev)
+    batch = batch_to_device(synth.make_batch(0, 2, num_points=8192, lang_num_max=2), dev)
+    loss = step.run(batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    print("smoke step loss", float(loss.detach()))

@@ -45,6 +45,10 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
     def forward(self, xyz, features=None, inds=None):
+        # geometry and the gather kernels are fp32-only (like the reference's CHECK_IS_FLOAT); under
+        # autocast the previous layer hands over bf16 activations
+        xyz = xyz.float()
+        features = features.float() if features is not None else None
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
@@ -82,6 +86,7 @@ class PointnetFPModule(nn.Module):
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
+        known_feats = known_feats.float()
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

@@ -1,0 +1,120 @@
+"""Attention blocks of the grounding path with the reference's interface and state_dict layout.
+
+Mirrors models/transformer/attention.py (ScaledDotProductAttention :6-78, MultiHeadAttention :81-131)
+and models/transformer/mmattention.py (PositionwiseFeedForward :36-50, CrossAttentionDecoderLayer
+:53-86).  The projections / FFN are plain library GEMMs; the softmax(QK^T/sqrt(dk) [+bias]) V core
+runs in the fused HIP kernel (``impl='hip'``, the default: no (B,h,nq,nk) matrix is materialised).
+``impl='torch'`` is the unfused formulation, kept ONLY as an explicit opt-in for host-logic unit
+tests and A/B numerics — it is never selected automatically.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import fused_attention
+
+DEFAULT_IMPL = "hip"
+
+
+class ScaledDotProductAttention(nn.Module):
+    """out = fc_o(softmax(fc_q(q) fc_k(k)^T / sqrt(d_k) [+|* weights] [masked]) fc_v(v))."""
+
+    def __init__(self, d_model, d_k, d_v, h, impl=None):
+        super().__init__()
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
+        self.impl = impl
+        for fc in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.constant_(fc.bias, 0)
+
+    def forward(self, queries, keys, values, attention_mask=None, attention_weights=None, way="add",
+                need_att=True):
+        """queries (b,nq,d_model), keys/values (b,nk,d_model); attention_mask broadcastable to
+        (b,h,nq,nk) with 0 = masked (filled with -10000); attention_weights (b,h,nq,nk).
+        Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran)."""
+        b_s, nq = queries.shape[:2]
+        nk = keys.shape[1]
+        q = self.fc_q(queries)
+        k = self.fc_k(keys)
+        v = self.fc_v(values)
+        if way not in ("add", "mul"):
+            raise NotImplementedError(way)
+        impl = self.impl or DEFAULT_IMPL
+        if impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk):
+            out = fused_attention.sdpa(q.float(), k.float(), v.float(), self.h,
+                                       None if attention_weights is None else attention_weights.float(), way,
+                                       attention_mask)
+            return self.fc_o(out), None
+        if impl == "hip" and not q.is_cuda:
+            raise RuntimeError("CPU not supported (impl='hip'); pass impl='torch' explicitly for host-side tests")
+        q = q.view(b_s, nq, self.h, self.d_k).permute(0, 2, 1, 3)
+        k = k.view(b_s, nk, self.h, self.d_k).permute(0, 2, 3, 1)
+        v = v.view(b_s, nk, self.h, self.d_v).permute(0, 2, 1, 3)
+        att = torch.matmul(q, k) / np.sqrt(self.d_k)
+        if attention_weights is not None:
+            att = att * attention_weights if way == "mul" else att + attention_weights
+        if attention_mask is not None:
+            att = att.masked_fill(attention_mask == 0, -10000)
+        att = torch.softmax(att, -1)
+        out = torch.matmul(att, v).permute(0, 2, 1, 3).contiguous().view(b_s, nq, self.h * self.d_v)
+        return self.fc_o(out), att
+
+
+class MultiHeadAttention(nn.Module):
+    """SDPA -> dropout -> LayerNorm(queries + out)  (post-LN; attention.py:108-131).
+    `identity_map_reordering` / stateful decoding are not used on the grounding path."""
+
+    def __init__(self, d_model, d_k, d_v, h, dropout=.1, identity_map_reordering=False, impl=None):
+        super().__init__()
+        self.identity_map_reordering = identity_map_reordering
+        self.attention = ScaledDotProductAttention(d_model=d_model, d_k=d_k, d_v=d_v, h=h, impl=impl)
+        self.dropout = nn.Dropout(p=dropout)
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, queries, keys, values, attention_mask=None, attention_weights=None, way="add",
+                output_attn=False):
+        if self.identity_map_reordering:
+            q_norm, k_norm, v_norm = (self.layer_norm(t) for t in (queries, keys, values))
+            out, att = self.attention(q_norm, k_norm, v_norm, attention_mask, attention_weights, way,
+                                      need_att=output_attn)
+            out = queries + self.dropout(torch.relu(out))
+        else:
+            out, att = self.attention(queries, keys, values, attention_mask, attention_weights, way,
+                                      need_att=output_attn)
+            out = self.layer_norm(queries + self.dropout(out))
+        return (out, att) if output_attn else out
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, hidden, drop_prob=0.1):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, hidden)
+        self.linear2 = nn.Linear(hidden, d_model)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(p=drop_prob)
+
+    def forward(self, x):
+        return self.linear2(self.dropout(self.relu(self.linear1(x))))
+
+
+class CrossAttentionDecoderLayer(nn.Module):
+    """self-attention -> proposal<->token cross-attention -> FFN, each followed by add & norm."""
+
+    def __init__(self, ffn_hidden=256, hidden_size=128, head=4, drop_prob=.1, impl=None):
+        super().__init__()
+        dk = hidden_size // head
+        self.self_attention = MultiHeadAttention(d_model=hidden_size, d_k=dk, d_v=dk, h=head, impl=impl)
+        self.enc_dec_attention = MultiHeadAttention(d_model=hidden_size, d_k=dk, d_v=dk, h=head, impl=impl)
+        self.ffn = PositionwiseFeedForward(d_model=hidden_size, hidden=ffn_hidden, drop_prob=drop_prob)
+        self.norm = nn.LayerNorm(hidden_size)
+        self.dropout = nn.Dropout(p=drop_prob)
+        self.head = head
+
+    def forward(self, query, key, value, src_mask=None, src_trg_mask=None):
+        x = self.self_attention(query, query, query, attention_mask=src_mask)
+        x = self.enc_dec_attention(x, key, value, attention_mask=src_trg_mask)
+        return self.norm(self.dropout(self.ffn(x)) + x)

@@ -1,0 +1,64 @@
+"""world_size-2 CPU (gloo) test of the data-parallel path: flat gradient bucket + one all-reduce."""
+import importlib
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    torch.manual_seed(rank)  # replicas start different on purpose
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    unused = torch.nn.Linear(2, 2)  # never used in forward: must still be reduced (as zeros)
+    model.add_module("unused", unused)
+    ddp.broadcast_parameters(model)
+    bucket = ddp.FlatGradBucket(model)
+    lo, hi = ddp.shard_range(8, rank, world)
+    torch.manual_seed(123)
+    x = torch.randn(8, 6)
+    bucket.zero()
+    model[2](model[1](model[0](x[lo:hi]))).pow(2).mean().backward()
+    bucket.all_reduce()
+    # single-process reference: gradient of the mean over BOTH shards with the same (broadcast) weights
+    import copy
+    full = copy.deepcopy(model)
+    for p in full.parameters():
+        p.grad = None
+    full[2](full[1](full[0](x))).pow(2).mean().backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in full.parameters()])
+    ret[rank] = (model[0].weight.detach().clone(), bucket.flat.clone(), model.unused.weight.grad.clone(), ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    (w0, g0, u0, r0), (w1, g1, u1, r1) = ret[0], ret[1]
+    assert torch.equal(w0, w1)          # parameter broadcast
+    assert torch.allclose(g0, g1)       # identical averaged gradients on both ranks
+    assert (u0 == 0).all() and (u1 == 0).all()
+    assert torch.allclose(g0, r0, atol=1e-6) and torch.allclose(g1, r1, atol=1e-6)  # == full-batch gradient
+
+
+def test_shard_range_covers_batch():
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    spans = [ddp.shard_range(64, r, 8) for r in range(8)]
+    assert spans[0] == (0, 8) and spans[-1] == (56, 64)
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
