@@ -30,6 +30,16 @@ SIGNATURES = {
     "vlp3d_three_interpolate": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_three_interpolate_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_nn_distance": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "vlp3d_group_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "vlp3d_group_rows_grad": [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "vlp3d_sa_fwd_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_fwd_layer": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_pool": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "vlp3d_sa_pool_grad": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp],
+    "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
+    "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                       _i, _f, _vp, _i, _vp],
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _vp],
@@ -265,3 +275,44 @@ def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias):
                                      _p(dout), B, H, nq, nk, HD // H, _p(dq), _p(dk), _p(dv), _opt(dbias),
                                      _p(delta), _stream()), "sdpa_bwd")
     return dq, dk, dv, dbias
+
+
+def group_rows(xyz, new_xyz, idx, feat_pm, radius, out_dtype):
+    """-> (B*M*S, C+4) rows [features | (xyz[idx]-new_xyz)/radius | 0] in out_dtype (float32 / bfloat16)."""
+    _chk_float(xyz, "xyz")
+    _chk_float(new_xyz, "new_xyz")
+    _chk_int(idx, "idx")
+    _chk_float(feat_pm, "features")
+    _chk_dev(xyz, ("new_xyz", new_xyz), ("idx", idx), ("features", feat_pm))
+    B, N, _ = xyz.shape
+    _, M, S = idx.shape
+    C = feat_pm.shape[2]
+    if tuple(feat_pm.shape) != (B, N, C) or C % 4:
+        raise RuntimeError("group_rows: features must be point-major (B,N,C) with C % 4 == 0")
+    out = torch.empty((B * M * S, C + 4), dtype=out_dtype, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(load().vlp3d_group_rows(_p(xyz), _p(new_xyz), _p(idx), _p(feat_pm), B, N, M, S, C, float(radius),
+                                       _p(out), int(out_dtype == torch.bfloat16), _stream()), "group_rows")
+    return out
+
+
+def group_rows_grad(dout, idx, B, N, C, radius, need_feat, need_xyz, need_new_xyz):
+    _, M, S = idx.shape
+    if not dout.is_contiguous() or dout.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("group_rows_grad: dout must be a contiguous float/bfloat16 tensor")
+    dev = dout.device
+    dfeat = torch.empty((B, N, C), dtype=torch.float32, device=dev) if need_feat else None
+    dxyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if need_xyz else None
+    dnew = torch.empty((B, M, 3), dtype=torch.float32, device=dev) if need_new_xyz else None
+    with torch.cuda.device(dev):
+        _check(load().vlp3d_group_rows_grad(_p(dout), int(dout.dtype == torch.bfloat16), _p(idx), B, N, M, S, C,
+                                            float(radius), _opt(dfeat), _opt(dxyz), _opt(dnew), _stream()),
+               "group_rows_grad")
+    return dfeat, dxyz, dnew
+
+
+def call(name, *args):
+    """Raw checked call of a C entry point on torch's current stream (stream appended automatically).
+    Tensors are passed as pointers, None as NULL; ints/floats as they are."""
+    conv = [(_opt(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    _check(getattr(load(), name)(*conv, _stream()), name)

@@ -1,0 +1,562 @@
+// Grouped per-ball MLP of a set-abstraction layer on the matrix cores — replaces, for
+// PointnetSAModuleVotes.forward (lib/pointnet2/pointnet2_modules.py:233-267), the sequence
+// group_points x2 -> sub/div -> cat -> 3 x (1x1 conv -> BatchNorm2d -> ReLU) -> max_pool over nsample
+// (and its autograd backward), each of which round-trips a (B,C,npoint,nsample) tensor through HBM.
+//
+// Everything is a product over ROWS r = (b*npoint + m)*nsample + s of row-major matrices:
+//     Y_l (R x Cout) = A_{l-1} (R x K) * W_l^T,   A_l = relu(bn_l(Y_l)),   A_0 = gathered [features | xyz | 0]
+// One kernel template `row_gemm` does every such product.  A wave owns 32 rows; both MFMA operands are
+// 16-byte row slices read straight from memory (lane = row for A, lane = output column for W), so there is
+// no LDS staging and no layout shuffle:
+//   * the A operand is produced by a LOADER that applies the preceding element-wise stage on the fly:
+//       GATHER  rows of the point-major feature tensor through the ball-query indices (+ local xyz),
+//       BNRELU  relu(y*scale + shift) of the previous layer's pre-activations (training-mode BN folded into
+//               per-channel scale/shift once its batch statistics are known),
+//       BNBWD   the BatchNorm backward formula dY = k1*(g - k2 - yhat*k3) from the stored masked gradient g;
+//   * the EPILOGUE consumes the accumulators in registers:
+//       STORE   write Y_l and accumulate the per-channel sum / sum of squares (BN batch statistics, fp64),
+//       MASK    ReLU-mask the propagated gradient with the saved pre-activation, accumulate the two BN-backward
+//               reductions, store g_{l-1},
+//       SCATTER add the input gradient rows to d(features) (point-major, contiguous atomics) and d(xyz).
+// `wgrad` computes dW_l = sum_r dY_l[r]^T A_{l-1}[r] (split over row chunks, fp32 MFMA, coalesced row reads)
+// and `pool` takes the max over nsample through the monotone BN+ReLU (max or min of Y by the sign of the scale).
+// T = float uses v_mfma_f32_32x32x2_f32 (exact fp32: parity path); T = bf16 uses v_mfma_f32_32x32x16_bf16.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __hip_bfloat16 bf16;
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const bf16 *p) {
+  const uint2 u = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16 *p) { return __bfloat162float(*p); }
+__device__ __forceinline__ void st1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16 *p, float v) { *p = __float2bfloat16(v); }
+__device__ __forceinline__ short bf16_bits(float v) {
+  bf16 h = __float2bfloat16(v);
+  return *reinterpret_cast<short *>(&h);
+}
+
+enum Loader { GATHER = 0, BNRELU = 1, BNBWD = 2, PLAIN = 3 };
+enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2 };
+
+// Per-column constants, all fp32 vectors of length >= K (loader) / >= COUT (epilogue).
+struct RowGemmArgs {
+  // GATHER
+  const float *xyz, *new_xyz, *feat_pm;
+  const int *idx;
+  int N, M, S, C;
+  float radius;
+  // BNRELU / BNBWD / PLAIN: source matrices (R x ldin)
+  const void *Yin, *Gin;
+  int ldin;
+  const float *scale, *shift;            // BNRELU: a = relu(y*scale + shift)
+  const float *rstd, *nmean_rstd;        // BNBWD: yhat = y*rstd + nmean_rstd
+  const float *k1, *k2, *k3;             // BNBWD: dy = k1*(g - k2 - yhat*k3)
+  // weight (COUT x K) row-major, K % (8 or 16) == 0
+  const void *W;
+  int K;
+  long long R;
+  // STORE
+  void *Yout;
+  int ldout;
+  double *stats;  // [2][COUT]: sum, sum of squares
+  // MASK: previous layer's pre-activation (R x ldprev) + its BN scale/shift/rstd/nmean_rstd (length COUT)
+  const void *Yprev;
+  int ldprev;
+  const float *p_scale, *p_shift, *p_rstd, *p_nmean_rstd;
+  double *tstats;  // [2][COUT]: sum g, sum g*yhat
+  // SCATTER
+  float *dfeat_pm, *dxyz, *dnew_xyz;
+};
+
+template <typename T, int LOADER>
+__device__ __forceinline__ float4 load_a4(const RowGemmArgs &a, long long row, int col0, long long gather_base,
+                                          long long xyz_base, long long centre_base) {
+  if (LOADER == GATHER) {
+    if (col0 < a.C) return ld4(a.feat_pm + gather_base + col0);
+    if (col0 == a.C) {
+      const float *q = a.xyz + xyz_base;
+      const float *c = a.new_xyz + centre_base;
+      return make_float4((q[0] - c[0]) / a.radius, (q[1] - c[1]) / a.radius, (q[2] - c[2]) / a.radius, 0.f);
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4 y = ld4(reinterpret_cast<const T *>(a.Yin) + row * a.ldin + col0);
+  if (LOADER == PLAIN) return y;
+  if (LOADER == BNRELU) {
+    const float4 sc = ld4(a.scale + col0), sh = ld4(a.shift + col0);
+    return make_float4(fmaxf(0.f, y.x * sc.x + sh.x), fmaxf(0.f, y.y * sc.y + sh.y), fmaxf(0.f, y.z * sc.z + sh.z),
+                       fmaxf(0.f, y.w * sc.w + sh.w));
+  }
+  // BNBWD
+  const float4 g = ld4(reinterpret_cast<const T *>(a.Gin) + row * a.ldin + col0);
+  const float4 rs = ld4(a.rstd + col0), nm = ld4(a.nmean_rstd + col0);
+  const float4 k1 = ld4(a.k1 + col0), k2 = ld4(a.k2 + col0), k3 = ld4(a.k3 + col0);
+  return make_float4(k1.x * (g.x - k2.x - (y.x * rs.x + nm.x) * k3.x), k1.y * (g.y - k2.y - (y.y * rs.y + nm.y) * k3.y),
+                     k1.z * (g.z - k2.z - (y.z * rs.z + nm.z) * k3.z), k1.w * (g.w - k2.w - (y.w * rs.w + nm.w) * k3.w));
+}
+
+// acc[ct] (32 rows x 32 cols) += A(32 x G) * W[32ct..32ct+32][G]^T for one K-group of G columns.
+template <typename T, int NCT>
+struct Mma;
+
+template <int NCT>
+struct Mma<float, NCT> {
+  static constexpr int G = 8;  // lane half h covers columns 8g+4h .. +3 (4 k-steps of the 32x32x2 MFMA)
+  template <int LOADER>
+  static __device__ __forceinline__ void step(const RowGemmArgs &a, f32x16 (&acc)[NCT], int g, int r, int half,
+                                              long long row, long long gb, long long xb, long long cb) {
+    const int col0 = 8 * g + 4 * half;
+    const float4 av = load_a4<float, LOADER>(a, row, col0, gb, xb, cb);
+    const float *W = reinterpret_cast<const float *>(a.W);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 bv = ld4(W + (long long)(32 * ct + r) * a.K + col0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[ct], 0, 0, 0);
+    }
+  }
+};
+
+template <int NCT>
+struct Mma<bf16, NCT> {
+  static constexpr int G = 16;  // lane half h covers columns 16g+8h .. +7 (one 32x32x16 MFMA)
+  template <int LOADER>
+  static __device__ __forceinline__ void step(const RowGemmArgs &a, f32x16 (&acc)[NCT], int g, int r, int half,
+                                              long long row, long long gb, long long xb, long long cb) {
+    const int col0 = 16 * g + 8 * half;
+    const float4 a0 = load_a4<bf16, LOADER>(a, row, col0, gb, xb, cb);
+    const float4 a1 = load_a4<bf16, LOADER>(a, row, col0 + 4, gb, xb, cb);
+    bf16x8 av;
+    av[0] = bf16_bits(a0.x); av[1] = bf16_bits(a0.y); av[2] = bf16_bits(a0.z); av[3] = bf16_bits(a0.w);
+    av[4] = bf16_bits(a1.x); av[5] = bf16_bits(a1.y); av[6] = bf16_bits(a1.z); av[7] = bf16_bits(a1.w);
+    const bf16 *W = reinterpret_cast<const bf16 *>(a.W);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(W + (long long)(32 * ct + r) * a.K + col0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ct], 0, 0, 0);
+    }
+  }
+};
+
+template <typename T, int COUT, int LOADER, int EPI>
+__global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
+  constexpr int NCT = COUT / 32;
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ntiles = a.R / 32;
+
+  double s1[NCT], s2[NCT];  // per-lane (column) running reductions of the epilogue
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) s1[ct] = s2[ct] = 0.0;
+
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const long long row = tile * 32 + r;
+    long long gb = 0, xb = 0, cb = 0;
+    if (LOADER == GATHER) {
+      const long long bm = row / a.S, b = bm / a.M;
+      const long long p = a.idx[row];
+      gb = (b * a.N + p) * a.C;
+      xb = (b * a.N + p) * 3;
+      cb = bm * 3;
+    }
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
+    const int ngroups = a.K / Mma<T, NCT>::G;
+    for (int g = 0; g < ngroups; ++g) Mma<T, NCT>::template step<LOADER>(a, acc, g, r, half, row, gb, xb, cb);
+
+    // ---- epilogue: acc[ct][i] is element (row = tile*32 + acc_row(i,half), col = 32ct + r) ----
+    if (EPI == STORE) {
+      T *Y = reinterpret_cast<T *>(a.Yout);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[ct][i];
+          st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, v);
+          ps += v;
+          pq += v * v;
+        }
+        s1[ct] += (double)ps;
+        s2[ct] += (double)pq;
+      }
+    } else if (EPI == MASK) {
+      T *G = reinterpret_cast<T *>(a.Yout);
+      const T *Yp = reinterpret_cast<const T *>(a.Yprev);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 32 * ct + r;
+        const float sc = a.p_scale[col], sh = a.p_shift[col], rs = a.p_rstd[col], nm = a.p_nmean_rstd[col];
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long long rr = tile * 32 + acc_row(i, half);
+          const float y = ld1(Yp + rr * a.ldprev + col);
+          const float g = (y * sc + sh > 0.f) ? acc[ct][i] : 0.f;
+          st1(G + rr * a.ldout + col, g);
+          ps += g;
+          pq += g * (y * rs + nm);
+        }
+        s1[ct] += (double)ps;
+        s2[ct] += (double)pq;
+      }
+    } else {  // SCATTER: columns [0,C) -> d(features), [C,C+3) -> d(xyz), the rest is padding
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long long rr = tile * 32 + acc_row(i, half);
+        const long long bm = rr / a.S, b = bm / a.M;
+        const long long p = a.idx[rr];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int col = 32 * ct + r;
+          const float v = acc[ct][i];
+          if (col < a.C) {
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + (b * a.N + p) * a.C + col, v);
+          } else if (col < a.C + 3) {
+            const float gv = v / a.radius;
+            if (a.dxyz) atomicAdd(a.dxyz + (b * a.N + p) * 3 + (col - a.C), gv);
+            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + bm * 3 + (col - a.C), -gv);
+          }
+        }
+      }
+    }
+  }
+
+  if (EPI == STORE || EPI == MASK) {
+    double *out = (EPI == STORE) ? a.stats : a.tstats;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const double t1 = s1[ct] + __shfl_xor(s1[ct], 32);
+      const double t2 = s2[ct] + __shfl_xor(s2[ct], 32);
+      if (half == 0) {
+        atomicAdd(out + 32 * ct + r, t1);
+        atomicAdd(out + COUT + 32 * ct + r, t2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pool: out[bm][c] = relu(sel*scale + shift), sel = max_s Y (scale >= 0) or min_s Y (scale < 0);
+// sel_idx[bm][c] = first s attaining it (the row the gradient is routed to, like max_pool2d).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ Y, int ld, int S, int C, long long BM,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   float *__restrict__ out, unsigned char *__restrict__ sel_idx) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= BM * C) return;
+  const long long bm = t / C;
+  const int c = (int)(t - bm * C);
+  const float sc = scale[c];
+  float best = ld1(Y + (bm * S) * ld + c);
+  int bi = 0;
+  for (int s = 1; s < S; ++s) {
+    const float v = ld1(Y + (bm * S + s) * ld + c);
+    const bool better = sc >= 0.f ? (v > best) : (v < best);
+    if (better) { best = v; bi = s; }
+  }
+  out[t] = fmaxf(0.f, best * sc + shift[c]);
+  sel_idx[t] = (unsigned char)bi;
+}
+
+// G3[(bm*S + s)][c] = (s == sel_idx[bm][c] && out[bm][c] > 0) ? dP[bm][c] : 0   (max-pool + ReLU backward)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_grad_kernel(const float *__restrict__ dP, const float *__restrict__ out,
+                                                        const unsigned char *__restrict__ sel_idx, int S, int C,
+                                                        long long BM, T *__restrict__ G) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= BM * S * C) return;
+  const long long row = t / C;
+  const int c = (int)(t - row * C);
+  const long long bm = row / S;
+  const int s = (int)(row - bm * S);
+  const long long o = bm * C + c;
+  st1(G + t, (sel_idx[o] == s && out[o] > 0.f) ? dP[o] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[c][k] = sum_r dY[r][c] * A[r][k]   (COUT x K), fp32 MFMA, rows split over workgroups.
+// MFMA step = 2 rows: A-operand lane (c = 32ct + r) reads dY[row 2kk+half][c], B-operand lane
+// (k = 32kt + r) reads A[row 2kk+half][k]: both are coalesced 128-byte row segments.
+// dY and A come through the same element-wise loaders as row_gemm (scalar form).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LOADER>
+__device__ __forceinline__ float load_a1(const RowGemmArgs &a, long long row, int col) {
+  if (LOADER == GATHER) {
+    const long long bm = row / a.S, b = bm / a.M;
+    const long long p = a.idx[row];
+    if (col < a.C) return a.feat_pm[(b * a.N + p) * a.C + col];
+    if (col < a.C + 3) return (a.xyz[(b * a.N + p) * 3 + col - a.C] - a.new_xyz[bm * 3 + col - a.C]) / a.radius;
+    return 0.f;
+  }
+  const float y = ld1(reinterpret_cast<const T *>(a.Yin) + row * a.ldin + col);
+  if (LOADER == PLAIN) return y;
+  return fmaxf(0.f, y * a.scale[col] + a.shift[col]);  // BNRELU
+}
+
+struct WgradArgs {
+  RowGemmArgs src;       // loader of A_{l-1} (GATHER or BNRELU), K = src.K columns
+  const void *Y, *G;     // this layer's pre-activation and masked gradient (R x ld)
+  int ld;
+  const float *rstd, *nmean_rstd, *k1, *k2, *k3;  // BN backward constants of this layer (length COUT)
+  float *dW;             // (COUT x K) fp32, zeroed by the caller
+  long long rows_per_block;
+};
+
+template <typename T, int COUT, int LOADER>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
+  constexpr int NCT = COUT / 32;            // c-tiles, distributed over the 4 waves
+  constexpr int CT_PER_WAVE = (NCT + 3) / 4;
+  constexpr int KT_PER_BLOCK = 3;           // k-tiles handled by one workgroup (blockIdx.y selects the group)
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = w.src.K;
+  const int kt0 = blockIdx.y * KT_PER_BLOCK;
+  const long long row0 = (long long)blockIdx.x * w.rows_per_block;
+  const long long row1 = min(w.src.R, row0 + w.rows_per_block);
+
+  f32x16 acc[CT_PER_WAVE][KT_PER_BLOCK];
+  float rs[CT_PER_WAVE], nm[CT_PER_WAVE], k1[CT_PER_WAVE], k2[CT_PER_WAVE], k3[CT_PER_WAVE];
+  bool ct_ok[CT_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < CT_PER_WAVE; ++i) {
+    const int ct = wave + 4 * i;
+    ct_ok[i] = ct < NCT;
+    const int c = min(32 * ct + r, COUT - 1);
+    rs[i] = w.rstd[c]; nm[i] = w.nmean_rstd[c]; k1[i] = w.k1[c]; k2[i] = w.k2[c]; k3[i] = w.k3[c];
+#pragma unroll
+    for (int j = 0; j < KT_PER_BLOCK; ++j) acc[i][j] = zero16();
+  }
+  const T *Y = reinterpret_cast<const T *>(w.Y);
+  const T *G = reinterpret_cast<const T *>(w.G);
+
+  for (long long rr = row0 + half; rr < row1; rr += 2) {
+    float bv[KT_PER_BLOCK];
+#pragma unroll
+    for (int j = 0; j < KT_PER_BLOCK; ++j) {
+      const int k = 32 * (kt0 + j) + r;
+      bv[j] = k < K ? load_a1<T, LOADER>(w.src, rr, k) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CT_PER_WAVE; ++i) {
+      if (!ct_ok[i]) continue;  // wave-uniform
+      const int c = 32 * (wave + 4 * i) + r;
+      const float y = ld1(Y + rr * w.ld + c), g = ld1(G + rr * w.ld + c);
+      const float dy = k1[i] * (g - k2[i] - (y * rs[i] + nm[i]) * k3[i]);
+#pragma unroll
+      for (int j = 0; j < KT_PER_BLOCK; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy, bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CT_PER_WAVE; ++i) {
+    if (!ct_ok[i]) continue;
+#pragma unroll
+    for (int j = 0; j < KT_PER_BLOCK; ++j) {
+      const int k = 32 * (kt0 + j) + r;
+      if (k >= K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = 32 * (wave + 4 * i) + acc_row(e, half);
+        atomicAdd(w.dW + (long long)c * K + k, acc[i][j][e]);
+      }
+    }
+  }
+}
+
+unsigned grid_tiles(long long R) {
+  const long long blocks = (R / 32 + 3) / 4;
+  const long long cap = 256 * 4;  // a few persistent workgroups per CU; each wave walks tiles with a grid stride
+  return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+template <typename T, int LOADER, int EPI>
+int launch_row_gemm_t(int cout, const RowGemmArgs &a, hipStream_t s) {
+  const dim3 grid(grid_tiles(a.R)), block(256);
+  switch (cout) {
+    case 32: hipLaunchKernelGGL((row_gemm_kernel<T, 32, LOADER, EPI>), grid, block, 0, s, a); break;
+    case 64: hipLaunchKernelGGL((row_gemm_kernel<T, 64, LOADER, EPI>), grid, block, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((row_gemm_kernel<T, 128, LOADER, EPI>), grid, block, 0, s, a); break;
+    case 160: hipLaunchKernelGGL((row_gemm_kernel<T, 160, LOADER, EPI>), grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((row_gemm_kernel<T, 256, LOADER, EPI>), grid, block, 0, s, a); break;
+    case 288: hipLaunchKernelGGL((row_gemm_kernel<T, 288, LOADER, EPI>), grid, block, 0, s, a); break;
+    default: return VLP3D_EINVAL;
+  }
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+template <typename T>
+int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStream_t s) {
+  if (loader == GATHER && epi == STORE) return launch_row_gemm_t<T, GATHER, STORE>(cout, a, s);
+  if (loader == BNRELU && epi == STORE) return launch_row_gemm_t<T, BNRELU, STORE>(cout, a, s);
+  if (loader == BNBWD && epi == MASK) return launch_row_gemm_t<T, BNBWD, MASK>(cout, a, s);
+  if (loader == BNBWD && epi == SCATTER) return launch_row_gemm_t<T, BNBWD, SCATTER>(cout, a, s);
+  return VLP3D_EINVAL;
+}
+
+template <typename T, int LOADER>
+int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
+  const long long nblk = (w.src.R + w.rows_per_block - 1) / w.rows_per_block;
+  const dim3 grid((unsigned)nblk, (unsigned)((w.src.K + 95) / 96)), block(256);
+  switch (cout) {
+    case 32: hipLaunchKernelGGL((wgrad_kernel<T, 32, LOADER>), grid, block, 0, s, w); break;
+    case 64: hipLaunchKernelGGL((wgrad_kernel<T, 64, LOADER>), grid, block, 0, s, w); break;
+    case 128: hipLaunchKernelGGL((wgrad_kernel<T, 128, LOADER>), grid, block, 0, s, w); break;
+    case 256: hipLaunchKernelGGL((wgrad_kernel<T, 256, LOADER>), grid, block, 0, s, w); break;
+    default: return VLP3D_EINVAL;
+  }
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+}  // namespace
+
+// ---- C ABI -----------------------------------------------------------------------------------------
+// `bf16` selects the storage/MFMA type of Y / G / W (0: fp32, 1: bf16).  Per-channel vectors are fp32.
+
+extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm,
+                                   int B, int N, int M, int S, int C, float radius, const void *W, int K, int cout,
+                                   void *Y, double *stats, int bf16_io, void *stream) {
+  if (!xyz || !new_xyz || !idx || !feat_pm || !W || !Y || !stats || B < 1 || N < 1 || M < 1 || S < 1 || C < 4 ||
+      (C & 3) || K < C + 4 || (K % (bf16_io ? 16 : 8)) || (((long long)B * M * S) & 31))
+    return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feat_pm = feat_pm;
+  a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
+  a.W = W; a.K = K; a.R = (long long)B * M * S; a.Yout = Y; a.ldout = cout; a.stats = stats;
+  return bf16_io ? launch_row_gemm<bf16>(GATHER, STORE, cout, a, (hipStream_t)stream)
+                 : launch_row_gemm<float>(GATHER, STORE, cout, a, (hipStream_t)stream);
+}
+
+extern "C" int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const float *scale, const float *shift,
+                                  const void *W, int cout, void *Y, double *stats, int bf16_io, void *stream) {
+  if (!Yin || !scale || !shift || !W || !Y || !stats || R < 32 || (R & 31) || (K % (bf16_io ? 16 : 8)))
+    return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.Yin = Yin; a.ldin = K; a.scale = scale; a.shift = shift;
+  a.W = W; a.K = K; a.R = R; a.Yout = Y; a.ldout = cout; a.stats = stats;
+  return bf16_io ? launch_row_gemm<bf16>(BNRELU, STORE, cout, a, (hipStream_t)stream)
+                 : launch_row_gemm<float>(BNRELU, STORE, cout, a, (hipStream_t)stream);
+}
+
+extern "C" int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift,
+                             float *out, unsigned char *sel_idx, int bf16_io, void *stream) {
+  if (!Y || !scale || !shift || !out || !sel_idx || BM < 1 || S < 1 || S > 255 || C < 1) return VLP3D_EINVAL;
+  const long long total = BM * C;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (bf16_io)
+    hipLaunchKernelGGL((pool_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16 *)Y, C, S, C, BM, scale,
+                       shift, out, sel_idx);
+  else
+    hipLaunchKernelGGL((pool_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float *)Y, C, S, C, BM, scale,
+                       shift, out, sel_idx);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *sel_idx, long long BM, int S,
+                                  int C, void *G, int bf16_io, void *stream) {
+  if (!dP || !out || !sel_idx || !G || BM < 1 || S < 1 || C < 1) return VLP3D_EINVAL;
+  const long long total = BM * S * C;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (bf16_io)
+    hipLaunchKernelGGL((pool_grad_kernel<bf16>), grid, block, 0, (hipStream_t)stream, dP, out, sel_idx, S, C, BM,
+                       (bf16 *)G);
+  else
+    hipLaunchKernelGGL((pool_grad_kernel<float>), grid, block, 0, (hipStream_t)stream, dP, out, sel_idx, S, C, BM,
+                       (float *)G);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// dA_{l-1} = dY_l * W_l   (WT = W_l^T, (K_prev x COUT_l) row-major), dY_l = BN-backward(G_l, Y_l).
+// bn5 = [rstd | nmean_rstd | k1 | k2 | k3] of layer l (5 x ld); prev4 = [scale | shift | rstd | nmean_rstd] of
+// layer l-1 (4 x kprev).  Writes G_{l-1} (R x kprev) and accumulates tstats (2 x kprev).
+extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT,
+                                  int kprev, const void *Yprev, const float *prev4, void *Gprev, double *tstats,
+                                  int bf16_io, void *stream) {
+  if (!G || !Y || !bn5 || !WT || !Yprev || !prev4 || !Gprev || !tstats || R < 32 || (R & 31) ||
+      (ld % (bf16_io ? 16 : 8)))
+    return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.Gin = G; a.Yin = Y; a.ldin = ld;
+  a.rstd = bn5; a.nmean_rstd = bn5 + ld; a.k1 = bn5 + 2 * ld; a.k2 = bn5 + 3 * ld; a.k3 = bn5 + 4 * ld;
+  a.W = WT; a.K = ld; a.R = R;
+  a.Yout = Gprev; a.ldout = kprev; a.Yprev = Yprev; a.ldprev = kprev;
+  a.p_scale = prev4; a.p_shift = prev4 + kprev; a.p_rstd = prev4 + 2 * kprev; a.p_nmean_rstd = prev4 + 3 * kprev;
+  a.tstats = tstats;
+  return bf16_io ? launch_row_gemm<bf16>(BNBWD, MASK, kprev, a, (hipStream_t)stream)
+                 : launch_row_gemm<float>(BNBWD, MASK, kprev, a, (hipStream_t)stream);
+}
+
+// first layer: dX = dY_1 * W_1 scattered to d(features) (B,N,C), d(xyz) (B,N,3), d(new_xyz) (B,M,3)
+// (each optional; NOT zeroed here).  WT = W_1^T padded to (kpad x COUT_1) with kpad a multiple of 32.
+extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
+                                   const int *idx, int B, int N, int M, int S, int C, float radius, float *dfeat_pm,
+                                   float *dxyz, float *dnew_xyz, int bf16_io, void *stream) {
+  if (!G || !Y || !bn5 || !WT || !idx || (kpad & 31) || kpad < C + 3 || (ld % (bf16_io ? 16 : 8)) ||
+      (((long long)B * M * S) & 31))
+    return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.Gin = G; a.Yin = Y; a.ldin = ld;
+  a.rstd = bn5; a.nmean_rstd = bn5 + ld; a.k1 = bn5 + 2 * ld; a.k2 = bn5 + 3 * ld; a.k3 = bn5 + 4 * ld;
+  a.W = WT; a.K = ld; a.R = (long long)B * M * S;
+  a.idx = idx; a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
+  a.dfeat_pm = dfeat_pm; a.dxyz = dxyz; a.dnew_xyz = dnew_xyz;
+  return bf16_io ? launch_row_gemm<bf16>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream)
+                 : launch_row_gemm<float>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream);
+}
+
+// dW_l (cout x K) += sum_r dY_l[r]^T A_{l-1}[r];  A_{l-1} = relu(Yprev*scale+shift) (gather == 0) or the gathered
+// rows (gather != 0: xyz/new_xyz/idx/feat_pm given, Yprev ignored).  dW must be zeroed by the caller.
+extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
+                              const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
+                              const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
+                              float radius, float *dW, int bf16_io, void *stream) {
+  if (!G || !Y || !bn5 || !dW || R < 2 || (R & 1) || K < 1) return VLP3D_EINVAL;
+  WgradArgs w = {};
+  w.src.K = K; w.src.R = R;
+  if (gather) {
+    if (!xyz || !new_xyz || !idx || !feat_pm) return VLP3D_EINVAL;
+    w.src.xyz = xyz; w.src.new_xyz = new_xyz; w.src.idx = idx; w.src.feat_pm = feat_pm;
+    w.src.N = N; w.src.M = M; w.src.S = S; w.src.C = C; w.src.radius = radius;
+  } else {
+    if (!Yprev || !scale || !shift) return VLP3D_EINVAL;
+    w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;
+  }
+  w.Y = Y; w.G = G; w.ld = cout;
+  w.rstd = bn5; w.nmean_rstd = bn5 + cout; w.k1 = bn5 + 2 * cout; w.k2 = bn5 + 3 * cout; w.k3 = bn5 + 4 * cout;
+  w.dW = dW;
+  long long rpb = (R + 1023) / 1024;  // ~1024 row chunks (x K-tile groups) fill the chip
+  rpb = (rpb + 1) & ~1ll;
+  if (rpb < 64) rpb = 64;
+  w.rows_per_block = rpb;
+  hipStream_t s = (hipStream_t)stream;
+  if (bf16_io) return gather ? launch_wgrad_t<bf16, GATHER>(cout, w, s) : launch_wgrad_t<bf16, BNRELU>(cout, w, s);
+  return gather ? launch_wgrad_t<float, GATHER>(cout, w, s) : launch_wgrad_t<float, BNRELU>(cout, w, s);
+}

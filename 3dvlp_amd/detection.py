@@ -40,7 +40,9 @@ class Pointnet2Backbone(nn.Module):
     @staticmethod
     def _break_up_pc(pc):
         xyz = pc[..., :3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        # (B,C,N) like the reference, but as a transposed VIEW of one point-major copy: the fused SA layer
+        # gathers whole point rows and takes it back without a second 169 MB transpose
+        features = pc[..., 3:].contiguous().transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
     def forward(self, data_dict):

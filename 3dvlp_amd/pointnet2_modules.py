@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import pointnet2_utils
+from . import sa_fused
 from . import pytorch_utils as pt_utils
 
 
@@ -43,6 +44,47 @@ class PointnetSAModuleVotes(nn.Module):
         if use_xyz and len(mlp_spec) > 0:
             mlp_spec[0] += 3  # the reference mutates the caller's list the same way (:207-208)
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
+        # row-major fused path (group_rows kernel + GEMMs on (rows, C) matrices); `fused=False` restores the
+        # literal op-by-op sequence of the reference (NCHW grouped tensor)
+        # "mfma": hand-written matrix-core kernels (csrc/sa_mlp.hip); "rows": torch GEMM/BN on the gathered rows;
+        # False: the reference's literal NCHW sequence
+        ok = bool(bn and use_xyz and pooling == "max" and npoint is not None and not sample_uniformly
+                  and not ret_unique_cnt)
+        self.fused = "mfma" if ok else False
+
+    def _forward_rows(self, xyz, features, inds):
+        """Same math as the reference sequence, on GEMM-ready rows: group_rows -> (linear, BN, ReLU) x L ->
+        max over nsample.  BatchNorm over the (B*npoint*nsample) rows of a channel is exactly BatchNorm2d over
+        (B, npoint, nsample); the first layer's weight columns are permuted to [features | xyz | 0]."""
+        B, N, _ = xyz.shape
+        M, S = self.npoint, self.nsample
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+        idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
+        feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
+        if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S):
+            pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm.float(), self.radius if self.normalize_xyz else 1.0,
+                                          self.mlp_module, dtype == torch.bfloat16)
+            return new_xyz, pooled.transpose(1, 2), inds
+        x = pointnet2_utils.group_rows(xyz, new_xyz, idx, feat_pm, self.radius if self.normalize_xyz else 1.0, dtype)
+        for i, layer in enumerate(self.mlp_module):
+            w = layer.conv.weight[:, :, 0, 0]
+            if i == 0:
+                w = torch.cat([w[:, 3:], w[:, :3], w.new_zeros(w.shape[0], 1)], dim=1)
+            x = F.linear(x, w)
+            bn = layer.bn.bn
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked.add_(1)
+                factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+            else:
+                factor = 0.0
+            x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                             bn.training or not bn.track_running_stats, factor, bn.eps)
+            x = F.relu(x, inplace=True)
+        pooled = x.view(B * M, S, x.shape[-1]).max(dim=1)[0]
+        return new_xyz, pooled.view(B, M, -1).transpose(1, 2), inds  # (B,C,npoint) view of point-major data
 
     def forward(self, xyz, features=None, inds=None):
         # geometry and the gather kernels are fp32-only (like the reference's CHECK_IS_FLOAT); under
@@ -54,6 +96,9 @@ class PointnetSAModuleVotes(nn.Module):
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
+        if self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda:
+            return self._forward_rows(xyz, features, inds)
+        features = features.contiguous() if features is not None else None
         new_xyz = (pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
                    if self.npoint is not None else None)
 
@@ -86,7 +131,7 @@ class PointnetFPModule(nn.Module):
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
-        known_feats = known_feats.float()
+        known_feats = known_feats.float().contiguous()
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

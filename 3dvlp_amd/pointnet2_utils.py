@@ -116,6 +116,29 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+class GroupRows(Function):
+    """Fused gather of QueryAndGroup in GEMM-ready row layout (csrc/group_rows.hip):
+    rows (B*npoint*nsample, C+4) = [features[idx] | (xyz[idx] - new_xyz)/radius | 0]."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, out_dtype):
+        ctx.save_for_backward(idx)
+        ctx.dims = (xyz.shape[0], xyz.shape[1], feat_pm.shape[2], radius)
+        return _ext.group_rows(xyz, new_xyz, idx, feat_pm, radius, out_dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, N, C, radius = ctx.dims
+        need = ctx.needs_input_grad
+        dfeat, dxyz, dnew = _ext.group_rows_grad(grad_out.contiguous(), idx, B, N, C, radius, need[3], need[0],
+                                                 need[1])
+        return dxyz, dnew, None, dfeat, None, None
+
+
+group_rows = GroupRows.apply
+
+
 class QueryAndGroup(nn.Module):
     """Ball query + grouping + centre subtraction (+ /radius) + channel concat.
 

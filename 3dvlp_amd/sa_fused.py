@@ -1,0 +1,161 @@
+"""Autograd wrapper of the fused grouped-MLP kernels (csrc/sa_mlp.hip) for PointnetSAModuleVotes.
+
+forward : gather -> (GEMM, BN batch statistics) x 3 -> max over nsample through BN+ReLU, all on the matrix
+          cores, nothing of shape (B,C,npoint,nsample) except the stored pre-activations Y_l.
+backward: BatchNorm / ReLU / max-pool backward folded into the loaders and epilogues of the same kernels.
+Same math as pointnet2_modules.py:233-267 of the reference (training-mode BatchNorm2d statistics over
+B*npoint*nsample rows == batch_norm over the rows of a (rows, C) matrix).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as _ext
+
+_ext.load()
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def supported(C, mlp_out, S, R):
+    return C % 4 == 0 and all(c in (32, 64, 128, 256) for c in mlp_out) and len(mlp_out) == 3 and S <= 255 and \
+        R % 32 == 0
+
+
+def _bn_fold(stats, R, gamma, beta, eps):
+    """Batch statistics (fp64 sums) -> fp32 per-channel vectors [scale, shift, rstd, -mean*rstd], mean, var."""
+    mean = stats[0] / R
+    var = (stats[1] / R - mean * mean).clamp_(min=0.0)
+    rstd = torch.rsqrt(var + eps)
+    scale = gamma.double() * rstd
+    shift = beta.double() - mean * scale
+    vec = torch.stack([scale, shift, rstd, -mean * rstd]).float().contiguous()
+    return vec, mean, var
+
+
+class FusedSAMLP(Function):
+    """(xyz, new_xyz, idx, feat_pm, W1,g1,b1, W2,g2,b2, W3,g3,b3) -> pooled (B*M, C3) fp32."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, *params):
+        W, gam, bet = params[0::3], params[1::3], params[2::3]
+        B, N, _ = xyz.shape
+        _, M, S = idx.shape
+        C = feat_pm.shape[2]
+        R = B * M * S
+        dt = torch.bfloat16 if use_bf16 else torch.float32
+        bf = int(use_bf16)
+        dev = xyz.device
+        cout = [w.shape[0] for w in W]
+        K1 = _round_up(C + 4, 16 if use_bf16 else 8)
+        w1 = W[0][:, :, 0, 0]
+        W1p = torch.zeros((cout[0], K1), dtype=torch.float32, device=dev)
+        W1p[:, :C] = w1[:, 3:]
+        W1p[:, C:C + 3] = w1[:, :3]
+        Wd = [W1p.to(dt).contiguous(), W[1][:, :, 0, 0].to(dt).contiguous(), W[2][:, :, 0, 0].to(dt).contiguous()]
+        Ks = [K1, cout[0], cout[1]]
+        Y, vecs = [], []
+        for l in range(3):
+            y = torch.empty((R, cout[l]), dtype=dt, device=dev)
+            stats = torch.zeros((2, cout[l]), dtype=torch.float64, device=dev)
+            if l == 0:
+                _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
+                          cout[0], y, stats, bf)
+            else:
+                _ext.call("vlp3d_sa_fwd_layer", Y[l - 1], R, Ks[l], vecs[l - 1][0], vecs[l - 1][1], Wd[l], cout[l], y,
+                          stats, bf)
+            bn = bns[l]
+            if training:
+                vec, mean, var = _bn_fold(stats, R, gam[l], bet[l], bn.eps)
+                if bn.track_running_stats:
+                    bn.num_batches_tracked.add_(1)
+                    f = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+                    bn.running_mean.mul_(1 - f).add_(mean.float(), alpha=f)
+                    bn.running_var.mul_(1 - f).add_((var * (R / max(R - 1, 1))).float(), alpha=f)
+            else:
+                rstd = torch.rsqrt(bn.running_var.double() + bn.eps)
+                scale = gam[l].double() * rstd
+                vec = torch.stack([scale, bet[l].double() - bn.running_mean.double() * scale, rstd,
+                                   -bn.running_mean.double() * rstd]).float().contiguous()
+            Y.append(y)
+            vecs.append(vec)
+        out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
+        sel = torch.empty((B * M, cout[2]), dtype=torch.uint8, device=dev)
+        _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf)
+        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *Wd, *gam, *bet)
+        ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
+        ctx.mark_non_differentiable(sel)
+        return out
+
+    @staticmethod
+    def backward(ctx, dP):
+        B, N, M, S, C, R, radius, bf, dt, cout, Ks, training = ctx.cfg
+        sv = ctx.saved_tensors
+        xyz, new_xyz, idx, feat_pm, out, sel = sv[:6]
+        Y, vecs, Wd, gam, bet = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21]
+        dev = xyz.device
+        dP = dP.contiguous().float()
+        need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
+        dparams = [None] * 9
+
+        def bn5(l, t1, t2):
+            rstd, nm = vecs[l][2], vecs[l][3]
+            k1 = gam[l].float() * rstd
+            if training:
+                k2, k3 = (t1 / R).float(), (t2 / R).float()
+            else:
+                k2, k3 = torch.zeros_like(k1), torch.zeros_like(k1)
+            return torch.stack([rstd, nm, k1, k2, k3]).contiguous()
+
+        # layer 3: masked gradient at the selected sample; its BN reductions come from the pooled tensors
+        G = torch.empty((R, cout[2]), dtype=dt, device=dev)
+        _ext.call("vlp3d_sa_pool_grad", dP, out, sel, B * M, S, cout[2], G, bf)
+        g3 = dP * (out > 0)
+        t1 = g3.sum(0).double()
+        gsafe = torch.where(gam[2] == 0, torch.ones_like(gam[2]), gam[2]).float()
+        t2 = (g3 * ((out - bet[2].float()) / gsafe)).sum(0).double()  # yhat_sel = (out - beta)/gamma where out > 0
+        for l in (2, 1, 0):
+            c5 = bn5(l, t1, t2)
+            dparams[3 * l + 1] = t2.float()  # d gamma
+            dparams[3 * l + 2] = t1.float()  # d beta
+            dW = torch.zeros((cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            if l > 0:
+                _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
+                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, bf)
+                dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
+                WT = Wd[l].t().contiguous()
+                Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
+                ts = torch.zeros((2, cout[l - 1]), dtype=torch.float64, device=dev)
+                _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WT, cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
+                          ts, bf)
+                G, t1, t2 = Gp, ts[0], ts[1]
+            else:
+                _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
+                          feat_pm, N, M, S, C, radius, dW, bf)
+                dW1 = torch.empty((cout[0], C + 3), dtype=torch.float32, device=dev)
+                dW1[:, 3:] = dW[:, :C]
+                dW1[:, :3] = dW[:, C:C + 3]
+                dparams[0] = dW1.view(cout[0], C + 3, 1, 1)
+                dfeat = dxyz = dnew = None
+                if need[0] or need[1] or need[3]:
+                    kpad = _round_up(C + 3, 32)
+                    WT = torch.zeros((kpad, cout[0]), dtype=dt, device=dev)
+                    WT[:Ks[0]] = Wd[0].t()
+                    dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dev) if need[3] else None
+                    dxyz = torch.zeros((B, N, 3), dtype=torch.float32, device=dev) if need[0] else None
+                    dnew = torch.zeros((B, M, 3), dtype=torch.float32, device=dev) if need[1] else None
+                    _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WT, kpad, idx, B, N, M, S, C, radius, dfeat,
+                              dxyz, dnew, bf)
+        return (dxyz, dnew, None, dfeat, None, None, None, None, *dparams)
+
+
+def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16):
+    """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32."""
+    bns = [layer.bn.bn for layer in mlp_module]
+    params = []
+    for layer in mlp_module:
+        params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
+    B, M = new_xyz.shape[:2]
+    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, *params)
+    return out.view(B, M, -1)

@@ -95,6 +95,57 @@ int vlp3d_three_interpolate_grad(const float *grad_out, const int *idx, const fl
 int vlp3d_nn_distance(const float *pc1, const float *pc2, int B, int N, int M, int mode, float delta, float *dist1,
                       long long *idx1, float *dist2, long long *idx2, void *stream);
 
+/* replaces QueryAndGroup's gather stage (lib/pointnet2/pointnet2_utils.py:343-355: group(xyz), -= centre,
+ * /= radius, group(features), cat) with GEMM-ready rows.  xyz (B,N,3), new_xyz (B,M,3), idx (B,M,S) i32,
+ * feat_pm (B,N,C) f32 POINT-MAJOR features, C % 4 == 0.
+ * -> out (B*M*S, C+4): [features(C) | (xyz[idx]-new_xyz)/radius (3) | 0], f32 or bf16 (out_bf16 != 0).
+ * Pass radius = 1 for normalize_xyz=False. */
+int vlp3d_group_rows(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
+                     int M, int S, int C, float radius, void *out, int out_bf16, void *stream);
+
+/* adjoint of vlp3d_group_rows: dout (B*M*S, C+4) f32/bf16 -> dfeat_pm (B,N,C), dxyz (B,N,3), dnew_xyz (B,M,3),
+ * each optional (NULL = not needed); zeroed by the call, then scatter-added with contiguous float atomics. */
+int vlp3d_group_rows_grad(const void *dout, int dout_bf16, const int *idx, int B, int N, int M, int S, int C,
+                          float radius, float *dfeat_pm, float *dxyz, float *dnew_xyz, void *stream);
+
+/* ---- grouped per-ball MLP of a set-abstraction layer on the matrix cores (csrc/sa_mlp.hip) ------------
+ * Replaces, for PointnetSAModuleVotes.forward (lib/pointnet2/pointnet2_modules.py:233-267) and its autograd
+ * backward: group_points x2, sub/div, cat, 3 x (1x1 conv, BatchNorm2d, ReLU), max_pool2d over nsample.
+ * Rows r = (b*M + m)*S + s; Y_l (R x cout_l) pre-activations, G_l masked gradients; bf16_io: 0 = fp32 storage +
+ * exact-fp32 MFMA, 1 = bf16 storage + bf16 MFMA (fp32 accumulate).  Per-channel vectors are fp32, batch
+ * statistics fp64.  R = B*M*S must be a multiple of 32; cout in {32,64,128,256}. */
+
+/* layer 1: Y = [feat_pm[idx] | (xyz[idx]-new_xyz)/radius | 0] * W^T; W (cout x K) in column order
+ * [features(C) | xyz(3) | 0], K >= C+4, K % 8 (fp32) / 16 (bf16) == 0.  stats (2 x cout) f64 += [sum, sumsq]. */
+int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
+                        int M, int S, int C, float radius, const void *W, int K, int cout, void *Y, double *stats,
+                        int bf16_io, void *stream);
+/* layers 2..: Y = relu(Yin*scale + shift) * W^T, Yin (R x K), W (cout x K). */
+int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const float *scale, const float *shift, const void *W,
+                       int cout, void *Y, double *stats, int bf16_io, void *stream);
+/* out (BM x C) f32 = relu(sel*scale + shift), sel = max_s Y (scale >= 0) / min_s Y (scale < 0); sel_idx u8. */
+int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
+                  unsigned char *sel_idx, int bf16_io, void *stream);
+/* G (BM*S x C) = dP routed to the selected sample where out > 0 (max-pool + ReLU backward). */
+int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *sel_idx, long long BM, int S, int C,
+                       void *G, int bf16_io, void *stream);
+/* G_{l-1} = relu-mask(BNbwd(G_l, Y_l) * W_l), tstats (2 x kprev) f64 += [sum g, sum g*yhat] of layer l-1.
+ * bn5 = [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)] (5 x ld) of layer l; WT = W_l^T (kprev x ld);
+ * prev4 = [scale | shift | rstd | -mean*rstd] (4 x kprev) of layer l-1. */
+int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT, int kprev,
+                       const void *Yprev, const float *prev4, void *Gprev, double *tstats, int bf16_io, void *stream);
+/* layer 1 input gradient, scatter-added (NOT zeroed here) into dfeat_pm (B,N,C) / dxyz (B,N,3) / dnew_xyz (B,M,3)
+ * (each optional).  WT = W_1^T zero-padded to (kpad x ld), kpad % 32 == 0. */
+int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
+                        const int *idx, int B, int N, int M, int S, int C, float radius, float *dfeat_pm, float *dxyz,
+                        float *dnew_xyz, int bf16_io, void *stream);
+/* dW (cout x K) f32 += sum_r BNbwd(G,Y)[r]^T A[r]; A = relu(Yprev*scale+shift) (gather == 0) or the gathered
+ * layer-1 rows (gather != 0).  dW zeroed by the caller. */
+int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
+                   const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
+                   const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
+                   float radius, float *dW, int bf16_io, void *stream);
+
 /* replaces the att = softmax(QK^T/sqrt(dk) [+bias | *w] [mask]) V core of
  * models/transformer/attention.py:63-75 without materialising att.
  * q (B,nq,H*D), k/v (B,nk,H*D) are the OUTPUTS of fc_q/fc_k/fc_v (head h = columns h*D..h*D+D-1);

@@ -138,7 +138,104 @@ def test_grounding_step_forward_backward_small():
         assert must in touched, must
     # OCC/OSC are active (epoch 50); whether they carry gradient at random init depends on IoU>0.25 hits
     assert torch.isfinite(d["lang_con_loss"]) and torch.isfinite(d["iou_con_loss"])
-    l0 = float(loss)
+    l0 = float(loss.detach())
     for _ in range(3):
-        l1 = float(step.run(batch))
+        l1 = float(step.run(batch).detach())
     assert np.isfinite(l1) and l1 < l0  # three AdamW steps on a fixed batch reduce the loss
+
+
+def test_group_rows_forward_backward_vs_oracle():
+    pu = importlib.import_module("3dvlp_amd.pointnet2_utils")
+    rng = np.random.default_rng(21)
+    B, N, M, S, C, r = 2, 600, 40, 8, 12, 0.5
+    xyz = rng.uniform(0, 2, (B, N, 3)).astype(np.float32)
+    new_xyz = xyz[:, :M].copy()
+    feat = rng.normal(size=(B, C, N)).astype(np.float32)
+    g_feat, g_xyz, idx = orc.query_and_group(xyz, new_xyz, feat, r, S, use_xyz=True, normalize_xyz=True)
+    exp = np.concatenate([g_feat[:, 3:], g_feat[:, :3], np.zeros((B, 1, M, S), np.float32)], 1)  # [feat|xyz|0]
+    exp = exp.transpose(0, 2, 3, 1).reshape(B * M * S, C + 4)
+    X, NX = dev(xyz).requires_grad_(True), dev(new_xyz).requires_grad_(True)
+    F_pm = dev(feat.transpose(0, 2, 1)).requires_grad_(True)
+    rows = pu.group_rows(X, NX, dev(idx), F_pm, r, torch.float32)
+    assert (rows.detach().cpu().numpy() == exp).all()  # gather + the same fp32 (q-c)/r
+    rows_bf = pu.group_rows(X, NX, dev(idx), F_pm, r, torch.bfloat16)
+    np.testing.assert_allclose(rows_bf.detach().float().cpu().numpy(), exp, rtol=8e-3, atol=1e-6)
+    g = rng.normal(size=exp.shape).astype(np.float32)
+    rows.backward(dev(g))
+    g4 = g.reshape(B, M, S, C + 4).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(F_pm.grad.cpu().numpy().transpose(0, 2, 1),
+                               orc.group_points_grad(np.ascontiguousarray(g4[:, :C]), idx, N), rtol=1e-5, atol=1e-5)
+    gx = np.ascontiguousarray(g4[:, C:C + 3]) / np.float32(r)
+    np.testing.assert_allclose(X.grad.cpu().numpy().transpose(0, 2, 1), orc.group_points_grad(gx, idx, N),
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(NX.grad.cpu().numpy(), -gx.sum(3).transpose(0, 2, 1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["mfma", "rows"])
+@pytest.mark.parametrize("training", [True, False])
+def test_sa_module_fused_equals_reference_sequence(training, mode):
+    """The fused SA paths (hand-written MFMA kernels / row-major torch) == the literal reference op sequence
+    (same weights, fp32): forward within 1e-4, gradients norm-wise."""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    torch.manual_seed(0)
+    sc = [synth.make_scene(1000 + i, 4096) for i in range(2)]
+    xyz = dev(np.stack([s["xyz"] for s in sc]))
+    feat = dev(np.stack([s["features"][:, :12].T for s in sc]).copy())
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 32, 32, 64], use_xyz=True,
+                                  normalize_xyz=True).cuda().train(training)
+    import copy
+    ref = copy.deepcopy(sa)
+    ref.fused = False
+    assert sa.fused == "mfma"
+    sa.fused = mode
+    x1, f1 = xyz.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    x2, f2 = xyz.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    nx1, nf1, i1 = sa(x1, f1)
+    nx2, nf2, i2 = ref(x2, f2)
+    assert torch.equal(i1, i2) and torch.equal(nx1, nx2)
+    torch.testing.assert_close(nf1, nf2, rtol=1e-4, atol=2e-5)
+    g = torch.randn_like(nf2)
+    (nf1 * g).sum().backward()
+    (nf2 * g).sum().backward()
+    torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-3, atol=1e-4)
+    for (n, p), (_, q) in zip(sa.named_parameters(), ref.named_parameters()):
+        err = (p.grad - q.grad).abs().max().item()
+        scale = q.grad.abs().max().item()
+        # train-mode BN makes weight gradients differences of large cancelling sums: compare norm-wise
+        assert err <= 2e-3 * scale + 1e-5, (n, err, scale)
+    if training:
+        for (n, p), (_, q) in zip(sa.named_buffers(), ref.named_buffers()):
+            torch.testing.assert_close(p.float(), q.float(), rtol=1e-4, atol=1e-6, msg=n)
+
+
+def test_sa_module_mfma_bf16_close_to_fp32():
+    """bf16 storage + bf16 MFMA variant: reported against the fp32 path with a bf16-sized tolerance."""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    torch.manual_seed(0)
+    sc = [synth.make_scene(1000 + i, 4096) for i in range(2)]
+    xyz = dev(np.stack([s["xyz"] for s in sc]))
+    feat = dev(np.stack([s["features"][:, :12].T for s in sc]).copy())
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 32, 32, 64], use_xyz=True,
+                                  normalize_xyz=True).cuda().train()
+    f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    _, a, _ = sa(xyz, f1)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        _, b, _ = sa(xyz, f2)
+    def rel(x, y):
+        return ((x - y).norm() / (y.norm() + 1e-20)).item()
+
+    errs = {"out": rel(b.float(), a)}
+    assert errs["out"] < 2e-2, errs
+    g = torch.randn_like(a)
+    (a * g).sum().backward()
+    ga = {n: p.grad.clone() for n, p in sa.named_parameters()}
+    sa.zero_grad()
+    (b * g).sum().backward()
+    for n, p in sa.named_parameters():
+        errs[n] = rel(p.grad, ga[n])
+    errs["dfeat"] = rel(f2.grad, f1.grad)
+    print("bf16 vs fp32 relative (Frobenius) errors:", {k: round(v, 4) for k, v in errs.items()})
+    assert max(errs.values()) < 0.15, errs

@@ -1,0 +1,25 @@
+"""Summarise ONE steady-state step out of a rocprofv3 kernel_trace.csv (warm-up excluded):
+the window between the last two launches of the SA1 FPS kernel."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+path = sys.argv[1]
+f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "fps_kernel<1024" in r["Kernel_Name"]]
+a, b = marks[-2], marks[-1]
+win = rows[a:b]
+t0, t1 = int(win[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
+agg = defaultdict(lambda: [0, 0])
+for r in win:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[r["Kernel_Name"]][0] += d
+    agg[r["Kernel_Name"]][1] += 1
+busy = sum(v[0] for v in agg.values())
+print(f"step wall {1e-6 * (t1 - t0):.3f} ms, kernel busy {1e-6 * busy:.3f} ms, {len(win)} launches")
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+    print(f"{1e-6 * d:8.3f} ms {n:5d}x  {k[:120]}")
