@@ -39,7 +39,7 @@ SIGNATURES = {
     "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
     "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
-                       _i, _f, _vp, _i, _vp],
+                       _i, _f, _vp, _vp, _i, _i, _vp],
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _vp],

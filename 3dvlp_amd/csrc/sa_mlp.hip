@@ -300,92 +300,152 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(const float *__restrict_
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[c][k] = sum_r dY[r][c] * A[r][k]   (COUT x K), fp32 MFMA, rows split over workgroups.
-// MFMA step = 2 rows: A-operand lane (c = 32ct + r) reads dY[row 2kk+half][c], B-operand lane
-// (k = 32kt + r) reads A[row 2kk+half][k]: both are coalesced 128-byte row segments.
-// dY and A come through the same element-wise loaders as row_gemm (scalar form).
+// Per 32-row tile the workgroup stages dY (32 x COUT, BN-backward applied) and A_{l-1} (32 x KP, gather or
+// BN+ReLU applied) in LDS with the same vectorised loaders as row_gemm, then every wave owns a set of
+// 32x32 output tiles: one MFMA step = 2 rows, A-operand lane (c = 32ct + r) reads dY[2kk+half][c], B-operand
+// lane (k = 32kt + r) reads A[2kk+half][k] — both conflict-free 128-byte LDS rows.  One workgroup covers the
+// WHOLE dW for its rows, so dY and A are read once.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int LOADER>
-__device__ __forceinline__ float load_a1(const RowGemmArgs &a, long long row, int col) {
-  if (LOADER == GATHER) {
-    const long long bm = row / a.S, b = bm / a.M;
-    const long long p = a.idx[row];
-    if (col < a.C) return a.feat_pm[(b * a.N + p) * a.C + col];
-    if (col < a.C + 3) return (a.xyz[(b * a.N + p) * 3 + col - a.C] - a.new_xyz[bm * 3 + col - a.C]) / a.radius;
-    return 0.f;
-  }
-  const float y = ld1(reinterpret_cast<const T *>(a.Yin) + row * a.ldin + col);
-  if (LOADER == PLAIN) return y;
-  return fmaxf(0.f, y * a.scale[col] + a.shift[col]);  // BNRELU
-}
-
 struct WgradArgs {
-  RowGemmArgs src;       // loader of A_{l-1} (GATHER or BNRELU), K = src.K columns
-  const void *Y, *G;     // this layer's pre-activation and masked gradient (R x ld)
-  int ld;
-  const float *rstd, *nmean_rstd, *k1, *k2, *k3;  // BN backward constants of this layer (length COUT)
-  float *dW;             // (COUT x K) fp32, zeroed by the caller
-  long long rows_per_block;
+  RowGemmArgs dy;   // BNBWD loader of this layer's dY (Gin, Yin, ldin = COUT, constants)
+  RowGemmArgs src;  // loader of A_{l-1} (GATHER or BNRELU), K = src.K valid columns
+  int KP;           // K rounded up to a multiple of 32
+  float *partials;  // (gridDim.x x COUT x K) fp32 scratch: one slab per workgroup
+  long long tiles_per_block;
 };
 
 template <typename T, int COUT, int LOADER>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
-  constexpr int NCT = COUT / 32;            // c-tiles, distributed over the 4 waves
-  constexpr int CT_PER_WAVE = (NCT + 3) / 4;
-  constexpr int KT_PER_BLOCK = 3;           // k-tiles handled by one workgroup (blockIdx.y selects the group)
+  extern __shared__ float lds[];
+  constexpr int NCT = COUT / 32;
+  constexpr int MAXT = 9;  // output tiles per wave (NCT * KP/32 <= 36)
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = w.src.K;
-  const int kt0 = blockIdx.y * KT_PER_BLOCK;
-  const long long row0 = (long long)blockIdx.x * w.rows_per_block;
-  const long long row1 = min(w.src.R, row0 + w.rows_per_block);
+  const int KP = w.KP, K = w.src.K, NKT = KP / 32, NT = NCT * NKT;
+  float *lds_dy = lds;               // [32][COUT]
+  float *lds_a = lds + 32 * COUT;    // [32][KP]
 
-  f32x16 acc[CT_PER_WAVE][KT_PER_BLOCK];
-  float rs[CT_PER_WAVE], nm[CT_PER_WAVE], k1[CT_PER_WAVE], k2[CT_PER_WAVE], k3[CT_PER_WAVE];
-  bool ct_ok[CT_PER_WAVE];
+  f32x16 acc[MAXT];
+  int off_c[MAXT], off_k[MAXT];  // this wave's output tiles: t = wave + 4i -> (ct, kt), hoisted out of the hot loop
+  bool tile_ok[MAXT];
 #pragma unroll
-  for (int i = 0; i < CT_PER_WAVE; ++i) {
-    const int ct = wave + 4 * i;
-    ct_ok[i] = ct < NCT;
-    const int c = min(32 * ct + r, COUT - 1);
-    rs[i] = w.rstd[c]; nm[i] = w.nmean_rstd[c]; k1[i] = w.k1[c]; k2[i] = w.k2[c]; k3[i] = w.k3[c];
-#pragma unroll
-    for (int j = 0; j < KT_PER_BLOCK; ++j) acc[i][j] = zero16();
+  for (int i = 0; i < MAXT; ++i) {
+    acc[i] = zero16();
+    const int t = wave + 4 * i;
+    tile_ok[i] = t < NT;
+    const int ct = tile_ok[i] ? t / NKT : 0;
+    off_c[i] = 32 * ct;
+    off_k[i] = 32 * (tile_ok[i] ? t - ct * NKT : 0);
   }
-  const T *Y = reinterpret_cast<const T *>(w.Y);
-  const T *G = reinterpret_cast<const T *>(w.G);
 
-  for (long long rr = row0 + half; rr < row1; rr += 2) {
-    float bv[KT_PER_BLOCK];
+  const long long ntiles = w.src.R / 32;
+  const long long t0 = (long long)blockIdx.x * w.tiles_per_block;
+  const long long t1 = min(ntiles, t0 + w.tiles_per_block);
+  // Staging is BRANCH-FREE: every global load is unconditional (clamped address) and only the LDS stores are
+  // predicated — hipcc otherwise branches around each load and waits vmcnt(0) per element, serialising them.
+  static_assert((32 * COUT / 4) % 256 == 0, "dY tile must split evenly over 256 threads");
+  constexpr int NE_DY = 32 * COUT / 4 / 256;
+  constexpr int MAXE_A = 9;                              // 32 * KP / 4 / 256 with KP <= 288
+  const int KF = (LOADER == GATHER) ? w.src.C : K;       // columns read as plain 16-byte row slices
+  const int kf4 = KF / 4, nef = 32 * kf4;
+  const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
+  float4 vdy[NE_DY], va[MAXE_A], vt;
+
+  auto fetch = [&](long long tile) {
+    const int row0 = (int)(tile * 32);
+    int pidx[MAXE_A];
 #pragma unroll
-    for (int j = 0; j < KT_PER_BLOCK; ++j) {
-      const int k = 32 * (kt0 + j) + r;
-      bv[j] = k < K ? load_a1<T, LOADER>(w.src, rr, k) : 0.f;
+    for (int j = 0; j < MAXE_A; ++j) {
+      const int e = min((int)threadIdx.x + 256 * j, nef - 1);
+      pidx[j] = (LOADER == GATHER) ? w.src.idx[row0 + e / kf4] : 0;
+    }
+    const int te = min((int)threadIdx.x, max(net, 1) - 1);
+    const int trow = row0 + te / max(tc, 1);
+    const int tp = (LOADER == GATHER) ? w.src.idx[trow] : 0;
+#pragma unroll
+    for (int j = 0; j < NE_DY; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      vdy[j] = load_a4<T, BNBWD>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < CT_PER_WAVE; ++i) {
-      if (!ct_ok[i]) continue;  // wave-uniform
-      const int c = 32 * (wave + 4 * i) + r;
-      const float y = ld1(Y + rr * w.ld + c), g = ld1(G + rr * w.ld + c);
-      const float dy = k1[i] * (g - k2[i] - (y * rs[i] + nm[i]) * k3[i]);
-#pragma unroll
-      for (int j = 0; j < KT_PER_BLOCK; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy, bv[j], acc[i][j], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < CT_PER_WAVE; ++i) {
-    if (!ct_ok[i]) continue;
-#pragma unroll
-    for (int j = 0; j < KT_PER_BLOCK; ++j) {
-      const int k = 32 * (kt0 + j) + r;
-      if (k >= K) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int c = 32 * (wave + 4 * i) + acc_row(e, half);
-        atomicAdd(w.dW + (long long)c * K + k, acc[i][j][e]);
+    for (int j = 0; j < MAXE_A; ++j) {
+      const int e = min((int)threadIdx.x + 256 * j, nef - 1);
+      const int row = e / kf4, k0 = (e - row * kf4) * 4;
+      const int rr = row0 + row;
+      if (LOADER == GATHER) {
+        const int b = (rr / w.src.S) / w.src.M;
+        va[j] = ld4(w.src.feat_pm + ((long long)b * w.src.N + pidx[j]) * w.src.C + k0);
+      } else {
+        va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
     }
+    vt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LOADER == GATHER) {
+      const int bm = trow / w.src.S, b = bm / w.src.M;
+      const float *q = w.src.xyz + ((long long)b * w.src.N + tp) * 3;
+      const float *c = w.src.new_xyz + (long long)bm * 3;
+      const float x = (q[0] - c[0]) / w.src.radius, y = (q[1] - c[1]) / w.src.radius, z = (q[2] - c[2]) / w.src.radius;
+      const bool first = (te % max(tc, 1)) == 0;  // chunk 0 of the tail is [dx, dy, dz, 0]
+      vt = make_float4(first ? x : 0.f, first ? y : 0.f, first ? z : 0.f, 0.f);
+    }
+  };
+
+  if (t0 < t1) fetch(t0);
+  for (long long tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // the previous tile's MFMA reads are done
+#pragma unroll
+    for (int j = 0; j < NE_DY; ++j) *reinterpret_cast<float4 *>(lds_dy + 4 * (threadIdx.x + 256 * j)) = vdy[j];
+#pragma unroll
+    for (int j = 0; j < MAXE_A; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < nef) {
+        const int row = e / kf4;
+        *reinterpret_cast<float4 *>(lds_a + row * KP + (e - row * kf4) * 4) = va[j];
+      }
+    }
+    if ((int)threadIdx.x < net) {
+      const int row = threadIdx.x / tc;
+      *reinterpret_cast<float4 *>(lds_a + row * KP + KF + (threadIdx.x - row * tc) * 4) = vt;
+    }
+    __syncthreads();
+    if (tile + 1 < t1) fetch(tile + 1);
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const float *pa = lds_dy + (2 * kk + half) * COUT + r;
+      const float *pb = lds_a + (2 * kk + half) * KP + r;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        if (tile_ok[i])  // wave-uniform
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[off_c[i]], pb[off_k[i]], acc[i], 0, 0, 0);
+    }
   }
+  // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
+  // thousands of workgroups atomically adding into the same 36 KB matrix run an order of magnitude slower
+  float *slab = w.partials + (long long)blockIdx.x * COUT * K;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= NT) continue;
+    const int ct = t / NKT, kt = t - ct * NKT;
+    const int k = 32 * kt + r;
+    if (k >= K) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) slab[(long long)(32 * ct + acc_row(e, half)) * K + k] = acc[i][e];
+  }
+}
+
+// dW[i] = sum_b partials[b][i]: 256 threads share the nblk slabs of 64 consecutive elements (4 slab-groups)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partials, int nblk, int n,
+                                                           float *__restrict__ dW) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (i < n)
+    for (int b = grp; b < nblk; b += 4) s += partials[(long long)b * n + i];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) dW[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 unsigned grid_tiles(long long R) {
@@ -421,13 +481,16 @@ int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStre
 
 template <typename T, int LOADER>
 int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
-  const long long nblk = (w.src.R + w.rows_per_block - 1) / w.rows_per_block;
-  const dim3 grid((unsigned)nblk, (unsigned)((w.src.K + 95) / 96)), block(256);
+  const long long ntiles = w.src.R / 32;
+  const long long nblk = (ntiles + w.tiles_per_block - 1) / w.tiles_per_block;
+  const dim3 grid((unsigned)nblk), block(256);
+  const size_t lds = (size_t)32 * (cout + w.KP) * sizeof(float);
+  if (lds > 64 * 1024 || (cout / 32) * (w.KP / 32) > 36) return VLP3D_EINVAL;
   switch (cout) {
-    case 32: hipLaunchKernelGGL((wgrad_kernel<T, 32, LOADER>), grid, block, 0, s, w); break;
-    case 64: hipLaunchKernelGGL((wgrad_kernel<T, 64, LOADER>), grid, block, 0, s, w); break;
-    case 128: hipLaunchKernelGGL((wgrad_kernel<T, 128, LOADER>), grid, block, 0, s, w); break;
-    case 256: hipLaunchKernelGGL((wgrad_kernel<T, 256, LOADER>), grid, block, 0, s, w); break;
+    case 32: hipLaunchKernelGGL((wgrad_kernel<T, 32, LOADER>), grid, block, lds, s, w); break;
+    case 64: hipLaunchKernelGGL((wgrad_kernel<T, 64, LOADER>), grid, block, lds, s, w); break;
+    case 128: hipLaunchKernelGGL((wgrad_kernel<T, 128, LOADER>), grid, block, lds, s, w); break;
+    case 256: hipLaunchKernelGGL((wgrad_kernel<T, 256, LOADER>), grid, block, lds, s, w); break;
     default: return VLP3D_EINVAL;
   }
   VLP3D_LAUNCH_CHECK();
@@ -537,8 +600,8 @@ extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const f
 extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
                               const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                               const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
-                              float radius, float *dW, int bf16_io, void *stream) {
-  if (!G || !Y || !bn5 || !dW || R < 2 || (R & 1) || K < 1) return VLP3D_EINVAL;
+                              float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream) {
+  if (!G || !Y || !bn5 || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
   WgradArgs w = {};
   w.src.K = K; w.src.R = R;
   if (gather) {
@@ -549,14 +612,23 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
     if (!Yprev || !scale || !shift) return VLP3D_EINVAL;
     w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;
   }
-  w.Y = Y; w.G = G; w.ld = cout;
-  w.rstd = bn5; w.nmean_rstd = bn5 + cout; w.k1 = bn5 + 2 * cout; w.k2 = bn5 + 3 * cout; w.k3 = bn5 + 4 * cout;
-  w.dW = dW;
-  long long rpb = (R + 1023) / 1024;  // ~1024 row chunks (x K-tile groups) fill the chip
-  rpb = (rpb + 1) & ~1ll;
-  if (rpb < 64) rpb = 64;
-  w.rows_per_block = rpb;
+  w.dy.Gin = G; w.dy.Yin = Y; w.dy.ldin = cout;
+  w.dy.rstd = bn5; w.dy.nmean_rstd = bn5 + cout; w.dy.k1 = bn5 + 2 * cout; w.dy.k2 = bn5 + 3 * cout;
+  w.dy.k3 = bn5 + 4 * cout;
+  w.KP = (K + 31) & ~31;
+  w.partials = partials;
+  const long long ntiles = R / 32;
+  long long tpb = (ntiles + max_blocks - 1) / max_blocks;  // each workgroup accumulates its rows in registers
+  if (tpb < 1) tpb = 1;
+  w.tiles_per_block = tpb;
+  const int nblk = (int)((ntiles + tpb - 1) / tpb);
   hipStream_t s = (hipStream_t)stream;
-  if (bf16_io) return gather ? launch_wgrad_t<bf16, GATHER>(cout, w, s) : launch_wgrad_t<bf16, BNRELU>(cout, w, s);
-  return gather ? launch_wgrad_t<float, GATHER>(cout, w, s) : launch_wgrad_t<float, BNRELU>(cout, w, s);
+  int st;
+  if (bf16_io) st = gather ? launch_wgrad_t<bf16, GATHER>(cout, w, s) : launch_wgrad_t<bf16, BNRELU>(cout, w, s);
+  else st = gather ? launch_wgrad_t<float, GATHER>(cout, w, s) : launch_wgrad_t<float, BNRELU>(cout, w, s);
+  if (st != VLP3D_OK) return st;
+  const int n = cout * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
 }

@@ -13,6 +13,8 @@ from . import _lib as _ext
 
 _ext.load()
 
+WGRAD_BLOCKS = 512  # workgroups (= partial dW slabs) of the weight-gradient kernel: two per CU
+
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
@@ -119,10 +121,11 @@ class FusedSAMLP(Function):
             c5 = bn5(l, t1, t2)
             dparams[3 * l + 1] = t2.float()  # d gamma
             dparams[3 * l + 2] = t1.float()  # d beta
-            dW = torch.zeros((cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            dW = torch.empty((cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            part = torch.empty((WGRAD_BLOCKS, cout[l], Ks[l]), dtype=torch.float32, device=dev)
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
-                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, bf)
+                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, WGRAD_BLOCKS, bf)
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 WT = Wd[l].t().contiguous()
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
@@ -132,7 +135,7 @@ class FusedSAMLP(Function):
                 G, t1, t2 = Gp, ts[0], ts[1]
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, bf)
+                          feat_pm, N, M, S, C, radius, dW, part, WGRAD_BLOCKS, bf)
                 dW1 = torch.empty((cout[0], C + 3), dtype=torch.float32, device=dev)
                 dW1[:, 3:] = dW[:, :C]
                 dW1[:, :3] = dW[:, C:C + 3]

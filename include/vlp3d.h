@@ -139,12 +139,13 @@ int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const 
 int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
                         const int *idx, int B, int N, int M, int S, int C, float radius, float *dfeat_pm, float *dxyz,
                         float *dnew_xyz, int bf16_io, void *stream);
-/* dW (cout x K) f32 += sum_r BNbwd(G,Y)[r]^T A[r]; A = relu(Yprev*scale+shift) (gather == 0) or the gathered
- * layer-1 rows (gather != 0).  dW zeroed by the caller. */
+/* dW (cout x K) f32 = sum_r BNbwd(G,Y)[r]^T A[r]; A = relu(Yprev*scale+shift) (gather == 0) or the gathered
+ * layer-1 rows (gather != 0).  partials: scratch of max_blocks*cout*K floats (one slab per workgroup, summed by
+ * a second kernel: no contended atomics); dW is fully written. */
 int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
                    const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
-                   float radius, float *dW, int bf16_io, void *stream);
+                   float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream);
 
 /* replaces the att = softmax(QK^T/sqrt(dk) [+bias | *w] [mask]) V core of
  * models/transformer/attention.py:63-75 without materialising att.
