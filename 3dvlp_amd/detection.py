@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .transformer import MultiHeadAttention
 
@@ -140,11 +141,17 @@ class StandardROIHeads(nn.Module):
 _CORNER_SIGNS = ((1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1), (1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1))
 
 
+_SIGN_CACHE = {}
+
+
 def box_corners(box_size, heading, center):
     """Device restatement of get_3d_box_batch (utils/box_util.py:361-385), which rotates with
     roty_batch (:324-338): corners = (signs * size/2) @ R^T + center, R = [[c,0,s],[0,1,0],[-s,0,c]].
     box_size (...,3), heading (...), center (...,3) -> (...,8,3)."""
-    signs = torch.tensor(_CORNER_SIGNS, dtype=box_size.dtype, device=box_size.device)
+    key = (box_size.device, box_size.dtype)
+    if key not in _SIGN_CACHE:
+        _SIGN_CACHE[key] = torch.tensor(_CORNER_SIGNS, dtype=box_size.dtype, device=box_size.device)
+    signs = _SIGN_CACHE[key]
     local = signs * (box_size.unsqueeze(-2) * 0.5)  # (...,8,3)
     c, s = torch.cos(heading).unsqueeze(-1), torch.sin(heading).unsqueeze(-1)
     x, y, z = local[..., 0], local[..., 1], local[..., 2]
@@ -221,6 +228,38 @@ class ProposalModule(nn.Module):
         return torch.where(m, rc, pred_center), torch.where(m, rs, pred_box_size)
 
 
+class _RelationBias(torch.autograd.Function):
+    """Fused pairwise-geometry bias MLP (csrc/relation_bias.hip): centre (B,K,3), packed params -> (B,4,K,K)."""
+    SLAB_BLOCKS = 512
+
+    @staticmethod
+    def forward(ctx, centre, params):
+        centre = centre.contiguous().float()
+        params = params.contiguous().float()
+        B, K, _ = centre.shape
+        out = torch.empty((B, 4, K, K), dtype=torch.float32, device=centre.device)
+        _ext.call("vlp3d_relation_bias_fwd", centre, params, B, K, out)
+        ctx.save_for_backward(centre, params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        centre, params = ctx.saved_tensors
+        B, K, _ = centre.shape
+        n = params.numel()
+        dparams = torch.empty_like(params)
+        slabs = torch.empty((_RelationBias.SLAB_BLOCKS * 4, n), dtype=torch.float32, device=centre.device)
+        _ext.call("vlp3d_relation_bias_bwd", centre, params, dout.contiguous().float(), B, K, dparams, slabs,
+                  _RelationBias.SLAB_BLOCKS)
+        return None, dparams
+
+
+def relation_bias(centre, fc):
+    """fc = the reference's self_attn_fc[i] Sequential; returns its output on all pairs as (B,4,K,K)."""
+    params = torch.cat([p.reshape(-1) for p in fc.parameters()])
+    return _RelationBias.apply(centre.detach(), params)
+
+
 class RelationModule(nn.Module):
     """2 layers of proposal self-attention with an additive pairwise-geometry bias."""
 
@@ -229,6 +268,7 @@ class RelationModule(nn.Module):
         self.use_box_embedding = True
         self.use_dist_weight_matrix = True
         self.use_obj_embedding = True
+        self.fused_bias = True  # pairwise MLP in one HIP kernel; False = the reference's op sequence (host tests)
         self.num_proposals, self.hidden_size, self.depth = num_proposals, hidden_size, depth
         self.features_concat = nn.Sequential(nn.Conv1d(det_channel, hidden_size, 1), nn.BatchNorm1d(hidden_size),
                                              nn.PReLU(hidden_size), nn.Conv1d(hidden_size, hidden_size, 1))
@@ -248,8 +288,10 @@ class RelationModule(nn.Module):
 
         # pairwise geometry (layer-independent): delta[b,i,j] = centre_j - centre_i, plus its norm
         centre = corners.mean(dim=-2)
-        delta = centre[:, None, :, :] - centre[:, :, None, :]
-        pair = torch.cat([delta, delta.pow(2).sum(-1, keepdim=True).sqrt()], dim=-1).detach()  # (B,K,K,4)
+        pair = None
+        if not (self.fused_bias and centre.is_cuda):
+            delta = centre[:, None, :, :] - centre[:, :, None, :]
+            pair = torch.cat([delta, delta.pow(2).sum(-1, keepdim=True).sqrt()], dim=-1).detach()  # (B,K,K,4)
 
         # "multiview feature of the proposal's source point" (:98-113).  REFERENCE QUIRK, reproduced
         # exactly because trained checkpoints depend on it: the reference offsets the per-batch point
@@ -271,7 +313,10 @@ class RelationModule(nn.Module):
 
         dist_weights = None
         for i in range(self.depth):
-            dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)  # (B,4,K,K) additive bias
+            if self.fused_bias and centre.is_cuda:
+                dist_weights = relation_bias(centre, self.self_attn_fc[i])  # (B,4,K,K) additive bias
+            else:
+                dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)
             features = features + self.obj_embedding[i](obj_feat) * 0.1
             features = features + self.bbox_embedding[i](manual_bbox_feat)
             features = self.self_attn[i](features, features, features, attention_weights=dist_weights, way="add")

@@ -5,8 +5,6 @@
 State-dict keys follow the reference (unused sub-modules such as lang_emb_proj / box_con_proj are kept
 for checkpoint compatibility).
 """
-import random
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -45,33 +43,40 @@ class MatchModule(nn.Module):
 
     @staticmethod
     def _copy_paste(features, objectness_masks):
-        """Train-time augmentation (:97-121): background proposals of scene i are overwritten with
-        object features taken from the (twice repeated) batch-wide list of object proposals, starting
-        after scene i's own objects.  Host-driven (data-dependent sizes), as in the reference."""
-        B, K = features.shape[:2]
-        feature0 = features.clone()
-        obj_masks = objectness_masks.bool().squeeze(2)
-        obj_lens = obj_masks.sum(1).tolist()
-        pool = features.reshape(B * K, -1)[obj_masks.reshape(-1)].repeat(2, 1)
-        total_len = int(sum(obj_lens))
-        j = 0
-        for i in range(B):
-            bg = torch.where(~obj_masks[i])[0]
-            j += obj_lens[i]
-            take = min(bg.shape[0], total_len - obj_lens[i])
-            feature0[i, bg[:take], :] = pool[j:j + take, :]
-        return feature0
+        """Train-time augmentation (:97-121): background proposals of scene i are overwritten with object
+        features taken from the (twice repeated) batch-wide list of object proposals, starting right after
+        scene i's own objects.  The reference drives this from the host (torch.where + Python slicing, one
+        sync per scene); here the same assignment is a fixed-shape gather, so the step stays capturable in a
+        HIP graph:  background slot of rank r in scene i  <-  pool[(J_i + r) mod total]  if r < total - n_i,
+        with J_i = objects in scenes 0..i, pool = object proposals in (scene, proposal) order."""
+        B, K, D = features.shape
+        obj = objectness_masks.bool().squeeze(2)            # (B,K)
+        n_obj = obj.sum(1)                                  # (B,)
+        total = n_obj.sum()
+        J = torch.cumsum(n_obj, 0)                          # (B,)
+        bg = ~obj
+        rank = torch.cumsum(bg.long(), 1) - 1               # rank of each background slot inside its scene
+        take = bg & (rank < (total - n_obj)[:, None])
+        obj_pos = torch.argsort((~obj.reshape(-1)).to(torch.int8), stable=True)  # object slots first, in order
+        src = obj_pos[(J[:, None] + rank).clamp(min=0) % total.clamp(min=1)]     # (B,K) flat source slot
+        pasted = features.reshape(B * K, D)[src.reshape(-1)].reshape(B, K, D)
+        return torch.where(take.unsqueeze(-1), pasted, features)
 
     def forward(self, data_dict):
         objectness_masks = data_dict["objectness_scores"].max(2)[1].float().unsqueeze(2)
         features = data_dict["bbox_feature"]  # (B, K, hidden)
         B, K = features.shape[:2]
         L = data_dict["input_ids"].shape[1]
-        data_dict["random"] = random.random()
-
         feature0 = features.clone()
-        if data_dict["istrain"][0] == 1 and data_dict["random"] < 0.5:
-            feature0 = self._copy_paste(features, objectness_masks)
+        if data_dict["istrain"][0] == 1:
+            # the reference draws random.random() < 0.5 on the host; a device-side draw keeps the step free of
+            # host decisions (graph-capturable) with the same 50 % rate
+            coin = data_dict.get("random")
+            if coin is None:
+                coin = torch.rand((), device=features.device)
+            data_dict["random"] = coin
+            use = torch.as_tensor(coin, device=features.device) < 0.5
+            feature0 = torch.where(use, self._copy_paste(features, objectness_masks), feature0)
 
         feature1 = feature0[:, None, :, :].expand(B, L, K, feature0.shape[-1]).reshape(B * L, K, -1)
         lang_fea = data_dict["lang_fea"][:, 1:]  # K/V = the tokens after [CLS]
@@ -136,6 +141,7 @@ class ContrastModule(nn.Module):
         self.config = config
         self.bce_loss = nn.BCEWithLogitsLoss()
         self.pc_proj_iou = nn.Sequential(nn.Linear(hidden, hidden, bias=False))
+        self._mean_size = None  # device copy of config.mean_size_arr (not a parameter/buffer: keeps the state_dict)
 
     def forward(self, data_dict):
         if data_dict["epoch"] < 50:
@@ -147,7 +153,9 @@ class ContrastModule(nn.Module):
         B, K = features.shape[:2]
         gt_center = data_dict["ref_center_label_list"].detach()[..., 0:3]  # (B,L,3)
         L = gt_center.shape[1]
-        mean_size = torch.as_tensor(self.config.mean_size_arr, dtype=torch.float32, device=features.device)
+        if self._mean_size is None or self._mean_size.device != features.device:
+            self._mean_size = torch.as_tensor(self.config.mean_size_arr, dtype=torch.float32, device=features.device)
+        mean_size = self._mean_size
         gt_size = mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
         lang_emb = data_dict["lang_emb"].view(B, -1, data_dict["lang_emb"].shape[-1])[:, :L]
         obj = data_dict["objectness_scores"].max(2)[1].float()  # (B,K) 1 = takes part

@@ -30,6 +30,7 @@ FAR_THRESHOLD = 0.6   # loss_detection.py:19-23
 NEAR_THRESHOLD = 0.3
 GT_VOTE_FACTOR = 3
 OBJECTNESS_CLS_WEIGHTS = (0.2, 0.8)
+_CLS_W = {}
 
 
 class GroundingNet(nn.Module):
@@ -88,7 +89,9 @@ def compute_objectness_loss(d):
     euc = torch.sqrt(dist1 + 1e-6)
     label = (euc < NEAR_THRESHOLD).long()
     mask = ((euc < NEAR_THRESHOLD) | (euc > FAR_THRESHOLD)).float()
-    w = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=agg.device)
+    if agg.device not in _CLS_W:
+        _CLS_W[agg.device] = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=agg.device)
+    w = _CLS_W[agg.device]
     ce = F.cross_entropy(d["objectness_scores"].float().transpose(2, 1), label, weight=w, reduction="none")
     return torch.sum(ce * mask) / (torch.sum(mask) + 1e-6), label, mask, ind1
 
@@ -122,9 +125,15 @@ def batch_to_device(batch, device):
 
 
 class GroundingStep:
-    """Owns model + optimiser + flat gradient bucket; `run(batch)` = fwd + loss + bwd + all-reduce + AdamW."""
+    """Owns model + optimiser + flat gradient bucket; `run(batch)` = fwd + loss + bwd + all-reduce + AdamW.
 
-    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0):
+    With `use_graph=True` the forward+loss+backward of a (static) batch is captured once into a HIP graph and
+    replayed: the step issues ~2500 kernel launches, which eager PyTorch cannot enqueue as fast as the GPU
+    retires them.  The step contains no host-side decision or sync (copy-paste augmentation, contrast losses and
+    box decode are all fixed-shape device code), which is what makes the capture legal.  The gradient
+    all-reduce and the optimiser step stay outside the graph."""
+
+    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False):
         torch.manual_seed(seed)
         self.device = device
         self.model = GroundingNet().to(device)
@@ -133,6 +142,10 @@ class GroundingStep:
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
+        self.use_graph = use_graph
+        self._graph = None
+        self._static_batch = None
+        self._static_loss = None
 
     def forward_loss(self, batch):
         d = dict(batch)
@@ -144,10 +157,36 @@ class GroundingStep:
             d = self.model(d)
         return grounding_loss(d, self.model.mean_size_arr), d
 
-    def run(self, batch):
+    def _fwd_bwd(self, batch):
         self.bucket.zero()
-        loss, d = self.forward_loss(batch)
+        loss, _ = self.forward_loss(batch)
         loss.backward()
+        return loss.detach()
+
+    def _capture(self, batch):
+        self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, MIOpen/hipBLASLt selection)
+            for _ in range(2):
+                self._fwd_bwd(self._static_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._fwd_bwd(self._static_batch)
+
+    def run(self, batch):
+        if self.use_graph:
+            if self._graph is None:
+                self._capture(batch)
+            elif batch is not self._static_batch:
+                for k, v in batch.items():
+                    if torch.is_tensor(v) and self._static_batch[k].data_ptr() != v.data_ptr():
+                        self._static_batch[k].copy_(v, non_blocking=True)
+            self._graph.replay()
+            loss = self._static_loss
+        else:
+            loss = self._fwd_bwd(batch)
         self.bucket.all_reduce()
         self.opt.step()
         return loss

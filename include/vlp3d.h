@@ -147,6 +147,17 @@ int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const fl
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                    float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream);
 
+/* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
+ * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
+ * with MLP = Linear(4,32) ReLU LayerNorm(32) Linear(32,32) ReLU LayerNorm(32) Linear(32,4) (:26-37).
+ * params: vlp3d_relation_bias_nparam() floats = [W1(32x4) b1 g1 be1 W2(32x32) b2 g2 be2 W3(4x32) b3]
+ * (the order of nn.Sequential.parameters()).  centre (B,K,3) -> out (B,4,K,K). */
+int vlp3d_relation_bias_nparam(void);
+int vlp3d_relation_bias_fwd(const float *centre, const float *params, int B, int K, float *out, void *stream);
+/* dout (B,4,K,K) -> dparams (nparam, fully written); slabs: scratch of nblocks*4*nparam floats. */
+int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
+                            float *dparams, float *slabs, int nblocks, void *stream);
+
 /* replaces the att = softmax(QK^T/sqrt(dk) [+bias | *w] [mask]) V core of
  * models/transformer/attention.py:63-75 without materialising att.
  * q (B,nq,H*D), k/v (B,nk,H*D) are the OUTPUTS of fc_q/fc_k/fc_v (head h = columns h*D..h*D+D-1);

@@ -182,3 +182,33 @@ def test_contrast_module_matches_oracle_loop():
     assert abs(float(d["iou_con_loss"]) - osc) < 1e-5 * max(1, abs(osc))
     d0 = cm({"epoch": 3})
     assert float(d0["con_loss"]) == 0.0  # no-op before epoch 50 (constrast_module.py:54-56)
+
+
+def test_copy_paste_device_formulation_equals_reference_loop():
+    """MatchModule._copy_paste (fixed-shape gather, no host sync) == the reference's host loop
+    (models/refnet/match_module.py:97-121) restated literally."""
+    gr = importlib.import_module("3dvlp_amd.grounding")
+    torch.manual_seed(0)
+    for trial in range(40):
+        B, K, D = 4, 12, 5
+        feats = torch.randn(B, K, D)
+        masks = (torch.rand(B, K, 1) > (0.2 + 0.15 * (trial % 5))).float()
+        if trial == 7:
+            masks[:] = 0
+        if trial == 8:
+            masks[:] = 1
+        got = gr.MatchModule._copy_paste(feats, masks)
+        feature0 = feats.clone()
+        obj_masks = masks.bool().squeeze(2)
+        obj_lens = [int(obj_masks[i].sum()) for i in range(B)]
+        obj_features = feats.reshape(B * K, -1)[obj_masks.reshape(-1)].repeat(2, 1)
+        total_len = sum(obj_lens)
+        j = 0
+        for i in range(B):
+            om = torch.where(obj_masks[i] == False)[0]  # noqa: E712
+            j += obj_lens[i]
+            if om.shape[0] < total_len - obj_lens[i]:
+                feature0[i, om, :] = obj_features[j:j + om.shape[0], :]
+            else:
+                feature0[i, om[:total_len - obj_lens[i]], :] = obj_features[j:j + total_len - obj_lens[i], :]
+        assert torch.equal(got, feature0), trial
