@@ -46,20 +46,39 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].contiguous().transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
+    GEOMETRY_KEYS = ("sa1", "sa2", "sa3", "sa4", "fp1", "fp2")
+
+    @torch.no_grad()
+    def compute_geometry(self, point_clouds):
+        """Everything in the backbone that depends only on the input coordinates (4x FPS + gather + ball query,
+        2x three_nn): (B,N,3+C) -> {layer: tuple of tensors}.  No weights, no features, no gradient — a step
+        driver can run it for the NEXT batch on a side stream while the dense layers of the current one run
+        (SURVEY.md §7 hard part 2c); pass the result back as data_dict["backbone_geometry"]."""
+        xyz = point_clouds[..., :3].contiguous()
+        g = {}
+        for name in ("sa1", "sa2", "sa3", "sa4"):
+            g[name] = getattr(self, name).compute_geometry(xyz)
+            xyz = g[name][1]
+        g["fp1"] = PointnetFPModule.compute_geometry(g["sa3"][1], g["sa4"][1])
+        g["fp2"] = PointnetFPModule.compute_geometry(g["sa2"][1], g["sa3"][1])
+        return g
+
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
-        xyz, features, fps_inds = self.sa1(xyz, features)
+        geo = data_dict.get("backbone_geometry") or {}
+        xyz, features, fps_inds = self.sa1(xyz, features, geometry=geo.get("sa1"))
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa2(xyz, features)
+        xyz, features, fps_inds = self.sa2(xyz, features, geometry=geo.get("sa2"))
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa3(xyz, features)
+        xyz, features, fps_inds = self.sa3(xyz, features, geometry=geo.get("sa3"))
         data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
-        xyz, features, fps_inds = self.sa4(xyz, features)
+        xyz, features, fps_inds = self.sa4(xyz, features, geometry=geo.get("sa4"))
         data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
 
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
-                            data_dict["sa4_features"])
-        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+                            data_dict["sa4_features"], geometry=geo.get("fp1"))
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features,
+                            geometry=geo.get("fp2"))
         data_dict["fp2_features"] = features
         data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
         num_seed = data_dict["fp2_xyz"].shape[1]

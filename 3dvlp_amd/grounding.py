@@ -59,7 +59,7 @@ class MatchModule(nn.Module):
         take = bg & (rank < (total - n_obj)[:, None])
         obj_pos = torch.argsort((~obj.reshape(-1)).to(torch.int8), stable=True)  # object slots first, in order
         src = obj_pos[(J[:, None] + rank).clamp(min=0) % total.clamp(min=1)]     # (B,K) flat source slot
-        pasted = features.reshape(B * K, D)[src.reshape(-1)].reshape(B, K, D)
+        pasted = torch.gather(features.reshape(B * K, D), 0, src.reshape(-1, 1).expand(-1, D)).reshape(B, K, D)
         return torch.where(take.unsqueeze(-1), pasted, features)
 
     def forward(self, data_dict):

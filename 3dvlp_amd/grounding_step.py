@@ -133,7 +133,7 @@ class GroundingStep:
     box decode are all fixed-shape device code), which is what makes the capture legal.  The gradient
     all-reduce and the optimiser step stay outside the graph."""
 
-    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False):
+    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False):
         torch.manual_seed(seed)
         self.device = device
         self.model = GroundingNet().to(device)
@@ -143,13 +143,20 @@ class GroundingStep:
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
         self.use_graph = use_graph
+        # geometry pipeline: the backbone's coordinate-only stage (FPS / ball query / three_nn) of the NEXT batch
+        # runs on a side stream while the dense layers of the current batch run (one workgroup per scene = 8 CUs)
+        self.pipeline = pipeline
+        self._side = torch.cuda.Stream(device=device) if pipeline else None
+        self._geom_cur = self._geom_next = None
         self._graph = None
-        self._static_batch = None
+        self._static_batch = self._static_next = None
         self._static_loss = None
 
-    def forward_loss(self, batch):
+    def forward_loss(self, batch, geometry=None):
         d = dict(batch)
         d["epoch"] = self.epoch
+        if geometry is not None:
+            d["backbone_geometry"] = geometry
         if self.autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                 d = self.model(d)
@@ -157,36 +164,68 @@ class GroundingStep:
             d = self.model(d)
         return grounding_loss(d, self.model.mean_size_arr), d
 
-    def _fwd_bwd(self, batch):
+    @staticmethod
+    def _copy_geometry(dst, src):
+        for k in src:
+            for a, b in zip(dst[k], src[k]):
+                a.copy_(b)
+
+    def _fwd_bwd(self, batch, next_batch=None):
+        """One forward+loss+backward.  With the pipeline on, uses the geometry prepared during the previous call
+        and prepares `next_batch`'s (default: the same batch again) on the side stream meanwhile."""
+        geometry = None
+        if self.pipeline:
+            backbone = self.model.backbone_net
+            cur = torch.cuda.current_stream()
+            if self._geom_next is None:  # very first call: nothing prepared yet
+                self._geom_next = backbone.compute_geometry(batch["point_clouds"])
+                self._geom_cur = {k: tuple(t.clone() for t in v) for k, v in self._geom_next.items()}
+            self._copy_geometry(self._geom_cur, self._geom_next)  # tiny: indices + sampled coordinates
+            self._side.wait_stream(cur)  # fork: the side branch may overwrite _geom_next from here on
+            with torch.cuda.stream(self._side):
+                nxt = backbone.compute_geometry((next_batch or batch)["point_clouds"])
+                self._copy_geometry(self._geom_next, nxt)
+            geometry = self._geom_cur
         self.bucket.zero()
-        loss, _ = self.forward_loss(batch)
+        loss, _ = self.forward_loss(batch, geometry)
         loss.backward()
+        if self.pipeline:
+            torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()
 
-    def _capture(self, batch):
+    def _capture(self, batch, next_batch):
         self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, MIOpen/hipBLASLt selection)
+        self._static_next = self._static_batch if next_batch is None else \
+            {k: (v.clone() if torch.is_tensor(v) else v) for k, v in next_batch.items()}
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):  # warm-up off the capture stream (allocator, MIOpen/hipBLASLt selection)
             for _ in range(2):
-                self._fwd_bwd(self._static_batch)
-        torch.cuda.current_stream().wait_stream(side)
+                self._fwd_bwd(self._static_batch, self._static_next)
+        torch.cuda.current_stream().wait_stream(warm)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._static_loss = self._fwd_bwd(self._static_batch)
+            self._static_loss = self._fwd_bwd(self._static_batch, self._static_next)
 
-    def run(self, batch):
+    @staticmethod
+    def _refill(static, batch):
+        for k, v in batch.items():
+            if torch.is_tensor(v) and static[k].data_ptr() != v.data_ptr():
+                static[k].copy_(v, non_blocking=True)
+
+    def run(self, batch, next_batch=None):
         if self.use_graph:
             if self._graph is None:
-                self._capture(batch)
-            elif batch is not self._static_batch:
-                for k, v in batch.items():
-                    if torch.is_tensor(v) and self._static_batch[k].data_ptr() != v.data_ptr():
-                        self._static_batch[k].copy_(v, non_blocking=True)
+                self._capture(batch, next_batch)
+            else:
+                if batch is not self._static_batch:
+                    self._refill(self._static_batch, batch)
+                if next_batch is not None and next_batch is not self._static_next:
+                    self._refill(self._static_next, next_batch)
             self._graph.replay()
             loss = self._static_loss
         else:
-            loss = self._fwd_bwd(batch)
+            loss = self._fwd_bwd(batch, next_batch)
         self.bucket.all_reduce()
         self.opt.step()
         return loss

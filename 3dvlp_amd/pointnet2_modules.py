@@ -52,15 +52,27 @@ class PointnetSAModuleVotes(nn.Module):
                   and not ret_unique_cnt)
         self.fused = "mfma" if ok else False
 
-    def _forward_rows(self, xyz, features, inds):
+    @torch.no_grad()
+    def compute_geometry(self, xyz):
+        """The weight-independent part of the layer: (inds, new_xyz, ball-query idx).  Depends only on the
+        coordinates, so a step driver may compute it ahead of time on a side stream (grounding_step.py)."""
+        inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        return inds, new_xyz, idx
+
+    def _forward_rows(self, xyz, features, inds, geometry=None):
         """Same math as the reference sequence, on GEMM-ready rows: group_rows -> (linear, BN, ReLU) x L ->
         max over nsample.  BatchNorm over the (B*npoint*nsample) rows of a channel is exactly BatchNorm2d over
         (B, npoint, nsample); the first layer's weight columns are permuted to [features | xyz | 0]."""
         B, N, _ = xyz.shape
         M, S = self.npoint, self.nsample
-        xyz_flipped = xyz.transpose(1, 2).contiguous()
-        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
-        idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
+        if geometry is not None:
+            inds, new_xyz, idx = geometry
+        else:
+            xyz_flipped = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+            idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
         feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
         mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
@@ -86,17 +98,21 @@ class PointnetSAModuleVotes(nn.Module):
         pooled = x.view(B * M, S, x.shape[-1]).max(dim=1)[0]
         return new_xyz, pooled.view(B, M, -1).transpose(1, 2), inds  # (B,C,npoint) view of point-major data
 
-    def forward(self, xyz, features=None, inds=None):
+    def forward(self, xyz, features=None, inds=None, geometry=None):
         # geometry and the gather kernels are fp32-only (like the reference's CHECK_IS_FLOAT); under
         # autocast the previous layer hands over bf16 activations
         xyz = xyz.float()
         features = features.float() if features is not None else None
         xyz_flipped = xyz.transpose(1, 2).contiguous()
+        use_rows = self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda
+        if geometry is not None:
+            assert use_rows, "precomputed geometry needs the fused path"
+            return self._forward_rows(xyz, features, None, geometry)
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
-        if self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda:
+        if use_rows:
             return self._forward_rows(xyz, features, inds)
         features = features.contiguous() if features is not None else None
         new_xyz = (pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
@@ -130,13 +146,24 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    @torch.no_grad()
+    def compute_geometry(unknown, known):
+        """Weight-independent part: three_nn indices + inverse-distance weights (:393-397)."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        dist_recip = 1.0 / (dist + 1e-8)
+        return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, geometry=None):
         known_feats = known_feats.float().contiguous()
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
+            if geometry is not None:
+                idx, weight = geometry
+            else:
+                dist, idx = pointnet2_utils.three_nn(unknown, known)
+                dist_recip = 1.0 / (dist + 1e-8)
+                norm = torch.sum(dist_recip, dim=2, keepdim=True)
+                weight = dist_recip / norm
             interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

@@ -266,3 +266,23 @@ def test_relation_bias_fused_forward_backward():
     for (n, _), a, b in zip(fc.named_parameters(), got, exp):
         scale = b.abs().max().item()
         assert (a.double() - b).abs().max().item() < 2e-4 * scale + 1e-5, n
+
+
+def test_geometry_pipeline_and_graph_equal_inline_step():
+    """Precomputed backbone geometry (side stream) and hipGraph replay give the same step as the inline path."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    devc = torch.device("cuda:0")
+    batch = gs.batch_to_device(synth.make_batch(0, 2, num_points=8192, lang_num_max=2), devc)
+    batch["random"] = torch.tensor(0.25, device=devc)  # fix the copy-paste coin
+    losses = {}
+    for name, kw in (("inline", {}), ("pipeline", {"pipeline": True}), ("graph", {"pipeline": True, "use_graph": True})):
+        step = gs.GroundingStep(devc, **kw)
+        step.model.eval()  # no dropout: the three variants must agree numerically
+        for m in step.model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.train()
+        losses[name] = [float(step.run(batch)) for _ in range(3)]
+    for name in ("pipeline", "graph"):
+        np.testing.assert_allclose(losses[name], losses["inline"], rtol=2e-3, err_msg=name)
+    assert losses["inline"][2] < losses["inline"][0]
