@@ -253,13 +253,18 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
   }
 }
 
+// out[i] = sum_k slabs[k][i]: 256 threads = 4 slab-groups x 64 consecutive elements
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ slabs, int nslab, int n,
                                                        float *__restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slabs[(long long)k * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int k = grp; k < nslab; k += 4) s += slabs[(long long)k * n + i];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 }  // namespace
@@ -291,7 +296,7 @@ extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params,
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(relation_bias_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
                      slabs);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, s, slabs, (int)blocks * 4, NPARAM,
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 63) / 64), dim3(256), 0, s, slabs, (int)blocks * 4, NPARAM,
                      dparams);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

@@ -314,11 +314,10 @@ struct WgradArgs {
   long long tiles_per_block;
 };
 
-template <typename T, int COUT, int LOADER>
+template <typename T, int COUT, int LOADER, int MAXT>  // MAXT = output tiles per wave >= ceil(NCT * KP/32 / 4)
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
-  constexpr int MAXT = 9;  // output tiles per wave (NCT * KP/32 <= 36)
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KP = w.KP, K = w.src.K, NKT = KP / 32, NT = NCT * NKT;
@@ -479,22 +478,34 @@ int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStre
   return VLP3D_EINVAL;
 }
 
+template <typename T, int LOADER, int COUT>
+int launch_wgrad_c(const WgradArgs &w, hipStream_t s, dim3 grid, size_t lds) {
+  const int per_wave = ((COUT / 32) * (w.KP / 32) + 3) / 4;
+  const dim3 block(256);
+  // fewer accumulator registers -> more resident workgroups -> more loads in flight (the kernel is latency bound)
+  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1>), grid, block, lds, s, w);
+  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3>), grid, block, lds, s, w);
+  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4>), grid, block, lds, s, w);
+  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6>), grid, block, lds, s, w);
+  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9>), grid, block, lds, s, w);
+  else return VLP3D_EINVAL;
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
 template <typename T, int LOADER>
 int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
   const long long ntiles = w.src.R / 32;
   const long long nblk = (ntiles + w.tiles_per_block - 1) / w.tiles_per_block;
-  const dim3 grid((unsigned)nblk), block(256);
+  const dim3 grid((unsigned)nblk);
   const size_t lds = (size_t)32 * (cout + w.KP) * sizeof(float);
-  if (lds > 64 * 1024 || (cout / 32) * (w.KP / 32) > 36) return VLP3D_EINVAL;
+  if (lds > 64 * 1024) return VLP3D_EINVAL;
   switch (cout) {
-    case 32: hipLaunchKernelGGL((wgrad_kernel<T, 32, LOADER>), grid, block, lds, s, w); break;
-    case 64: hipLaunchKernelGGL((wgrad_kernel<T, 64, LOADER>), grid, block, lds, s, w); break;
-    case 128: hipLaunchKernelGGL((wgrad_kernel<T, 128, LOADER>), grid, block, lds, s, w); break;
-    case 256: hipLaunchKernelGGL((wgrad_kernel<T, 256, LOADER>), grid, block, lds, s, w); break;
+    case 64: return launch_wgrad_c<T, LOADER, 64>(w, s, grid, lds);
+    case 128: return launch_wgrad_c<T, LOADER, 128>(w, s, grid, lds);
+    case 256: return launch_wgrad_c<T, LOADER, 256>(w, s, grid, lds);
     default: return VLP3D_EINVAL;
   }
-  VLP3D_LAUNCH_CHECK();
-  return VLP3D_OK;
 }
 
 }  // namespace

@@ -249,7 +249,7 @@ class ProposalModule(nn.Module):
 
 class _RelationBias(torch.autograd.Function):
     """Fused pairwise-geometry bias MLP (csrc/relation_bias.hip): centre (B,K,3), packed params -> (B,4,K,K)."""
-    SLAB_BLOCKS = 512
+    SLAB_BLOCKS = 256  # workgroups of the backward kernel (4 partial-gradient slabs each)
 
     @staticmethod
     def forward(ctx, centre, params):

@@ -189,6 +189,7 @@ class GroundingStep:
         self.bucket.zero()
         loss, _ = self.forward_loss(batch, geometry)
         loss.backward()
+        self.bucket.collect()
         if self.pipeline:
             torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()

@@ -21,7 +21,7 @@ def _round_up(x, m):
 
 
 def supported(C, mlp_out, S, R):
-    return C % 4 == 0 and all(c in (32, 64, 128, 256) for c in mlp_out) and len(mlp_out) == 3 and S <= 255 and \
+    return C % 4 == 0 and all(c in (64, 128, 256) for c in mlp_out) and len(mlp_out) == 3 and S <= 255 and \
         R % 32 == 0
 
 

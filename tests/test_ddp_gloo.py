@@ -32,6 +32,7 @@ def _worker(rank, world, port, ret):
     x = torch.randn(8, 6)
     bucket.zero()
     model[2](model[1](model[0](x[lo:hi]))).pow(2).mean().backward()
+    bucket.collect()
     bucket.all_reduce()
     # single-process reference: gradient of the mean over BOTH shards with the same (broadcast) weights
     import copy

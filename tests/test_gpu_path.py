@@ -130,6 +130,7 @@ def test_grounding_step_forward_backward_small():
     assert d["cluster_ref"].shape == (4, 256) and d["pred_bbox_corner"].shape == (2, 256, 8, 3)
     step.bucket.zero()
     loss.backward()
+    step.bucket.collect()
     assert torch.isfinite(step.bucket.flat).all()
     touched = [n for n, p in step.model.named_parameters() if p.grad.abs().sum() > 0]
     for must in ("backbone_net.sa1.mlp_module.layer0.conv.weight", "vgen.conv3.weight",
@@ -182,13 +183,15 @@ def test_sa_module_fused_equals_reference_sequence(training, mode):
     sc = [synth.make_scene(1000 + i, 4096) for i in range(2)]
     xyz = dev(np.stack([s["xyz"] for s in sc]))
     feat = dev(np.stack([s["features"][:, :12].T for s in sc]).copy())
-    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 32, 32, 64], use_xyz=True,
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 64, 64, 128], use_xyz=True,
                                   normalize_xyz=True).cuda().train(training)
     import copy
     ref = copy.deepcopy(sa)
     ref.fused = False
     assert sa.fused == "mfma"
     sa.fused = mode
+    sf = importlib.import_module("3dvlp_amd.sa_fused")
+    assert sf.supported(12, [64, 64, 128], 32, 2 * 256 * 32)  # the MFMA kernels really cover this shape
     x1, f1 = xyz.clone().requires_grad_(True), feat.clone().requires_grad_(True)
     x2, f2 = xyz.clone().requires_grad_(True), feat.clone().requires_grad_(True)
     nx1, nf1, i1 = sa(x1, f1)
@@ -218,7 +221,7 @@ def test_sa_module_mfma_bf16_close_to_fp32():
     sc = [synth.make_scene(1000 + i, 4096) for i in range(2)]
     xyz = dev(np.stack([s["xyz"] for s in sc]))
     feat = dev(np.stack([s["features"][:, :12].T for s in sc]).copy())
-    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 32, 32, 64], use_xyz=True,
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 64, 64, 128], use_xyz=True,
                                   normalize_xyz=True).cuda().train()
     f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
     _, a, _ = sa(xyz, f1)
