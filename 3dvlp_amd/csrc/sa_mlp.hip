@@ -447,6 +447,75 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   if (grp == 0 && i < n) dW[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-channel bookkeeping of the fused layer (each replaces ~20 tiny framework kernels per BatchNorm):
+// ------------------------------------------------------------------------------------------------
+// bn_fold: batch statistics (fp64 sums) -> vec[4][C] = [scale | shift | rstd | -mean*rstd], running-stat update.
+__global__ void bn_fold_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
+                               const float *__restrict__ beta, float *__restrict__ running_mean,
+                               float *__restrict__ running_var, int C, double R, float eps, float momentum,
+                               int training, float *__restrict__ vec) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    mean = stats[c] / R;
+    var = stats[C + c] / R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (R / (R > 1.0 ? R - 1.0 : 1.0)));
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double scale = (double)gamma[c] * rstd;
+  vec[c] = (float)scale;
+  vec[C + c] = (float)((double)beta[c] - mean * scale);
+  vec[2 * C + c] = (float)rstd;
+  vec[3 * C + c] = (float)(-mean * rstd);
+}
+
+// bn5: backward constants [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)] + d gamma, d beta
+__global__ void bn5_kernel(const float *__restrict__ vec, const float *__restrict__ gamma,
+                           const double *__restrict__ t, int C, double R, int training, float *__restrict__ bn5,
+                           float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = vec[2 * C + c];
+  bn5[c] = rstd;
+  bn5[C + c] = vec[3 * C + c];
+  bn5[2 * C + c] = gamma[c] * rstd;
+  bn5[3 * C + c] = training ? (float)(t[c] / R) : 0.f;
+  bn5[4 * C + c] = training ? (float)(t[C + c] / R) : 0.f;
+  dbeta[c] = (float)t[c];
+  dgamma[c] = (float)t[C + c];
+}
+
+// BN-backward reductions of the LAST layer straight from the pooled tensors: only the selected sample of each
+// ball carries gradient, and there z = gamma*yhat + beta = out, so yhat = (out - beta)/gamma.
+__global__ __launch_bounds__(256) void pool_tstats_kernel(const float *__restrict__ dP, const float *__restrict__ out,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, long long BM, int C,
+                                                          long long rows_per_block, double *__restrict__ t) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(BM, r0 + rows_per_block);
+  const float g = gamma[c], b = beta[c];
+  const float inv = g == 0.f ? 0.f : 1.f / g;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long r = r0; r < r1; ++r) {
+    const float o = out[r * C + c];
+    const float d = o > 0.f ? dP[r * C + c] : 0.f;
+    s1 += d;
+    s2 += d * ((o - b) * inv);
+  }
+  atomicAdd(t + c, s1);
+  atomicAdd(t + C + c, s2);
+}
+
 unsigned grid_tiles(long long R) {
   const long long blocks = (R / 32 + 3) / 4;
   const long long cap = 256 * 4;  // a few persistent workgroups per CU; each wave walks tiles with a grid stride
@@ -640,6 +709,42 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
   if (st != VLP3D_OK) return st;
   const int n = cout * K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+
+// vec (4 x C) f32 = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums (training) or the running
+// statistics (eval); in training also updates running_mean / running_var (may be NULL) with `momentum`.
+extern "C" int vlp3d_sa_bn_fold(const double *stats, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, int C, long long R, float eps, float momentum, int training,
+                                float *vec, void *stream) {
+  if (!gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
+                     running_mean, running_var, C, (double)R, eps, momentum, training, vec);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// bn5 (5 x C) backward constants + dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64.
+extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int C, long long R,
+                                      int training, float *bn5, float *dgamma, float *dbeta, void *stream) {
+  if (!vec || !gamma || !t || !bn5 || !dgamma || !dbeta || C < 1 || R < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(bn5_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, vec, gamma, t, C, (double)R,
+                     training, bn5, dgamma, dbeta);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// t (2 x C) f64 += [sum g, sum g*yhat] of the last layer from the pooled tensors (t zeroed by the caller).
+extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta,
+                                    long long BM, int C, double *t, void *stream) {
+  if (!dP || !out || !gamma || !beta || !t || BM < 1 || C < 1) return VLP3D_EINVAL;
+  long long rpb = (BM + 127) / 128;
+  if (rpb < 16) rpb = 16;
+  const dim3 grid((C + 255) / 256, (unsigned)((BM + rpb - 1) / rpb));
+  hipLaunchKernelGGL(pool_tstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dP, out, gamma, beta, BM, C, rpb, t);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

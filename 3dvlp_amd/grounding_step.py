@@ -133,7 +133,8 @@ class GroundingStep:
     box decode are all fixed-shape device code), which is what makes the capture legal.  The gradient
     all-reduce and the optimiser step stay outside the graph."""
 
-    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False):
+    def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False,
+                 sa_dtype=None):
         torch.manual_seed(seed)
         self.device = device
         self.model = GroundingNet().to(device)
@@ -142,6 +143,11 @@ class GroundingStep:
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
+        # bf16 for the grouped-MLP kernels only (the dense work that matters); everything else stays fp32, which
+        # removes the ~350 per-step cast kernels autocast would launch around the many small layers
+        for m in self.model.modules():
+            if hasattr(m, "mlp_dtype"):
+                m.mlp_dtype = sa_dtype
         self.use_graph = use_graph
         # geometry pipeline: the backbone's coordinate-only stage (FPS / ball query / three_nn) of the NEXT batch
         # runs on a side stream while the dense layers of the current batch run (one workgroup per scene = 8 CUs)

@@ -51,6 +51,9 @@ class PointnetSAModuleVotes(nn.Module):
         ok = bool(bn and use_xyz and pooling == "max" and npoint is not None and not sample_uniformly
                   and not ret_unique_cnt)
         self.fused = "mfma" if ok else False
+        # storage / MFMA type of the fused grouped MLP: None = follow autocast (bf16 inside an autocast region,
+        # else fp32); torch.bfloat16 selects the bf16 kernels explicitly while the rest of the model stays fp32
+        self.mlp_dtype = None
 
     @torch.no_grad()
     def compute_geometry(self, xyz):
@@ -74,7 +77,8 @@ class PointnetSAModuleVotes(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
             idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
         feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
-        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        dtype = self.mlp_dtype or (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
+                                   else torch.float32)
         mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
         if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S):
             pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm.float(), self.radius if self.normalize_xyz else 1.0,

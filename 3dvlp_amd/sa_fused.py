@@ -22,18 +22,7 @@ def _round_up(x, m):
 
 def supported(C, mlp_out, S, R):
     return C % 4 == 0 and all(c in (64, 128, 256) for c in mlp_out) and len(mlp_out) == 3 and S <= 255 and \
-        R % 32 == 0
-
-
-def _bn_fold(stats, R, gamma, beta, eps):
-    """Batch statistics (fp64 sums) -> fp32 per-channel vectors [scale, shift, rstd, -mean*rstd], mean, var."""
-    mean = stats[0] / R
-    var = (stats[1] / R - mean * mean).clamp_(min=0.0)
-    rstd = torch.rsqrt(var + eps)
-    scale = gamma.double() * rstd
-    shift = beta.double() - mean * scale
-    vec = torch.stack([scale, shift, rstd, -mean * rstd]).float().contiguous()
-    return vec, mean, var
+        R % 32 == 0 and R < 2 ** 31
 
 
 class FusedSAMLP(Function):
@@ -52,34 +41,33 @@ class FusedSAMLP(Function):
         cout = [w.shape[0] for w in W]
         K1 = _round_up(C + 4, 16 if use_bf16 else 8)
         w1 = W[0][:, :, 0, 0]
-        W1p = torch.zeros((cout[0], K1), dtype=torch.float32, device=dev)
-        W1p[:, :C] = w1[:, 3:]
-        W1p[:, C:C + 3] = w1[:, :3]
+        # first-layer weight in the row layout [features | xyz | 0-pad]
+        W1p = torch.cat([w1[:, 3:], w1[:, :3], w1.new_zeros(cout[0], K1 - C - 3)], dim=1)
         Wd = [W1p.to(dt).contiguous(), W[1][:, :, 0, 0].to(dt).contiguous(), W[2][:, :, 0, 0].to(dt).contiguous()]
         Ks = [K1, cout[0], cout[1]]
-        Y, vecs = [], []
+        stats = torch.zeros((2 * sum(cout),), dtype=torch.float64, device=dev)
+        Y, vecs, off = [], [], 0
         for l in range(3):
             y = torch.empty((R, cout[l]), dtype=dt, device=dev)
-            stats = torch.zeros((2, cout[l]), dtype=torch.float64, device=dev)
+            st = stats[off:off + 2 * cout[l]]
+            off += 2 * cout[l]
             if l == 0:
                 _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
-                          cout[0], y, stats, bf)
+                          cout[0], y, st, bf)
             else:
                 _ext.call("vlp3d_sa_fwd_layer", Y[l - 1], R, Ks[l], vecs[l - 1][0], vecs[l - 1][1], Wd[l], cout[l], y,
-                          stats, bf)
+                          st, bf)
             bn = bns[l]
-            if training:
-                vec, mean, var = _bn_fold(stats, R, gam[l], bet[l], bn.eps)
-                if bn.track_running_stats:
-                    bn.num_batches_tracked.add_(1)
-                    f = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
-                    bn.running_mean.mul_(1 - f).add_(mean.float(), alpha=f)
-                    bn.running_var.mul_(1 - f).add_((var * (R / max(R - 1, 1))).float(), alpha=f)
+            vec = torch.empty((4, cout[l]), dtype=torch.float32, device=dev)
+            track = training and bn.track_running_stats
+            if track:
+                bn.num_batches_tracked.add_(1)
+                mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             else:
-                rstd = torch.rsqrt(bn.running_var.double() + bn.eps)
-                scale = gam[l].double() * rstd
-                vec = torch.stack([scale, bet[l].double() - bn.running_mean.double() * scale, rstd,
-                                   -bn.running_mean.double() * rstd]).float().contiguous()
+                mom = 0.0
+            _ext.call("vlp3d_sa_bn_fold", st, gam[l], bet[l], bn.running_mean if (track or not training) else None,
+                      bn.running_var if (track or not training) else None, cout[l], R, float(bn.eps), float(mom),
+                      int(training), vec)
             Y.append(y)
             vecs.append(vec)
         out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
@@ -87,7 +75,6 @@ class FusedSAMLP(Function):
         _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf)
         ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *Wd, *gam, *bet)
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
-        ctx.mark_non_differentiable(sel)
         return out
 
     @staticmethod
@@ -101,26 +88,22 @@ class FusedSAMLP(Function):
         need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
         dparams = [None] * 9
 
-        def bn5(l, t1, t2):
-            rstd, nm = vecs[l][2], vecs[l][3]
-            k1 = gam[l].float() * rstd
-            if training:
-                k2, k3 = (t1 / R).float(), (t2 / R).float()
-            else:
-                k2, k3 = torch.zeros_like(k1), torch.zeros_like(k1)
-            return torch.stack([rstd, nm, k1, k2, k3]).contiguous()
+        # all BN-backward reductions (2 x C per layer, fp64) live in one zeroed buffer
+        tbuf = torch.zeros((2 * sum(cout),), dtype=torch.float64, device=dev)
+        toff = [0, 2 * cout[0], 2 * cout[0] + 2 * cout[1]]
+        t = [tbuf[toff[l]:toff[l] + 2 * cout[l]] for l in range(3)]
 
-        # layer 3: masked gradient at the selected sample; its BN reductions come from the pooled tensors
+        # layer 3: masked gradient at the selected sample; its reductions come from the pooled tensors
         G = torch.empty((R, cout[2]), dtype=dt, device=dev)
         _ext.call("vlp3d_sa_pool_grad", dP, out, sel, B * M, S, cout[2], G, bf)
-        g3 = dP * (out > 0)
-        t1 = g3.sum(0).double()
-        gsafe = torch.where(gam[2] == 0, torch.ones_like(gam[2]), gam[2]).float()
-        t2 = (g3 * ((out - bet[2].float()) / gsafe)).sum(0).double()  # yhat_sel = (out - beta)/gamma where out > 0
+        _ext.call("vlp3d_sa_pool_tstats", dP, out, gam[2], bet[2], B * M, cout[2], t[2])
+        dfeat = dxyz = dnew = None
         for l in (2, 1, 0):
-            c5 = bn5(l, t1, t2)
-            dparams[3 * l + 1] = t2.float()  # d gamma
-            dparams[3 * l + 2] = t1.float()  # d beta
+            c5 = torch.empty((5, cout[l]), dtype=torch.float32, device=dev)
+            dg = torch.empty((cout[l],), dtype=torch.float32, device=dev)
+            db = torch.empty((cout[l],), dtype=torch.float32, device=dev)
+            _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t[l], cout[l], R, int(training), c5, dg, db)
+            dparams[3 * l + 1], dparams[3 * l + 2] = dg, db
             dW = torch.empty((cout[l], Ks[l]), dtype=torch.float32, device=dev)
             part = torch.empty((WGRAD_BLOCKS, cout[l], Ks[l]), dtype=torch.float32, device=dev)
             if l > 0:
@@ -129,18 +112,13 @@ class FusedSAMLP(Function):
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 WT = Wd[l].t().contiguous()
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
-                ts = torch.zeros((2, cout[l - 1]), dtype=torch.float64, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WT, cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
-                          ts, bf)
-                G, t1, t2 = Gp, ts[0], ts[1]
+                          t[l - 1], bf)
+                G = Gp
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
                           feat_pm, N, M, S, C, radius, dW, part, WGRAD_BLOCKS, bf)
-                dW1 = torch.empty((cout[0], C + 3), dtype=torch.float32, device=dev)
-                dW1[:, 3:] = dW[:, :C]
-                dW1[:, :3] = dW[:, C:C + 3]
-                dparams[0] = dW1.view(cout[0], C + 3, 1, 1)
-                dfeat = dxyz = dnew = None
+                dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
                     kpad = _round_up(C + 3, 32)
                     WT = torch.zeros((kpad, cout[0]), dtype=dt, device=dev)

@@ -99,7 +99,7 @@ def main():
     first, _ = ddp.shard_range(B_PER_GPU * world, rank, world)
     batch_np = synth.make_batch(first, B_PER_GPU, NUM_POINTS, LANG_NUM)
     batch = gs.batch_to_device(batch_np, device)
-    step = gs.GroundingStep(device, epoch=50, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
+    step = gs.GroundingStep(device, epoch=50, sa_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
                             use_graph=not args.no_graph, pipeline=not args.no_pipeline)
     ddp.broadcast_parameters(step.model)
 
@@ -153,6 +153,8 @@ def main():
             "config": {"workload": "cfg2: ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
                        "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                        "step": "fwd + reduced loss + bwd + flat grad all-reduce + AdamW",
+                       "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs, fp32 elsewhere"
+                                     if args.dtype == "bf16" else "fp32 everywhere (exact-fp32 MFMA)"),
                        "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
                        "geometry": "inline" if args.no_pipeline else
                        "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)", "loss": float(loss.detach())},

@@ -147,6 +147,19 @@ int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const fl
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                    float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream);
 
+/* per-channel bookkeeping of the fused layer (one launch each instead of ~20 framework kernels):
+ * bn_fold: vec (4 x C) = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums `stats` (training) or the
+ * running statistics (eval); training also updates running_mean/var (may be NULL) like nn.BatchNorm. */
+int vlp3d_sa_bn_fold(const double *stats, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, int C, long long R, float eps, float momentum, int training, float *vec,
+                     void *stream);
+/* bn5 (5 x C) backward constants, dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64. */
+int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int C, long long R, int training,
+                           float *bn5, float *dgamma, float *dbeta, void *stream);
+/* t (2 x C) f64 += [sum g, sum g*yhat] of the LAST layer computed from the pooled tensors (t zeroed by caller). */
+int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,
+                         double *t, void *stream);
+
 /* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
  * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
  * with MLP = Linear(4,32) ReLU LayerNorm(32) Linear(32,32) ReLU LayerNorm(32) Linear(32,4) (:26-37).
