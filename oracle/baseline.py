@@ -72,4 +72,5 @@ def scene_forward(xyz, feats, lang_num=8, seed=0):
 
 
 def threads_used():
-    return int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    """Threads the C/OpenMP part actually runs on (numpy's BLAS may use its own pool for the dense part)."""
+    return int(orc.lib().orc_num_threads())

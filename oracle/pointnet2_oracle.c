@@ -30,7 +30,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define TOTAL_THREADS 512 /* include/cuda_utils.h:18 */
+
+/* OpenMP threads the parallel loops below will use (1 without OpenMP) — reported by the CPU baseline. */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 static inline float sumsq3(float a, float b, float c, int contract) {
   if (contract == 1) return fmaf(c, c, fmaf(a, a, b * b));
