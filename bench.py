@@ -181,10 +181,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # one process per GPU.  (Rehearsal on a single-GPU box: VLP3D_DIST_BACKEND=gloo lets several ranks share cuda:0.)
+    backend = os.environ.get("VLP3D_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     synth = importlib.import_module("3dvlp_amd.synth")
     gs = importlib.import_module("3dvlp_amd.grounding_step")
