@@ -21,6 +21,8 @@ SIGNATURES = {
     "vlp3d_abi_version": [],
     "vlp3d_fp_contract": [],
     "vlp3d_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_fps_workspace_bytes": [_i, _i],
+    "vlp3d_furthest_point_sampling_pruned": [_vp, _i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "vlp3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
@@ -66,7 +68,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith("_bytes") else ctypes.c_int
         _lib = lib
     return _lib
 
@@ -112,15 +114,28 @@ def _chk_dev(ref, *others):
 
 
 # ---- the nine _ext functions (same names / argument order as bindings.cpp:12-23) ----
-def furthest_point_sampling(points, nsamples):
+FPS_PRUNED_MIN_N = 8192   # below this the all-register dense kernel wins (no sort pre-pass)
+FPS_PRUNED_MAX_N = 65536  # 64 slots per wave
+
+
+def furthest_point_sampling(points, nsamples, algorithm=None):
+    """algorithm: None = pick by N, "dense" (csrc/fps.hip) or "pruned" (csrc/fps_pruned.hip) — identical output."""
     _chk_float(points, "points")
     _chk_dev(points)
     B, N, _ = points.shape
     out = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)
-    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+    if algorithm is None:
+        algorithm = "pruned" if FPS_PRUNED_MIN_N <= N <= FPS_PRUNED_MAX_N else "dense"
     with torch.cuda.device(points.device):
-        _check(load().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
-               "furthest_point_sampling")
+        if algorithm == "pruned":
+            nbytes = int(load().vlp3d_fps_workspace_bytes(B, N))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+            _check(load().vlp3d_furthest_point_sampling_pruned(_p(points), B, N, int(nsamples), _p(ws), nbytes,
+                                                               _p(out), _stream()), "furthest_point_sampling_pruned")
+        else:
+            tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+            _check(load().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
+                   "furthest_point_sampling")
     return out
 
 

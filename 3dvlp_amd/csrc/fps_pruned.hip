@@ -1,0 +1,312 @@
+// Furthest point sampling with distance-bound pruning for gfx950 — same results, bit for bit, as the dense
+// kernel of fps.hip (and therefore as the reference's sampling_gpu.cu:74-178), but most of the
+// B*(m-1)*n distance updates are never executed.
+//
+// Idea: after j samples every running minimum temp[p] is <= r_j^2 (the current max-min distance), so the new
+// sample q can only lower temp[p] for points within r_j of q.  Points are first sorted by a 15-bit Morton cell
+// (counting sort, 4 small kernels), so that a "slot" = 64 consecutive sorted points (one per lane of one wave)
+// is spatially compact.  Lane i of a wave keeps the metadata of the wave's slot i: its exact bounding box and
+// its current (max temp, tie key) as the same 64-bit key the dense kernel reduces.  Per iteration a lane tests
+// its slot:  box_distance^2(q) * (1 - 1e-5)  <  slot max  — if not, NO point of the slot can change
+// (computed d >= box distance up to a few ulp, the margin covers fp32 rounding) and the slot is skipped
+// wholesale; its cached key still takes part in the argmax.  Active slots (ballot -> scalar loop over set bits)
+// stream their 64 points (x,y,z,temp as one float4, L2 resident), update temp, and recompute the slot key with
+// one wave reduction.  The block argmax then runs over 16 x nslots cached keys instead of n points.
+// Tie order, skip rule (|p|^2 <= 1e-3 -> never a candidate) and the fp32 distance expression are those of the
+// dense kernel; the original index needed by the tie key travels with the point (perm).
+#include "common.h"
+
+namespace {
+
+constexpr int CELL_BITS = 5;                  // per axis
+constexpr int NCELL = 1 << (3 * CELL_BITS);   // 32768 Morton cells per scene
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+  unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0xB1>(v);
+  v = dpp_max_u64<0x4E>(v);
+  v = dpp_max_u64<0x141>(v);
+  v = dpp_max_u64<0x140>(v);
+  unsigned long long a = readlane_u64(v, 0), b = readlane_u64(v, 16);
+  unsigned long long c = readlane_u64(v, 32), d = readlane_u64(v, 48);
+  a = a > b ? a : b;
+  c = c > d ? c : d;
+  return a > c ? a : c;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = IS_MAX ? fmaxf(v, o) : fminf(v, o);
+  }
+  return v;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ unsigned spread5(unsigned v) {  // 5 bits -> every third bit
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+
+// ---- pre-pass 1: per-scene bounding box, histogram cleared -------------------------------------------------
+__global__ __launch_bounds__(1024) void fps_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ bbox,
+                                                        int *__restrict__ hist) {
+  __shared__ float red[6][16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *p = xyz + (size_t)b * N * 3;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = tid; k < N; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = p[k * 3 + a];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float l = wave_minmax_f32<false>(lo[a]), h = wave_minmax_f32<true>(hi[a]);
+    if ((tid & 63) == 0) {
+      red[a][tid >> 6] = l;
+      red[3 + a][tid >> 6] = h;
+    }
+  }
+  for (int c = tid; c < NCELL; c += 1024) hist[(size_t)b * NCELL + c] = 0;
+  __syncthreads();
+  if (tid < 6) {
+    float v = red[tid][0];
+    for (int w = 1; w < 16; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+    bbox[b * 6 + tid] = v;
+  }
+}
+
+// ---- pre-pass 2: Morton cell of every point + histogram ------------------------------------------------------
+__global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__ xyz, int N,
+                                                       const float *__restrict__ bbox, int *__restrict__ cellid,
+                                                       int *__restrict__ hist) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  const float *p = xyz + ((size_t)b * N + k) * 3;
+  unsigned q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = bbox[b * 6 + a], hi = bbox[b * 6 + 3 + a];
+    const float ext = hi - lo;
+    float t = ext > 0.f ? (p[a] - lo) / ext * 32.f : 0.f;
+    int c = (int)t;
+    c = c < 0 ? 0 : (c > 31 ? 31 : c);  // also catches NaN -> 0
+    q[a] = (unsigned)c;
+  }
+  const int cell = (int)(spread5(q[0]) | (spread5(q[1]) << 1) | (spread5(q[2]) << 2));
+  cellid[(size_t)b * N + k] = cell;
+  atomicAdd(hist + (size_t)b * NCELL + cell, 1);
+}
+
+// ---- pre-pass 3: exclusive scan of the 32768 bins of a scene (in place) --------------------------------------
+__global__ __launch_bounds__(1024) void fps_scan_kernel(int *__restrict__ hist) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int *h = hist + (size_t)b * NCELL + tid * 32;
+  int loc[32], s = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    loc[i] = s;
+    s += h[i];
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int base = part[tid] - s;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) h[i] = base + loc[i];
+}
+
+// ---- pre-pass 4: scatter into sorted order: pts = (x, y, z, temp0), perm = original index ---------------------
+__global__ __launch_bounds__(256) void fps_scatter_kernel(const float *__restrict__ xyz, int N,
+                                                          const int *__restrict__ cellid, int *__restrict__ hist,
+                                                          float4 *__restrict__ pts, int *__restrict__ perm) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  const float *p = xyz + ((size_t)b * N + k) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  const int pos = atomicAdd(hist + (size_t)b * NCELL + cellid[(size_t)b * N + k], 1);
+  pts[(size_t)b * N + pos] = make_float4(x, y, z, vlp3d_fps_skipped(x, y, z) ? -1.f : 1e10f);
+  perm[(size_t)b * N + pos] = k;
+}
+
+// ---- main kernel ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restrict__ xyz_all, float4 *__restrict__ pts_all,
+                                                          const int *__restrict__ perm_all, int *__restrict__ idx_all,
+                                                          int N, int m, int log2P) {
+  __shared__ unsigned long long s_best[3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  float4 *__restrict__ pts = pts_all + (size_t)b * N;
+  const int *__restrict__ perm = perm_all + (size_t)b * N;
+  int *__restrict__ idx = idx_all + (size_t)b * m;
+  const int nslots = (N + 1023) / 1024;  // <= 64: lane i of a wave holds the metadata of the wave's slot i
+  const unsigned Pm1 = (1u << log2P) - 1u;
+  const unsigned lowmask = (unsigned)((1ull << (32 - log2P)) - 1ull);
+
+  auto make_key = [&](float t, int orig, bool valid) -> unsigned long long {
+    if (!(valid && t >= 0.f)) return 0ull;
+    const unsigned k = (unsigned)orig;
+    const unsigned tie = __brev(k & Pm1) | (k >> log2P);
+    return ((unsigned long long)(__float_as_uint(t) + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+  };
+
+  // per-lane metadata of slot `lane`: exact bounding box + cached 64-bit key
+  float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};
+  unsigned long long mykey = 0ull;
+  for (int i = 0; i < nslots; ++i) {
+    const int pos = i * 1024 + wave * 64 + lane;
+    const bool valid = pos < N;
+    const float4 p = pts[valid ? pos : N - 1];
+    const int o = perm[valid ? pos : N - 1];
+    float lo[3], hi[3];
+    const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = wave_minmax_f32<false>(valid ? c[a] : 3.0e38f);
+      hi[a] = wave_minmax_f32<true>(valid ? c[a] : -3.0e38f);
+    }
+    const unsigned long long k = wave_max_u64(make_key(p.w, o, valid));
+    if (lane == i) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        blo[a] = lo[a];
+        bhi[a] = hi[a];
+      }
+      mykey = k;
+    }
+  }
+  if (tid < 3) s_best[tid] = 0ull;
+  if (tid == 0) idx[0] = 0;
+  __syncthreads();
+
+  int old = 0, slot = 1;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+    // squared distance from the new sample to my slot's box; a slot whose bound exceeds its max is untouched
+    const float ex = fmaxf(0.f, fmaxf(blo[0] - x1, x1 - bhi[0]));
+    const float ey = fmaxf(0.f, fmaxf(blo[1] - y1, y1 - bhi[1]));
+    const float ez = fmaxf(0.f, fmaxf(blo[2] - z1, z1 - bhi[2]));
+    const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
+    const unsigned vk = (unsigned)(mykey >> 32);
+    const bool active = (lane < nslots) && (vk != 0u) && (lb2 < __uint_as_float(vk - 1u));
+    unsigned long long todo = __ballot(active);
+    while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time:
+      // all global loads of a batch are issued before the first wave reduction, so their latency overlaps
+      int si[4];
+      float4 p[4];
+      int o[4];
+      int nb = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        si[u] = -1;
+        if (todo != 0ull) {  // uniform
+          si[u] = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          nb = u + 1;
+          const int pos = si[u] * 1024 + wave * 64 + lane;
+          const int pc = pos < N ? pos : N - 1;
+          p[u] = pts[pc];
+          o[u] = perm[pc];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < nb) {  // uniform
+          const int pos = si[u] * 1024 + wave * 64 + lane;
+          const bool valid = pos < N;
+          const float d = vlp3d_sumsq3(p[u].x - x1, p[u].y - y1, p[u].z - z1);
+          const float t = vmin(d, p[u].w);
+          if (valid) pts[pos].w = t;
+          const unsigned long long k = wave_max_u64(make_key(t, o[u], valid));
+          if (lane == si[u]) mykey = k;
+        }
+      }
+    }
+    const unsigned long long cand = wave_max_u64(mykey);
+    if (lane == 0) atomicMax(&s_best[slot], cand);
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    if (tid == 0) s_best[nslot] = 0ull;
+    __syncthreads();
+    const unsigned long long g = s_best[slot];
+    slot = nslot;
+    unsigned k = 0u;
+    if ((unsigned)(g >> 32) != 0u) {
+      const unsigned tie = 0xFFFFFFFFu - (unsigned)g;
+      k = ((tie & lowmask) << log2P) | __brev(tie & ~lowmask);
+    }
+    old = __builtin_amdgcn_readfirstlane((int)k);
+    if (tid == 0) idx[j] = old;
+  }
+}
+
+int reference_log2_block(int n) {
+  int p = (int)(log((double)n) / log(2.0));
+  if (p > 9) p = 9;
+  if (p < 0) p = 0;
+  return p;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
+  if (B < 1 || N < 1) return 0;
+  return (long long)(align256((size_t)B * N * 16) + align256((size_t)B * N * 4) * 2 + align256((size_t)B * NCELL * 4) +
+                     align256((size_t)B * 6 * 4));
+}
+
+// Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
+// Requires N <= 65536 (64 slots per wave); same output as vlp3d_furthest_point_sampling.
+extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
+                                                    long long workspace_bytes, int *idx, void *stream) {
+  if (!xyz || !workspace || !idx || B < 1 || N < 1 || N > 65536 || m < 0 ||
+      workspace_bytes < vlp3d_fps_workspace_bytes(B, N))
+    return VLP3D_EINVAL;
+  if (m == 0) return VLP3D_OK;
+  hipStream_t s = (hipStream_t)stream;
+  char *w = (char *)workspace;
+  float4 *pts = (float4 *)w;
+  w += align256((size_t)B * N * 16);
+  int *perm = (int *)w;
+  w += align256((size_t)B * N * 4);
+  int *cellid = (int *)w;
+  w += align256((size_t)B * N * 4);
+  int *hist = (int *)w;
+  w += align256((size_t)B * NCELL * 4);
+  float *bbox = (float *)w;
+  const dim3 gridN((N + 255) / 256, B);
+  hipLaunchKernelGGL(fps_bbox_kernel, dim3(B), dim3(1024), 0, s, xyz, N, bbox, hist);
+  hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist);
+  hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
+  hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
+  hipLaunchKernelGGL(fps_pruned_kernel, dim3(B), dim3(1024), 0, s, xyz, pts, perm, idx, N, m, reference_log2_block(N));
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

@@ -47,6 +47,13 @@ int vlp3d_fp_contract(void);
  * tie order as the reference's 512-thread LDS tree. */
 int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *temp, int *idx, void *stream);
 
+/* Same output as vlp3d_furthest_point_sampling, computed with distance-bound pruning (csrc/fps_pruned.hip):
+ * points are Morton-sorted into 64-point slots and a slot whose bounding box is farther from the new sample than
+ * its current maximum is skipped.  workspace: vlp3d_fps_workspace_bytes(B,N) bytes of scratch.  N <= 65536. */
+long long vlp3d_fps_workspace_bytes(int B, int N);
+int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
+                                         long long workspace_bytes, int *idx, void *stream);
+
 /* replaces gather_points — sampling.cpp:20-43. points (B,C,N), idx (B,M) -> out (B,C,M). */
 int vlp3d_gather_points(const float *points, const int *idx, int B, int C, int N, int M, float *out, void *stream);
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "vlp3d.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char \*)\s*(vlp3d_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|long long|const char \*)\s*(vlp3d_\w+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

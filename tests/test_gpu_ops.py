@@ -58,6 +58,32 @@ def test_fps_ties_and_skip_rule(pu, N):
     assert (got == orc.furthest_point_sampling(xyz, m)).all()
 
 
+@pytest.mark.parametrize("B,N,m", [(2, 9000, 300), (2, 20000, 512), (1, 40000, 700), (1, 65536, 64), (3, 5000, 5000)])
+def test_fps_pruned_equals_dense_and_oracle(ext, B, N, m):
+    """Distance-bound pruning must not change a single index (random surfaces-like data)."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    xyz = np.stack([synth.make_scene(2000 + i, N)["xyz"] for i in range(B)])
+    t = dev(xyz)
+    pruned = ext.furthest_point_sampling(t, m, "pruned").cpu().numpy()
+    dense = ext.furthest_point_sampling(t, m, "dense").cpu().numpy()
+    assert (pruned == dense).all()
+    assert (pruned == orc.furthest_point_sampling(xyz, m)).all()
+
+
+@pytest.mark.parametrize("N", [1500, 9000, 36000])
+def test_fps_pruned_ties_and_skip_rule(ext, N):
+    rng = np.random.default_rng(N + 1)
+    xyz = rng.integers(1, 4, size=(3, N, 3)).astype(np.float32)  # massive exact ties
+    xyz[:, 5] = 0.01
+    xyz[1, 0] = 0.0
+    xyz[2, -1] = np.float32(np.sqrt(1e-3 / 3))
+    m = min(N, 300)
+    got = ext.furthest_point_sampling(dev(xyz), m, "pruned").cpu().numpy()
+    assert (got == orc.furthest_point_sampling(xyz, m)).all()
+    skipped = np.full((2, 200, 3), 0.001, np.float32)
+    assert (ext.furthest_point_sampling(dev(skipped), 10, "pruned").cpu().numpy() == 0).all()
+
+
 def test_fps_all_points_skipped(pu):
     xyz = np.full((2, 100, 3), 0.001, np.float32)
     got = pu.furthest_point_sample(dev(xyz), 10).cpu().numpy()
