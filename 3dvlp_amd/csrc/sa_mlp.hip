@@ -86,6 +86,11 @@ struct RowGemmArgs {
   double *tstats;  // [2][COUT]: sum g, sum g*yhat
   // SCATTER
   float *dfeat_pm, *dxyz, *dnew_xyz;
+  // BNBWD of the LAST layer: the masked gradient is synthesised from the pooled tensors (BM x ldin) instead of
+  // being read from a dense (R x ldin) matrix: g[r][c] = (sel[bm][c] == s && out[bm][c] > 0) ? dP[bm][c] : 0
+  const float *pool_g;   // (BM x ldin): dP where out > 0, else 0 (written by pool_tstats)
+  const unsigned char *pool_sel;
+  int pool_S, pool_shift;  // pool_shift = log2(pool_S) when it is a power of two, else -1
 };
 
 template <typename T, int LOADER>
@@ -108,7 +113,18 @@ __device__ __forceinline__ float4 load_a4(const RowGemmArgs &a, long long row, i
                        fmaxf(0.f, y.w * sc.w + sh.w));
   }
   // BNBWD
-  const float4 g = ld4(reinterpret_cast<const T *>(a.Gin) + row * a.ldin + col0);
+  float4 g;
+  if (a.pool_g != nullptr) {  // kernel-uniform
+    const int bm = a.pool_shift >= 0 ? ((int)row >> a.pool_shift) : ((int)row / a.pool_S);
+    const int sidx = (int)row - bm * a.pool_S;
+    const long long off = (long long)bm * a.ldin + col0;
+    const float4 dp = ld4(a.pool_g + off);
+    const uchar4 sl = *reinterpret_cast<const uchar4 *>(a.pool_sel + off);
+    g = make_float4(sl.x == sidx ? dp.x : 0.f, sl.y == sidx ? dp.y : 0.f, sl.z == sidx ? dp.z : 0.f,
+                    sl.w == sidx ? dp.w : 0.f);
+  } else {
+    g = ld4(reinterpret_cast<const T *>(a.Gin) + row * a.ldin + col0);
+  }
   const float4 rs = ld4(a.rstd + col0), nm = ld4(a.nmean_rstd + col0);
   const float4 k1 = ld4(a.k1 + col0), k2 = ld4(a.k2 + col0), k3 = ld4(a.k3 + col0);
   return make_float4(k1.x * (g.x - k2.x - (y.x * rs.x + nm.x) * k3.x), k1.y * (g.y - k2.y - (y.y * rs.y + nm.y) * k3.y),
@@ -499,7 +515,8 @@ __global__ void bn5_kernel(const float *__restrict__ vec, const float *__restric
 __global__ __launch_bounds__(256) void pool_tstats_kernel(const float *__restrict__ dP, const float *__restrict__ out,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, long long BM, int C,
-                                                          long long rows_per_block, double *__restrict__ t) {
+                                                          long long rows_per_block, double *__restrict__ t,
+                                                          float *__restrict__ gsel) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(BM, r0 + rows_per_block);
@@ -509,11 +526,21 @@ __global__ __launch_bounds__(256) void pool_tstats_kernel(const float *__restric
   for (long long r = r0; r < r1; ++r) {
     const float o = out[r * C + c];
     const float d = o > 0.f ? dP[r * C + c] : 0.f;
+    gsel[r * C + c] = d;
     s1 += d;
     s2 += d * ((o - b) * inv);
   }
   atomicAdd(t + c, s1);
   atomicAdd(t + C + c, s2);
+}
+
+void set_pool(RowGemmArgs &a, const float *pool_g, const unsigned char *pool_sel, int pool_S) {
+  a.pool_g = pool_g;
+  a.pool_sel = pool_sel;
+  a.pool_S = pool_S;
+  a.pool_shift = -1;
+  for (int sh = 0; sh < 31; ++sh)
+    if ((1 << sh) == pool_S) a.pool_shift = sh;
 }
 
 unsigned grid_tiles(long long R) {
@@ -642,8 +669,9 @@ extern "C" int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsig
 // layer l-1 (4 x kprev).  Writes G_{l-1} (R x kprev) and accumulates tstats (2 x kprev).
 extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT,
                                   int kprev, const void *Yprev, const float *prev4, void *Gprev, double *tstats,
-                                  int bf16_io, void *stream) {
-  if (!G || !Y || !bn5 || !WT || !Yprev || !prev4 || !Gprev || !tstats || R < 32 || (R & 31) ||
+                                  const float *pool_g, const unsigned char *pool_sel, int pool_S, int bf16_io,
+                                  void *stream) {
+  if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || !WT || !Yprev || !prev4 || !Gprev || !tstats || R < 32 || (R & 31) ||
       (ld % (bf16_io ? 16 : 8)))
     return VLP3D_EINVAL;
   RowGemmArgs a = {};
@@ -653,6 +681,7 @@ extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int
   a.Yout = Gprev; a.ldout = kprev; a.Yprev = Yprev; a.ldprev = kprev;
   a.p_scale = prev4; a.p_shift = prev4 + kprev; a.p_rstd = prev4 + 2 * kprev; a.p_nmean_rstd = prev4 + 3 * kprev;
   a.tstats = tstats;
+  if (!G) set_pool(a, pool_g, pool_sel, pool_S);
   return bf16_io ? launch_row_gemm<bf16>(BNBWD, MASK, kprev, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(BNBWD, MASK, kprev, a, (hipStream_t)stream);
 }
@@ -680,8 +709,9 @@ extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const f
 extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
                               const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                               const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
-                              float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream) {
-  if (!G || !Y || !bn5 || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
+                              float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
+                              const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream) {
+  if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
   WgradArgs w = {};
   w.src.K = K; w.src.R = R;
   if (gather) {
@@ -693,6 +723,7 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
     w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;
   }
   w.dy.Gin = G; w.dy.Yin = Y; w.dy.ldin = cout;
+  if (!G) set_pool(w.dy, pool_g, pool_sel, pool_S);
   w.dy.rstd = bn5; w.dy.nmean_rstd = bn5 + cout; w.dy.k1 = bn5 + 2 * cout; w.dy.k2 = bn5 + 3 * cout;
   w.dy.k3 = bn5 + 4 * cout;
   w.KP = (K + 31) & ~31;
@@ -739,12 +770,13 @@ extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, cons
 
 // t (2 x C) f64 += [sum g, sum g*yhat] of the last layer from the pooled tensors (t zeroed by the caller).
 extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta,
-                                    long long BM, int C, double *t, void *stream) {
-  if (!dP || !out || !gamma || !beta || !t || BM < 1 || C < 1) return VLP3D_EINVAL;
+                                    long long BM, int C, double *t, float *gsel, void *stream) {
+  if (!dP || !out || !gamma || !beta || !t || !gsel || BM < 1 || C < 1) return VLP3D_EINVAL;
   long long rpb = (BM + 127) / 128;
   if (rpb < 16) rpb = 16;
   const dim3 grid((C + 255) / 256, (unsigned)((BM + rpb - 1) / rpb));
-  hipLaunchKernelGGL(pool_tstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dP, out, gamma, beta, BM, C, rpb, t);
+  hipLaunchKernelGGL(pool_tstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dP, out, gamma, beta, BM, C, rpb, t,
+                     gsel);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

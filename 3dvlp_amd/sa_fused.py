@@ -93,10 +93,12 @@ class FusedSAMLP(Function):
         toff = [0, 2 * cout[0], 2 * cout[0] + 2 * cout[1]]
         t = [tbuf[toff[l]:toff[l] + 2 * cout[l]] for l in range(3)]
 
-        # layer 3: masked gradient at the selected sample; its reductions come from the pooled tensors
-        G = torch.empty((R, cout[2]), dtype=dt, device=dev)
-        _ext.call("vlp3d_sa_pool_grad", dP, out, sel, B * M, S, cout[2], G, bf)
-        _ext.call("vlp3d_sa_pool_tstats", dP, out, gam[2], bet[2], B * M, cout[2], t[2])
+        # layer 3: the masked gradient lives only at the selected sample of each ball — it is synthesised inside the
+        # loaders from (dP, out, sel), and its BN reductions come from the pooled tensors
+        G = None
+        gsel = torch.empty_like(out)
+        _ext.call("vlp3d_sa_pool_tstats", dP, out, gam[2], bet[2], B * M, cout[2], t[2], gsel)
+        pool = (gsel, sel, S)
         dfeat = dxyz = dnew = None
         for l in (2, 1, 0):
             c5 = torch.empty((5, cout[l]), dtype=torch.float32, device=dev)
@@ -108,16 +110,17 @@ class FusedSAMLP(Function):
             part = torch.empty((WGRAD_BLOCKS, cout[l], Ks[l]), dtype=torch.float32, device=dev)
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
-                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, WGRAD_BLOCKS, bf)
+                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, WGRAD_BLOCKS,
+                          *(pool if G is None else (None, None, 0)), bf)
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 WT = Wd[l].t().contiguous()
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WT, cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
-                          t[l - 1], bf)
+                          t[l - 1], *(pool if G is None else (None, None, 0)), bf)
                 G = Gp
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, part, WGRAD_BLOCKS, bf)
+                          feat_pm, N, M, S, C, radius, dW, part, WGRAD_BLOCKS, None, None, 0, bf)
                 dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
                     kpad = _round_up(C + 3, 32)

@@ -138,9 +138,12 @@ int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *s
                        void *G, int bf16_io, void *stream);
 /* G_{l-1} = relu-mask(BNbwd(G_l, Y_l) * W_l), tstats (2 x kprev) f64 += [sum g, sum g*yhat] of layer l-1.
  * bn5 = [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)] (5 x ld) of layer l; WT = W_l^T (kprev x ld);
- * prev4 = [scale | shift | rstd | -mean*rstd] (4 x kprev) of layer l-1. */
+ * prev4 = [scale | shift | rstd | -mean*rstd] (4 x kprev) of layer l-1.
+ * LAST layer: pass G = NULL and the pooled tensors (pool_g = gsel of vlp3d_sa_pool_tstats, sel (BM x ld) u8, pool_S = nsample):
+ * the masked gradient is then synthesised on the fly (no dense (R x ld) gradient matrix is ever written). */
 int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT, int kprev,
-                       const void *Yprev, const float *prev4, void *Gprev, double *tstats, int bf16_io, void *stream);
+                       const void *Yprev, const float *prev4, void *Gprev, double *tstats, const float *pool_g,
+                       const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream);
 /* layer 1 input gradient, scatter-added (NOT zeroed here) into dfeat_pm (B,N,C) / dxyz (B,N,3) / dnew_xyz (B,M,3)
  * (each optional).  WT = W_1^T zero-padded to (kpad x ld), kpad % 32 == 0. */
 int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
@@ -148,11 +151,12 @@ int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, 
                         float *dnew_xyz, int bf16_io, void *stream);
 /* dW (cout x K) f32 = sum_r BNbwd(G,Y)[r]^T A[r]; A = relu(Yprev*scale+shift) (gather == 0) or the gathered
  * layer-1 rows (gather != 0).  partials: scratch of max_blocks*cout*K floats (one slab per workgroup, summed by
- * a second kernel: no contended atomics); dW is fully written. */
+ * a second kernel: no contended atomics); dW is fully written.  G = NULL + pooled tensors as in vlp3d_sa_bwd_layer. */
 int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const float *bn5, int gather,
                    const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
-                   float radius, float *dW, float *partials, int max_blocks, int bf16_io, void *stream);
+                   float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
+                   const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream);
 
 /* per-channel bookkeeping of the fused layer (one launch each instead of ~20 framework kernels):
  * bn_fold: vec (4 x C) = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums `stats` (training) or the
@@ -163,9 +167,10 @@ int vlp3d_sa_bn_fold(const double *stats, const float *gamma, const float *beta,
 /* bn5 (5 x C) backward constants, dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64. */
 int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int C, long long R, int training,
                            float *bn5, float *dgamma, float *dbeta, void *stream);
-/* t (2 x C) f64 += [sum g, sum g*yhat] of the LAST layer computed from the pooled tensors (t zeroed by caller). */
+/* t (2 x C) f64 += [sum g, sum g*yhat] of the LAST layer computed from the pooled tensors (t zeroed by caller);
+ * gsel (BM x C) f32 = dP where out > 0 else 0 (the ReLU-masked pooled gradient the last-layer loaders read). */
 int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,
-                         double *t, void *stream);
+                         double *t, float *gsel, void *stream);
 
 /* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
  * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
