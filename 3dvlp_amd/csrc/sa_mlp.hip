@@ -176,6 +176,30 @@ struct Mma<bf16, NCT> {
   }
 };
 
+// Per-column reductions of a workgroup -> its own slab [blockIdx.x][2][COUT] (fp64).  Thousands of waves adding
+// atomically into the same 2*COUT addresses serialise at the memory side (that alone cost ~0.4 ms per launch at
+// R = 1 M); the consumers (bn_fold / bn_bwd_consts) sum the slabs instead.
+template <int COUT>
+__device__ __forceinline__ void block_stats_to_slab(const double (&s1)[COUT / 32], const double (&s2)[COUT / 32],
+                                                    double *__restrict__ slabs, int r, int half, int wave) {
+  __shared__ double red[4][2][COUT];
+#pragma unroll
+  for (int ct = 0; ct < COUT / 32; ++ct) {
+    const double t1 = s1[ct] + __shfl_xor(s1[ct], 32);
+    const double t2 = s2[ct] + __shfl_xor(s2[ct], 32);
+    if (half == 0) {
+      red[wave][0][32 * ct + r] = t1;
+      red[wave][1][32 * ct + r] = t2;
+    }
+  }
+  __syncthreads();
+  double *slab = slabs + (size_t)blockIdx.x * 2 * COUT;
+  for (int i = threadIdx.x; i < 2 * COUT; i += 256) {
+    const int which = i / COUT, c = i - which * COUT;
+    slab[i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
 template <typename T, int COUT, int LOADER, int EPI>
 __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   constexpr int NCT = COUT / 32;
@@ -261,18 +285,161 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
     }
   }
 
-  if (EPI == STORE || EPI == MASK) {
-    double *out = (EPI == STORE) ? a.stats : a.tstats;
+  if (EPI == STORE || EPI == MASK) block_stats_to_slab<COUT>(s1, s2, (EPI == STORE) ? a.stats : a.tstats, r, half, wave);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row_gemm_lds (bf16): same products, loaders and epilogues as row_gemm, but the operands reach the matrix
+// cores through LDS so that every global access is a full, coalesced row segment:
+//   * W (COUT x K) is staged once per workgroup;
+//   * each wave loads its 32 x K tile cooperatively — consecutive lanes read consecutive 16-byte chunks of a row
+//     (the direct form has every lane on a different row: 64 cache lines per load instruction) — applies the
+//     loader's element-wise stage, and writes bf16 into its private LDS tile;
+//   * MFMA fragments come back with ds_read_b128; rows are padded by 16 bytes, which makes the 16-lane groups of
+//     ds_read_b128 hit 16 distinct 4-bank slots (conflict-free for every K used here).
+// The tile of a wave is private, so no workgroup barrier is needed inside the tile loop (LDS is in order per wave).
+// ------------------------------------------------------------------------------------------------
+template <int LOADER>
+__device__ __forceinline__ void tile_chunk_load(const RowGemmArgs &a, int row, int col0, float4 &v0, float4 &v1) {
+  long long gb = 0, xb = 0, cb = 0;
+  if (LOADER == GATHER) {
+    const int bm = row / a.S, b = bm / a.M;
+    const long long p = a.idx[row];
+    gb = ((long long)b * a.N + p) * a.C;
+    xb = ((long long)b * a.N + p) * 3;
+    cb = (long long)bm * 3;
+  }
+  v0 = load_a4<bf16, LOADER>(a, row, col0, gb, xb, cb);
+  v1 = load_a4<bf16, LOADER>(a, row, col0 + 4, gb, xb, cb);
+}
+
+__device__ __forceinline__ uint4 pack8(const float4 &a0, const float4 &a1) {
+  union {
+    short h[8];
+    uint4 u;
+  } p;
+  p.h[0] = bf16_bits(a0.x); p.h[1] = bf16_bits(a0.y); p.h[2] = bf16_bits(a0.z); p.h[3] = bf16_bits(a0.w);
+  p.h[4] = bf16_bits(a1.x); p.h[5] = bf16_bits(a1.y); p.h[6] = bf16_bits(a1.z); p.h[7] = bf16_bits(a1.w);
+  return p.u;
+}
+
+template <int COUT, int LOADER, int EPI>
+__global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
+  typedef bf16 T;
+  constexpr int NCT = COUT / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = a.K, ldw = K + 8, kc = K / 8;  // kc = 16-byte chunks per row
+  bf16 *sW = reinterpret_cast<bf16 *>(smem);
+  bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * 32 * ldw;
+  const long long ntiles = a.R / 32;
+
+  {  // stage the weight once per workgroup
+    const bf16 *W = reinterpret_cast<const bf16 *>(a.W);
+    for (int c = threadIdx.x; c < COUT * kc; c += 256) {
+      const int row = c / kc, ch = c - row * kc;
+      *reinterpret_cast<uint4 *>(sW + row * ldw + ch * 8) = *reinterpret_cast<const uint4 *>(W + (long long)row * K + ch * 8);
+    }
+  }
+  __syncthreads();
+
+  double s1[NCT], s2[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const double t1 = s1[ct] + __shfl_xor(s1[ct], 32);
-      const double t2 = s2[ct] + __shfl_xor(s2[ct], 32);
-      if (half == 0) {
-        atomicAdd(out + 32 * ct + r, t1);
-        atomicAdd(out + COUT + 32 * ct + r, t2);
+  for (int ct = 0; ct < NCT; ++ct) s1[ct] = s2[ct] = 0.0;
+
+  const int nch = 32 * kc;  // chunks of this wave's tile; 64 lanes take them 64 at a time, 4 batches in flight
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const int row0 = (int)(tile * 32);
+    for (int c0 = 0; c0 < nch; c0 += 256) {
+      float4 v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
+        const int c = min(c0 + 64 * u + lane, nch - 1);
+        const int row = c / kc, ch = c - row * kc;
+        tile_chunk_load<LOADER>(a, row0 + row, ch * 8, v0[u], v1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 64 * u + lane;
+        if (c < nch) {
+          const int row = c / kc, ch = c - row * kc;
+          *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = pack8(v0[u], v1[u]);
+        }
+      }
+    }
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
+    const bf16 *pa = sA + r * ldw + 8 * half;
+    const bf16 *pw = sW + r * ldw + 8 * half;
+    for (int g = 0; g < K / 16; ++g) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8 *>(pa + 16 * g);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(pw + (32 * ct) * ldw + 16 * g);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ct], 0, 0, 0);
+      }
+    }
+
+    if (EPI == STORE) {
+      T *Y = reinterpret_cast<T *>(a.Yout);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[ct][i];
+          st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, v);
+          ps += v;
+          pq += v * v;
+        }
+        s1[ct] += (double)ps;
+        s2[ct] += (double)pq;
+      }
+    } else if (EPI == MASK) {
+      T *G = reinterpret_cast<T *>(a.Yout);
+      const T *Yp = reinterpret_cast<const T *>(a.Yprev);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 32 * ct + r;
+        const float sc = a.p_scale[col], sh = a.p_shift[col], rs = a.p_rstd[col], nm = a.p_nmean_rstd[col];
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long long rr = tile * 32 + acc_row(i, half);
+          const float y = ld1(Yp + rr * a.ldprev + col);
+          const float g = (y * sc + sh > 0.f) ? acc[ct][i] : 0.f;
+          st1(G + rr * a.ldout + col, g);
+          ps += g;
+          pq += g * (y * rs + nm);
+        }
+        s1[ct] += (double)ps;
+        s2[ct] += (double)pq;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long long rr = tile * 32 + acc_row(i, half);
+        const long long bm = rr / a.S, b = bm / a.M;
+        const long long p = a.idx[rr];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int col = 32 * ct + r;
+          const float v = acc[ct][i];
+          if (col < a.C) {
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + (b * a.N + p) * a.C + col, v);
+          } else if (col < a.C + 3) {
+            const float gv = v / a.radius;
+            if (a.dxyz) atomicAdd(a.dxyz + (b * a.N + p) * 3 + (col - a.C), gv);
+            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + bm * 3 + (col - a.C), -gv);
+          }
+        }
       }
     }
   }
+
+  if (EPI == STORE || EPI == MASK) block_stats_to_slab<COUT>(s1, s2, (EPI == STORE) ? a.stats : a.tstats, r, half, wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,17 +633,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // Per-channel bookkeeping of the fused layer (each replaces ~20 tiny framework kernels per BatchNorm):
 // ------------------------------------------------------------------------------------------------
+// Sum the per-workgroup slabs [nslab][2][C] for 16 columns per block: 256 threads = 16 slab-groups x 16 columns.
+// Returns (sum of [0][c], sum of [1][c]) to the threads of group 0 (threadIdx.x < 16); c = blockIdx.x*16 + col.
+__device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int nslab, int C, double &s0, double &s1) {
+  __shared__ double red[2][16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + col;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int k = grp; k < nslab; k += 16) {
+      a += slabs[(size_t)k * 2 * C + c];
+      b += slabs[(size_t)k * 2 * C + C + c];
+    }
+  red[0][grp][col] = a;
+  red[1][grp][col] = b;
+  __syncthreads();
+  s0 = s1 = 0.0;
+  if (grp == 0)
+    for (int g = 0; g < 16; ++g) {
+      s0 += red[0][g][col];
+      s1 += red[1][g][col];
+    }
+}
+
 // bn_fold: batch statistics (fp64 sums) -> vec[4][C] = [scale | shift | rstd | -mean*rstd], running-stat update.
-__global__ void bn_fold_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
+__global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, const float *__restrict__ gamma,
                                const float *__restrict__ beta, float *__restrict__ running_mean,
                                float *__restrict__ running_var, int C, double R, float eps, float momentum,
                                int training, float *__restrict__ vec) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  if (training) slab_sum16(stats, nslab, C, s, q);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (threadIdx.x >= 16 || c >= C) return;
   double mean, var;
   if (training) {
-    mean = stats[c] / R;
-    var = stats[C + c] / R - mean * mean;
+    mean = s / R;
+    var = q / R - mean * mean;
     if (var < 0.0) var = 0.0;
     if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -496,18 +688,20 @@ __global__ void bn_fold_kernel(const double *__restrict__ stats, const float *__
 
 // bn5: backward constants [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)] + d gamma, d beta
 __global__ void bn5_kernel(const float *__restrict__ vec, const float *__restrict__ gamma,
-                           const double *__restrict__ t, int C, double R, int training, float *__restrict__ bn5,
-                           float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+                           const double *__restrict__ tslabs, int nslab, int C, double R, int training,
+                           float *__restrict__ bn5, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  double t[2];
+  slab_sum16(tslabs, nslab, C, t[0], t[1]);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (threadIdx.x >= 16 || c >= C) return;
   const float rstd = vec[2 * C + c];
   bn5[c] = rstd;
   bn5[C + c] = vec[3 * C + c];
   bn5[2 * C + c] = gamma[c] * rstd;
-  bn5[3 * C + c] = training ? (float)(t[c] / R) : 0.f;
-  bn5[4 * C + c] = training ? (float)(t[C + c] / R) : 0.f;
-  dbeta[c] = (float)t[c];
-  dgamma[c] = (float)t[C + c];
+  bn5[3 * C + c] = training ? (float)(t[0] / R) : 0.f;
+  bn5[4 * C + c] = training ? (float)(t[1] / R) : 0.f;
+  dbeta[c] = (float)t[0];
+  dgamma[c] = (float)t[1];
 }
 
 // BN-backward reductions of the LAST layer straight from the pooled tensors: only the selected sample of each
@@ -565,8 +759,51 @@ int launch_row_gemm_t(int cout, const RowGemmArgs &a, hipStream_t s) {
   return VLP3D_OK;
 }
 
+template <int COUT, int LOADER, int EPI>
+int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
+  const size_t lds = (size_t)(COUT + 4 * 32) * (a.K + 8) * sizeof(bf16);
+  if (lds > 160 * 1024) return VLP3D_EINVAL;
+  auto kern = row_gemm_lds_kernel<COUT, LOADER, EPI>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid_tiles(a.R)), dim3(256), lds, s, a);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+template <int LOADER, int EPI>
+int launch_row_gemm_lds(int cout, const RowGemmArgs &a, hipStream_t s) {
+  switch (cout) {
+    case 64: return launch_lds_c<64, LOADER, EPI>(a, s);
+    case 128: return launch_lds_c<128, LOADER, EPI>(a, s);
+    case 160: return launch_lds_c<160, LOADER, EPI>(a, s);
+    case 256: return launch_lds_c<256, LOADER, EPI>(a, s);
+    case 288: return launch_lds_c<288, LOADER, EPI>(a, s);
+    default: return VLP3D_EINVAL;
+  }
+}
+
+template <int LOADER, int EPI>
+int launch_bf16(int cout, const RowGemmArgs &a, hipStream_t s) {
+  // the LDS form needs K % 16 == 0 (always true for bf16 storage here); fall back to the direct form otherwise
+  const bool lds_shape = cout == 64 || cout == 128 || cout == 160 || cout == 256 || cout == 288;
+  if (lds_shape && a.K % 16 == 0 && (size_t)(cout + 128) * (a.K + 8) * 2 <= 160 * 1024)
+    return launch_row_gemm_lds<LOADER, EPI>(cout, a, s);
+  return launch_row_gemm_t<bf16, LOADER, EPI>(cout, a, s);
+}
+
 template <typename T>
 int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStream_t s) {
+  if (sizeof(T) == 2) {
+    if (loader == GATHER && epi == STORE) return launch_bf16<GATHER, STORE>(cout, a, s);
+    if (loader == BNRELU && epi == STORE) return launch_bf16<BNRELU, STORE>(cout, a, s);
+    if (loader == BNBWD && epi == MASK) return launch_bf16<BNBWD, MASK>(cout, a, s);
+    if (loader == BNBWD && epi == SCATTER) return launch_bf16<BNBWD, SCATTER>(cout, a, s);
+    return VLP3D_EINVAL;
+  }
   if (loader == GATHER && epi == STORE) return launch_row_gemm_t<T, GATHER, STORE>(cout, a, s);
   if (loader == BNRELU && epi == STORE) return launch_row_gemm_t<T, BNRELU, STORE>(cout, a, s);
   if (loader == BNBWD && epi == MASK) return launch_row_gemm_t<T, BNBWD, MASK>(cout, a, s);
@@ -747,22 +984,25 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
 
 // vec (4 x C) f32 = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums (training) or the running
 // statistics (eval); in training also updates running_mean / running_var (may be NULL) with `momentum`.
-extern "C" int vlp3d_sa_bn_fold(const double *stats, const float *gamma, const float *beta, float *running_mean,
-                                float *running_var, int C, long long R, float eps, float momentum, int training,
-                                float *vec, void *stream) {
-  if (!gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
+extern "C" int vlp3d_sa_stat_slabs(long long R) { return (int)grid_tiles(R); }
+
+extern "C" int vlp3d_sa_bn_fold(const double *stats, int nslab, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, int C, long long R, float eps, float momentum,
+                                int training, float *vec, void *stream) {
+  if (nslab < 1 || !gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
     return VLP3D_EINVAL;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, nslab, gamma, beta,
                      running_mean, running_var, C, (double)R, eps, momentum, training, vec);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
 
 // bn5 (5 x C) backward constants + dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64.
-extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int C, long long R,
-                                      int training, float *bn5, float *dgamma, float *dbeta, void *stream) {
-  if (!vec || !gamma || !t || !bn5 || !dgamma || !dbeta || C < 1 || R < 1) return VLP3D_EINVAL;
-  hipLaunchKernelGGL(bn5_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, vec, gamma, t, C, (double)R,
+extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int nslab, int C,
+                                      long long R, int training, float *bn5, float *dgamma, float *dbeta,
+                                      void *stream) {
+  if (nslab < 1 || !vec || !gamma || !t || !bn5 || !dgamma || !dbeta || C < 1 || R < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(bn5_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, vec, gamma, t, nslab, C, (double)R,
                      training, bn5, dgamma, dbeta);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

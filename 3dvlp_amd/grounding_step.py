@@ -210,9 +210,43 @@ class GroundingStep:
             for _ in range(2):
                 self._fwd_bwd(self._static_batch, self._static_next)
         torch.cuda.current_stream().wait_stream(warm)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_loss = self._fwd_bwd(self._static_batch, self._static_next)
+        torch.cuda.synchronize()
+        if not self.pipeline:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_loss = self._fwd_bwd(self._static_batch, self._static_next)
+            return
+        # Pipelined: THREE single-stream graphs instead of one graph with a forked branch.  ROCm launches a
+        # linear graph in ~0.3 ms of host time but walks a multi-stream graph node by node (16 ms for the 1300
+        # nodes of this step), which made the step host-bound.  The fork/join are two events outside the graphs:
+        #   gC (main): hand the prepared geometry over;   gS (side): geometry of the next batch;
+        #   gM (main): forward + loss + backward of the current batch.
+        backbone = self.model.backbone_net
+        self._gC, self._gS, self._gM = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._gC):
+            self._copy_geometry(self._geom_cur, self._geom_next)
+        with torch.cuda.graph(self._gS, stream=self._side):
+            nxt = backbone.compute_geometry(self._static_next["point_clouds"])
+            self._copy_geometry(self._geom_next, nxt)
+        with torch.cuda.graph(self._gM):
+            self.bucket.zero()
+            loss, _ = self.forward_loss(self._static_batch, self._geom_cur)
+            loss.backward()
+            self.bucket.collect()
+            self._static_loss = loss.detach()
+        self._graph = self._gM
+
+    def _replay(self):
+        if not self.pipeline:
+            self._graph.replay()
+            return
+        cur = torch.cuda.current_stream()
+        self._gC.replay()
+        self._side.wait_stream(cur)          # fork: geometry of the next batch may overwrite _geom_next now
+        with torch.cuda.stream(self._side):
+            self._gS.replay()
+        self._gM.replay()
+        cur.wait_stream(self._side)          # join
 
     @staticmethod
     def _refill(static, batch):
@@ -229,7 +263,7 @@ class GroundingStep:
                     self._refill(self._static_batch, batch)
                 if next_batch is not None and next_batch is not self._static_next:
                     self._refill(self._static_next, next_batch)
-            self._graph.replay()
+            self._replay()
             loss = self._static_loss
         else:
             loss = self._fwd_bwd(batch, next_batch)

@@ -45,12 +45,11 @@ class FusedSAMLP(Function):
         W1p = torch.cat([w1[:, 3:], w1[:, :3], w1.new_zeros(cout[0], K1 - C - 3)], dim=1)
         Wd = [W1p.to(dt).contiguous(), W[1][:, :, 0, 0].to(dt).contiguous(), W[2][:, :, 0, 0].to(dt).contiguous()]
         Ks = [K1, cout[0], cout[1]]
-        stats = torch.zeros((2 * sum(cout),), dtype=torch.float64, device=dev)
-        Y, vecs, off = [], [], 0
+        nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))  # one [sum | sumsq] slab per workgroup, no atomics
+        Y, vecs = [], []
         for l in range(3):
             y = torch.empty((R, cout[l]), dtype=dt, device=dev)
-            st = stats[off:off + 2 * cout[l]]
-            off += 2 * cout[l]
+            st = torch.empty((nslab, 2, cout[l]), dtype=torch.float64, device=dev)
             if l == 0:
                 _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
                           cout[0], y, st, bf)
@@ -65,7 +64,7 @@ class FusedSAMLP(Function):
                 mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             else:
                 mom = 0.0
-            _ext.call("vlp3d_sa_bn_fold", st, gam[l], bet[l], bn.running_mean if (track or not training) else None,
+            _ext.call("vlp3d_sa_bn_fold", st, nslab, gam[l], bet[l], bn.running_mean if (track or not training) else None,
                       bn.running_var if (track or not training) else None, cout[l], R, float(bn.eps), float(mom),
                       int(training), vec)
             Y.append(y)
@@ -88,10 +87,13 @@ class FusedSAMLP(Function):
         need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
         dparams = [None] * 9
 
-        # all BN-backward reductions (2 x C per layer, fp64) live in one zeroed buffer
-        tbuf = torch.zeros((2 * sum(cout),), dtype=torch.float64, device=dev)
-        toff = [0, 2 * cout[0], 2 * cout[0] + 2 * cout[1]]
-        t = [tbuf[toff[l]:toff[l] + 2 * cout[l]] for l in range(3)]
+        # BN-backward reductions: per-workgroup slabs for layers 1-2 (written by the MASK epilogue), one zeroed
+        # (2 x C) buffer for the last layer (pool_tstats adds into it)
+        nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))
+        t = [torch.empty((nslab, 2, cout[0]), dtype=torch.float64, device=dev),
+             torch.empty((nslab, 2, cout[1]), dtype=torch.float64, device=dev),
+             torch.zeros((1, 2, cout[2]), dtype=torch.float64, device=dev)]
+        tn = [nslab, nslab, 1]
 
         # layer 3: the masked gradient lives only at the selected sample of each ball — it is synthesised inside the
         # loaders from (dP, out, sel), and its BN reductions come from the pooled tensors
@@ -104,7 +106,7 @@ class FusedSAMLP(Function):
             c5 = torch.empty((5, cout[l]), dtype=torch.float32, device=dev)
             dg = torch.empty((cout[l],), dtype=torch.float32, device=dev)
             db = torch.empty((cout[l],), dtype=torch.float32, device=dev)
-            _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t[l], cout[l], R, int(training), c5, dg, db)
+            _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t[l], tn[l], cout[l], R, int(training), c5, dg, db)
             dparams[3 * l + 1], dparams[3 * l + 2] = dg, db
             dW = torch.empty((cout[l], Ks[l]), dtype=torch.float32, device=dev)
             part = torch.empty((WGRAD_BLOCKS, cout[l], Ks[l]), dtype=torch.float32, device=dev)

@@ -105,7 +105,7 @@ def report(args, world, elapsed, loss, batch, ext):
     K1 = (C + 4 + (15 if bf else 7)) // (16 if bf else 8) * (16 if bf else 8)
     W = (torch.randn(cout, K1, device=xyz.device) * 0.05).to(dt)
     Y = torch.empty((R, cout), dtype=dt, device=xyz.device)
-    stats = torch.zeros((2 * cout,), dtype=torch.float64, device=xyz.device)
+    stats = torch.empty((int(ext.load().vlp3d_sa_stat_slabs(R)), 2, cout), dtype=torch.float64, device=xyz.device)
     g_ms = time_kernel(lambda: ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1,
                                         cout, Y, stats, int(bf)), reps)
 

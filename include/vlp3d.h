@@ -123,7 +123,10 @@ int vlp3d_group_rows_grad(const void *dout, int dout_bf16, const int *idx, int B
  * statistics fp64.  R = B*M*S must be a multiple of 32; cout in {32,64,128,256}. */
 
 /* layer 1: Y = [feat_pm[idx] | (xyz[idx]-new_xyz)/radius | 0] * W^T; W (cout x K) in column order
- * [features(C) | xyz(3) | 0], K >= C+4, K % 8 (fp32) / 16 (bf16) == 0.  stats (2 x cout) f64 += [sum, sumsq]. */
+ * [features(C) | xyz(3) | 0], K >= C+4, K % 8 (fp32) / 16 (bf16) == 0.
+ * stats: (vlp3d_sa_stat_slabs(R) x 2 x cout) f64 — one [sum | sumsq] slab per workgroup, fully written (no atomics;
+ * vlp3d_sa_bn_fold sums the slabs).  The same convention holds for `tstats` of vlp3d_sa_bwd_layer. */
+int vlp3d_sa_stat_slabs(long long R);
 int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
                         int M, int S, int C, float radius, const void *W, int K, int cout, void *Y, double *stats,
                         int bf16_io, void *stream);
@@ -161,12 +164,12 @@ int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const fl
 /* per-channel bookkeeping of the fused layer (one launch each instead of ~20 framework kernels):
  * bn_fold: vec (4 x C) = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums `stats` (training) or the
  * running statistics (eval); training also updates running_mean/var (may be NULL) like nn.BatchNorm. */
-int vlp3d_sa_bn_fold(const double *stats, const float *gamma, const float *beta, float *running_mean,
+int vlp3d_sa_bn_fold(const double *stats, int nslab, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, int C, long long R, float eps, float momentum, int training, float *vec,
                      void *stream);
 /* bn5 (5 x C) backward constants, dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64. */
-int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int C, long long R, int training,
-                           float *bn5, float *dgamma, float *dbeta, void *stream);
+int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int nslab, int C, long long R,
+                           int training, float *bn5, float *dgamma, float *dbeta, void *stream);
 /* t (2 x C) f64 += [sum g, sum g*yhat] of the LAST layer computed from the pooled tensors (t zeroed by caller);
  * gsel (BM x C) f32 = dP where out > 0 else 0 (the ReLU-masked pooled gradient the last-layer loaders read). */
 int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,

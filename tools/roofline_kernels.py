@@ -27,7 +27,7 @@ for bf in (1, 0):
     K1 = 144 if bf else 136
     W = (torch.randn(cout, K1, device=dev) * 0.05).to(dt)
     Y = torch.empty((R, cout), dtype=dt, device=dev)
-    stats = torch.zeros((2 * cout,), dtype=torch.float64, device=dev)
+    stats = torch.empty((int(ext.load().vlp3d_sa_stat_slabs(R)), 2, cout), dtype=torch.float64, device=dev)
     for _ in range(3):
         ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf)
 q = torch.randn(64, 256, 128, device=dev)
