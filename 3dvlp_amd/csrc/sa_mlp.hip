@@ -327,12 +327,15 @@ template <int COUT, int LOADER, int EPI>
 __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
   typedef bf16 T;
   constexpr int NCT = COUT / 32;
+  constexpr int CC = COUT / 8;  // 16-byte chunks per output row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = a.K, ldw = K + 8, kc = K / 8;  // kc = 16-byte chunks per row
+  const int K = a.K, ldw = K + 8, kc = K / 8;  // kc = 16-byte chunks per input row
+  const int lde = COUT + 8;                    // padded row of the output staging tile
+  const int wtile = 32 * (ldw > lde ? ldw : lde);  // per-wave LDS tile, shared by the A operand and the epilogue
   bf16 *sW = reinterpret_cast<bf16 *>(smem);
-  bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * 32 * ldw;
+  bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * wtile;
   const long long ntiles = a.R / 32;
 
   {  // stage the weight once per workgroup
@@ -382,24 +385,36 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
       }
     }
 
+    // ---- epilogue.  Global traffic goes through the wave's LDS tile in 16-byte row chunks (a lane storing one
+    // bf16 per instruction is store-issue bound); per-column reductions stay in the accumulator layout. ----
     if (EPI == STORE) {
-      T *Y = reinterpret_cast<T *>(a.Yout);
+      constexpr bool STAGED = COUT <= 128;  // wider outputs: the 2-byte LDS writes cost more than they save
+      T *Y = reinterpret_cast<T *>(a.Yout) + (long long)row0 * a.ldout;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float v = acc[ct][i];
-          st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, v);
+          if (STAGED) sA[acc_row(i, half) * lde + 32 * ct + r] = __float2bfloat16(v);
+          else st1(Y + (long long)acc_row(i, half) * a.ldout + 32 * ct + r, v);
           ps += v;
           pq += v * v;
         }
         s1[ct] += (double)ps;
         s2[ct] += (double)pq;
       }
+      if (STAGED)
+        for (int c = lane; c < 32 * CC; c += 64) {
+          const int row = c / CC, ch = c - row * CC;
+          *reinterpret_cast<uint4 *>(Y + (long long)row * a.ldout + ch * 8) = *reinterpret_cast<const uint4 *>(sA + row * lde + ch * 8);
+        }
     } else if (EPI == MASK) {
-      T *G = reinterpret_cast<T *>(a.Yout);
-      const T *Yp = reinterpret_cast<const T *>(a.Yprev);
+      const T *Yp = reinterpret_cast<const T *>(a.Yprev) + (long long)row0 * a.ldprev;
+      for (int c = lane; c < 32 * CC; c += 64) {  // previous layer's pre-activation tile, coalesced
+        const int row = c / CC, ch = c - row * CC;
+        *reinterpret_cast<uint4 *>(sA + row * lde + ch * 8) = *reinterpret_cast<const uint4 *>(Yp + (long long)row * a.ldprev + ch * 8);
+      }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         const int col = 32 * ct + r;
@@ -407,15 +422,20 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
         float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const long long rr = tile * 32 + acc_row(i, half);
-          const float y = ld1(Yp + rr * a.ldprev + col);
+          bf16 *cell = sA + acc_row(i, half) * lde + col;
+          const float y = __bfloat162float(*cell);
           const float g = (y * sc + sh > 0.f) ? acc[ct][i] : 0.f;
-          st1(G + rr * a.ldout + col, g);
+          *cell = __float2bfloat16(g);
           ps += g;
           pq += g * (y * rs + nm);
         }
         s1[ct] += (double)ps;
         s2[ct] += (double)pq;
+      }
+      T *G = reinterpret_cast<T *>(a.Yout) + (long long)row0 * a.ldout;
+      for (int c = lane; c < 32 * CC; c += 64) {
+        const int row = c / CC, ch = c - row * CC;
+        *reinterpret_cast<uint4 *>(G + (long long)row * a.ldout + ch * 8) = *reinterpret_cast<const uint4 *>(sA + row * lde + ch * 8);
       }
     } else {
 #pragma unroll
@@ -761,8 +781,10 @@ int launch_row_gemm_t(int cout, const RowGemmArgs &a, hipStream_t s) {
 
 template <int COUT, int LOADER, int EPI>
 int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
-  const size_t lds = (size_t)(COUT + 4 * 32) * (a.K + 8) * sizeof(bf16);
-  if (lds > 160 * 1024) return VLP3D_EINVAL;
+  const size_t wtile = 32 * (size_t)((a.K > COUT ? a.K : COUT) + 8);  // A operand / epilogue staging, per wave
+  const size_t lds = ((size_t)COUT * (a.K + 8) + 4 * wtile) * sizeof(bf16);
+  const size_t lds_static = (EPI == SCATTER) ? 0 : sizeof(double) * 4 * 2 * COUT;  // block_stats_to_slab
+  if (lds + lds_static > 160 * 1024) return VLP3D_EINVAL;
   auto kern = row_gemm_lds_kernel<COUT, LOADER, EPI>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -790,7 +812,8 @@ template <int LOADER, int EPI>
 int launch_bf16(int cout, const RowGemmArgs &a, hipStream_t s) {
   // the LDS form needs K % 16 == 0 (always true for bf16 storage here); fall back to the direct form otherwise
   const bool lds_shape = cout == 64 || cout == 128 || cout == 160 || cout == 256 || cout == 288;
-  if (lds_shape && a.K % 16 == 0 && (size_t)(cout + 128) * (a.K + 8) * 2 <= 160 * 1024)
+  const size_t need = ((size_t)cout * (a.K + 8) + 128 * (size_t)((a.K > cout ? a.K : cout) + 8)) * 2 + 64 * (size_t)cout;
+  if (lds_shape && a.K % 16 == 0 && need <= 158 * 1024)
     return launch_row_gemm_lds<LOADER, EPI>(cout, a, s);
   return launch_row_gemm_t<bf16, LOADER, EPI>(cout, a, s);
 }
