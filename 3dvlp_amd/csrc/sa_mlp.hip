@@ -56,7 +56,7 @@ __device__ __forceinline__ short bf16_bits(float v) {
 }
 
 enum Loader { GATHER = 0, BNRELU = 1, BNBWD = 2, PLAIN = 3 };
-enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2 };
+enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2, BIAS = 3 };
 
 // Per-column constants, all fp32 vectors of length >= K (loader) / >= COUT (epilogue).
 struct RowGemmArgs {
@@ -262,6 +262,15 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
         }
         s1[ct] += (double)ps;
         s2[ct] += (double)pq;
+      }
+    } else if (EPI == BIAS) {  // plain linear layer: Y = A W^T + bias (bias may be NULL), no statistics
+      T *Y = reinterpret_cast<T *>(a.Yout);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const float bv = a.scale ? a.scale[32 * ct + r] : 0.f;  // `scale` doubles as the bias vector here
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, acc[ct][i] + bv);
       }
     } else {  // SCATTER: columns [0,C) -> d(features), [C,C+3) -> d(xyz), the rest is padding
 #pragma unroll
@@ -517,7 +526,7 @@ struct WgradArgs {
   long long tiles_per_block;
 };
 
-template <typename T, int COUT, int LOADER, int MAXT>  // MAXT = output tiles per wave >= ceil(NCT * KP/32 / 4)
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD>  // MAXT = output tiles per wave
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < NE_DY; ++j) {
       const int e = threadIdx.x + 256 * j;
-      vdy[j] = load_a4<T, BNBWD>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, 0, 0, 0);
+      vdy[j] = load_a4<T, DYL>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
@@ -834,16 +843,16 @@ int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStre
   return VLP3D_EINVAL;
 }
 
-template <typename T, int LOADER, int COUT>
+template <typename T, int LOADER, int COUT, int DYL = BNBWD>
 int launch_wgrad_c(const WgradArgs &w, hipStream_t s, dim3 grid, size_t lds) {
   const int per_wave = ((COUT / 32) * (w.KP / 32) + 3) / 4;
   const dim3 block(256);
   // fewer accumulator registers -> more resident workgroups -> more loads in flight (the kernel is latency bound)
-  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1>), grid, block, lds, s, w);
-  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3>), grid, block, lds, s, w);
-  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4>), grid, block, lds, s, w);
-  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6>), grid, block, lds, s, w);
-  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9>), grid, block, lds, s, w);
+  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1, DYL>), grid, block, lds, s, w);
+  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3, DYL>), grid, block, lds, s, w);
+  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4, DYL>), grid, block, lds, s, w);
+  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6, DYL>), grid, block, lds, s, w);
+  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9, DYL>), grid, block, lds, s, w);
   else return VLP3D_EINVAL;
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
@@ -1040,6 +1049,55 @@ extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const flo
   const dim3 grid((C + 255) / 256, (unsigned)((BM + rpb - 1) / rpb));
   hipLaunchKernelGGL(pool_tstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dP, out, gamma, beta, BM, C, rpb, t,
                      gsel);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+
+// ---- plain linear layers on the same kernels (fp32 storage, exact-fp32 MFMA) -------------------------------------
+// The transformer / head projections of this path are 2048..16384-row x 128..256 GEMMs; the BLAS library runs
+// them at ~5 TFLOP/s (99 us for 16384x128x128).  row_gemm<PLAIN, BIAS> does the same product in ~15 us.
+
+// Y (R x N) = X (R x K) W^T + bias;  W (N x K) row-major, bias (N) or NULL.  R % 32 == 0, K % 8 == 0,
+// N in {32, 64, 128, 160, 256, 288}.
+extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
+                                void *stream) {
+  if (!X || !W || !Y || R < 32 || (R & 31) || K < 8 || (K & 7)) return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.Yin = X; a.ldin = K; a.W = W; a.K = K; a.R = R; a.Yout = Y; a.ldout = N; a.scale = bias;
+  return launch_row_gemm_t<float, PLAIN, BIAS>(N, a, (hipStream_t)stream);
+}
+
+// dW (N x K) = dY^T X   (dY (R x N), X (R x K));  partials: max_blocks * N * K floats of scratch.
+extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
+                                  int max_blocks, void *stream) {
+  if (!dY || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
+      (N & 31))
+    return VLP3D_EINVAL;
+  WgradArgs w = {};
+  w.src.K = K; w.src.R = R; w.src.Yin = X; w.src.ldin = K;
+  w.dy.Yin = dY; w.dy.ldin = N;
+  w.KP = (K + 31) & ~31;
+  w.partials = partials;
+  const long long ntiles = R / 32;
+  long long tpb = (ntiles + max_blocks - 1) / max_blocks;
+  if (tpb < 1) tpb = 1;
+  w.tiles_per_block = tpb;
+  const int nblk = (int)((ntiles + tpb - 1) / tpb);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)nblk);
+  const size_t lds = (size_t)32 * (N + w.KP) * sizeof(float);
+  if (lds > 64 * 1024) return VLP3D_EINVAL;
+  int st;
+  switch (N) {
+    case 64: st = launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds); break;
+    case 128: st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, grid, lds); break;
+    case 256: st = launch_wgrad_c<float, PLAIN, 256, PLAIN>(w, s, grid, lds); break;
+    default: return VLP3D_EINVAL;
+  }
+  if (st != VLP3D_OK) return st;
+  const int n = N * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

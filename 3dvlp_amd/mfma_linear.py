@@ -1,0 +1,64 @@
+"""nn.Linear on the hand-written MFMA kernels (csrc/sa_mlp.hip: row_gemm<PLAIN,BIAS>, wgrad<PLAIN>).
+
+The projections / FFNs / heads of the grounding path are 2 048..16 384-row by 128..256 GEMMs that the BLAS
+library runs at ~5 TFLOP/s; here they use the same exact-fp32 MFMA kernels as the grouped MLP.  `linear(x, w, b)`
+has F.linear semantics; shapes the kernels do not cover (rows not a multiple of 32, tiny widths) go to F.linear.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib as _ext
+
+_ext.load()
+
+WGRAD_BLOCKS = 256
+_FWD_N = (32, 64, 128, 160, 256, 288)
+_WGRAD_N = (64, 128, 256)
+
+
+def supported(x, weight):
+    R = x.numel() // x.shape[-1]
+    N, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
+            and K % 8 == 0 and N in _WGRAD_N and K in _FWD_N and 32 * (N + ((K + 31) // 32) * 32) * 4 <= 65536)
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        R, K = x2.shape
+        N = weight.shape[0]
+        w = weight.contiguous()
+        y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_linear_fwd", x2, w, bias, R, K, N, y)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        R, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(R, N).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, K), dtype=torch.float32, device=dy.device)
+            _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            part = torch.empty((WGRAD_BLOCKS, N, K), dtype=torch.float32, device=dy.device)
+            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dw, part, WGRAD_BLOCKS)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    if supported(x, weight) and not torch.is_autocast_enabled("cuda"):
+        return _Linear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

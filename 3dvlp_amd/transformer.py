@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from . import fused_attention
+from .mfma_linear import linear as _linear
 
 DEFAULT_IMPL = "hip"
 
@@ -38,9 +39,9 @@ class ScaledDotProductAttention(nn.Module):
         Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran)."""
         b_s, nq = queries.shape[:2]
         nk = keys.shape[1]
-        q = self.fc_q(queries)
-        k = self.fc_k(keys)
-        v = self.fc_v(values)
+        q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
+        k = _linear(keys, self.fc_k.weight, self.fc_k.bias)
+        v = _linear(values, self.fc_v.weight, self.fc_v.bias)
         if way not in ("add", "mul"):
             raise NotImplementedError(way)
         impl = self.impl or DEFAULT_IMPL
@@ -48,7 +49,7 @@ class ScaledDotProductAttention(nn.Module):
             out = fused_attention.sdpa(q.float(), k.float(), v.float(), self.h,
                                        None if attention_weights is None else attention_weights.float(), way,
                                        attention_mask)
-            return self.fc_o(out), None
+            return _linear(out, self.fc_o.weight, self.fc_o.bias), None
         if impl == "hip" and not q.is_cuda:
             raise RuntimeError("CPU not supported (impl='hip'); pass impl='torch' explicitly for host-side tests")
         q = q.view(b_s, nq, self.h, self.d_k).permute(0, 2, 1, 3)
@@ -61,7 +62,7 @@ class ScaledDotProductAttention(nn.Module):
             att = att.masked_fill(attention_mask == 0, -10000)
         att = torch.softmax(att, -1)
         out = torch.matmul(att, v).permute(0, 2, 1, 3).contiguous().view(b_s, nq, self.h * self.d_v)
-        return self.fc_o(out), att
+        return _linear(out, self.fc_o.weight, self.fc_o.bias), att
 
 
 class MultiHeadAttention(nn.Module):
@@ -98,7 +99,8 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(p=drop_prob)
 
     def forward(self, x):
-        return self.linear2(self.dropout(self.relu(self.linear1(x))))
+        h = self.relu(_linear(x, self.linear1.weight, self.linear1.bias))
+        return _linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
 
 
 class CrossAttentionDecoderLayer(nn.Module):

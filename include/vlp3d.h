@@ -175,6 +175,16 @@ int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t
 int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,
                          double *t, float *gsel, void *stream);
 
+/* ---- plain linear layers on the grouped-MLP kernels (fp32, exact-fp32 MFMA) -----------------------------------
+ * replace nn.Linear forward / weight-gradient of the attention projections, FFNs and heads on this path
+ * (models/transformer/attention.py:22-25, mmattention.py:40-41, match_module.py:30-40): Y = X W^T + bias.
+ * R % 32 == 0, K % 8 == 0, N in {32,64,128,160,256,288} (fwd) / {64,128,256} (wgrad).  The input gradient
+ * dX = dY W is vlp3d_linear_fwd(dY, W^T, NULL, ...). */
+int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
+                     void *stream);
+int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
+                       int max_blocks, void *stream);
+
 /* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
  * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
  * with MLP = Linear(4,32) ReLU LayerNorm(32) Linear(32,32) ReLU LayerNorm(32) Linear(32,4) (:26-37).

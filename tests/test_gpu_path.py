@@ -289,3 +289,21 @@ def test_geometry_pipeline_and_graph_equal_inline_step():
     for name in ("pipeline", "graph"):
         np.testing.assert_allclose(losses[name], losses["inline"], rtol=2e-3, err_msg=name)
     assert losses["inline"][2] < losses["inline"][0]
+
+
+@pytest.mark.parametrize("R,K,N", [(16384, 128, 128), (3136, 128, 128), (2048, 128, 256), (2048, 256, 128), (64, 64, 64)])
+def test_mfma_linear_equals_f_linear(R, K, N):
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    torch.manual_seed(R + K)
+    x = torch.randn(R // 32, 32, K, device="cuda", requires_grad=True)
+    w = (torch.randn(N, K, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(N, device="cuda", requires_grad=True)
+    assert ml.supported(x, w)
+    y = ml.linear(x, w, b)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, [x, w, b], g)
+    exp = torch.autograd.grad(ref, [x, w, b], g.double())
+    for a, e in zip(got, exp):
+        assert (a.double() - e.double()).abs().max().item() < 1e-4 * e.abs().max().item() + 1e-5
