@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
 
@@ -336,7 +337,7 @@ class RelationModule(nn.Module):
                 dist_weights = relation_bias(centre, self.self_attn_fc[i])  # (B,4,K,K) additive bias
             else:
                 dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)
-            features = features + self.obj_embedding[i](obj_feat) * 0.1
+            features = features + _linear(obj_feat, self.obj_embedding[i].weight, self.obj_embedding[i].bias) * 0.1
             features = features + self.bbox_embedding[i](manual_bbox_feat)
             features = self.self_attn[i](features, features, features, attention_weights=dist_weights, way="add")
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .mfma_linear import linear as _linear
 from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
 
 
@@ -86,7 +87,10 @@ class MatchModule(nn.Module):
         data_dict["cross_box_feature"] = feature1
 
         feature1_agg = feature1.reshape(B * L * K, -1)
-        confidence = self.match(feature1_agg).squeeze(1).view(B * L, K)
+        x = feature1_agg
+        for layer in self.match:  # nn.Sequential of Linear / GELU / Dropout: the Linears run on the MFMA kernels
+            x = _linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+        confidence = x.squeeze(1).view(B * L, K)
 
         if self.use_lang_emb:
             lang_emb = data_dict["lang_emb"]

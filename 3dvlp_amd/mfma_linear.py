@@ -12,6 +12,7 @@ from . import _lib as _ext
 
 _ext.load()
 
+_ROWS_PER_BLOCK = int(__import__('os').environ.get('VLP3D_LIN_RPB', 64))
 WGRAD_BLOCKS = 256
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256)
@@ -51,8 +52,9 @@ class _Linear(Function):
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            part = torch.empty((WGRAD_BLOCKS, N, K), dtype=torch.float32, device=dy.device)
-            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dw, part, WGRAD_BLOCKS)
+            nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
+            part = torch.empty((nblk, N, K), dtype=torch.float32, device=dy.device)
+            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dw, part, nblk)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
         return dx, dw, db

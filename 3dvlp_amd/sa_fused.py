@@ -13,7 +13,7 @@ from . import _lib as _ext
 
 _ext.load()
 
-WGRAD_BLOCKS = 512  # workgroups (= partial dW slabs) of the weight-gradient kernel: two per CU
+WGRAD_BLOCKS = int(__import__('os').environ.get('VLP3D_WGRAD_BLOCKS', 512))  # workgroups (= partial dW slabs) of the weight-gradient kernel
 
 
 def _round_up(x, m):
