@@ -91,6 +91,7 @@ struct RowGemmArgs {
   const float *pool_g;   // (BM x ldin): dP where out > 0, else 0 (written by pool_tstats)
   const unsigned char *pool_sel;
   int pool_S, pool_shift;  // pool_shift = log2(pool_S) when it is a power of two, else -1
+  int S_shift;             // GATHER in wgrad: log2(S) when S is a power of two, else -1
 };
 
 template <typename T, int LOADER>
@@ -322,6 +323,15 @@ __device__ __forceinline__ void tile_chunk_load(const RowGemmArgs &a, int row, i
   v1 = load_a4<bf16, LOADER>(a, row, col0 + 4, gb, xb, cb);
 }
 
+__device__ __forceinline__ uint2 pack4(const float4 &a) {
+  union {
+    short h[4];
+    uint2 u;
+  } p;
+  p.h[0] = bf16_bits(a.x); p.h[1] = bf16_bits(a.y); p.h[2] = bf16_bits(a.z); p.h[3] = bf16_bits(a.w);
+  return p.u;
+}
+
 __device__ __forceinline__ uint4 pack8(const float4 &a0, const float4 &a1) {
   union {
     short h[8];
@@ -533,8 +543,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KP = w.KP, K = w.src.K, NKT = KP / 32, NT = NCT * NKT;
-  float *lds_dy = lds;               // [32][COUT]
-  float *lds_a = lds + 32 * COUT;    // [32][KP]
+  constexpr bool BF = sizeof(T) == 2;  // bf16 storage: both tiles are staged as bf16 and contracted with the bf16 MFMA
+  float *lds_dy = lds;               // fp32: [32][COUT]
+  float *lds_a = lds + 32 * COUT;    // fp32: [32][KP]
+  // bf16: [32][COUT + 4] and [32][KP + 4] shorts — row strides of 8 (mod 16) bytes put the two lane halves (rows +8)
+  // on opposite bank halves for the column reads of the MFMA operands
+  const int RSD = COUT + 4, RSA = KP + 4;
+  short *ldb_dy = reinterpret_cast<short *>(lds);
+  short *ldb_a = ldb_dy + 32 * RSD;
 
   f32x16 acc[MAXT];
   int off_c[MAXT], off_k[MAXT];  // this wave's output tiles: t = wave + 4i -> (ct, kt), hoisted out of the hot loop
@@ -562,17 +578,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[NE_DY], va[MAXE_A], vt;
 
-  auto fetch = [&](long long tile) {
+  // The gathered operand needs idx[row] before its feature row can be requested: two dependent memory latencies per
+  // tile.  The indices therefore run ONE TILE FURTHER AHEAD than the data (pidx/tp hold the next tile's indices).
+  int pidx[MAXE_A], tp = 0;
+  auto fetch_idx = [&](long long tile) {
+    if (LOADER != GATHER) return;
     const int row0 = (int)(tile * 32);
-    int pidx[MAXE_A];
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
-      pidx[j] = (LOADER == GATHER) ? w.src.idx[row0 + e / kf4] : 0;
+      pidx[j] = w.src.idx[row0 + e / kf4];
     }
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
+    tp = w.src.idx[row0 + te / max(tc, 1)];
+  };
+  // M*S is a multiple of 32 (checked by the host), so a tile never straddles two scenes: the scene index is a
+  // scalar that follows the (monotone) tile counter instead of two integer divisions per staged element.
+  const long long tiles_per_scene = (LOADER == GATHER) ? ((long long)w.src.M * w.src.S) / 32 : 1;
+  int scene = (LOADER == GATHER) ? (int)(t0 / tiles_per_scene) : 0;
+  long long scene_end = (long long)(scene + 1) * tiles_per_scene;
+  auto fetch = [&](long long tile) {
+    const int row0 = (int)(tile * 32);
+    const int te = min((int)threadIdx.x, max(net, 1) - 1);
     const int trow = row0 + te / max(tc, 1);
-    const int tp = (LOADER == GATHER) ? w.src.idx[trow] : 0;
+    if (LOADER == GATHER) {
+      if (tile >= scene_end) {  // tiles advance by one and tiles_per_scene >= 1
+        ++scene;
+        scene_end += tiles_per_scene;
+      }
+    }
+    const long long pbase = (long long)scene * w.src.N;
 #pragma unroll
     for (int j = 0; j < NE_DY; ++j) {
       const int e = threadIdx.x + 256 * j;
@@ -584,16 +619,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       const int row = e / kf4, k0 = (e - row * kf4) * 4;
       const int rr = row0 + row;
       if (LOADER == GATHER) {
-        const int b = (rr / w.src.S) / w.src.M;
-        va[j] = ld4(w.src.feat_pm + ((long long)b * w.src.N + pidx[j]) * w.src.C + k0);
+        va[j] = ld4(w.src.feat_pm + (pbase + pidx[j]) * w.src.C + k0);
       } else {
         va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
     }
     vt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOADER == GATHER) {
-      const int bm = trow / w.src.S, b = bm / w.src.M;
-      const float *q = w.src.xyz + ((long long)b * w.src.N + tp) * 3;
+      const int bm = w.src.S_shift >= 0 ? (trow >> w.src.S_shift) : trow / w.src.S;
+      const float *q = w.src.xyz + (pbase + tp) * 3;
       const float *c = w.src.new_xyz + (long long)bm * 3;
       const float x = (q[0] - c[0]) / w.src.radius, y = (q[1] - c[1]) / w.src.radius, z = (q[2] - c[2]) / w.src.radius;
       const bool first = (te % max(tc, 1)) == 0;  // chunk 0 of the tail is [dx, dy, dz, 0]
@@ -601,33 +635,78 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
     }
   };
 
-  if (t0 < t1) fetch(t0);
+  if (t0 < t1) {
+    fetch_idx(t0);
+    fetch(t0);
+    fetch_idx(min(t0 + 1, t1 - 1));
+  }
   for (long long tile = t0; tile < t1; ++tile) {
     __syncthreads();  // the previous tile's MFMA reads are done
+    if (BF) {
 #pragma unroll
-    for (int j = 0; j < NE_DY; ++j) *reinterpret_cast<float4 *>(lds_dy + 4 * (threadIdx.x + 256 * j)) = vdy[j];
+      for (int j = 0; j < NE_DY; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        *reinterpret_cast<uint2 *>(ldb_dy + (e / (COUT / 4)) * RSD + (e % (COUT / 4)) * 4) = pack4(vdy[j]);
+      }
 #pragma unroll
-    for (int j = 0; j < MAXE_A; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      if (e < nef) {
-        const int row = e / kf4;
-        *reinterpret_cast<float4 *>(lds_a + row * KP + (e - row * kf4) * 4) = va[j];
+      for (int j = 0; j < MAXE_A; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        if (e < nef) {
+          const int row = e / kf4;
+          *reinterpret_cast<uint2 *>(ldb_a + row * RSA + (e - row * kf4) * 4) = pack4(va[j]);
+        }
+      }
+      if ((int)threadIdx.x < net) {
+        const int row = threadIdx.x / tc;
+        *reinterpret_cast<uint2 *>(ldb_a + row * RSA + KF + (threadIdx.x - row * tc) * 4) = pack4(vt);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE_DY; ++j) *reinterpret_cast<float4 *>(lds_dy + 4 * (threadIdx.x + 256 * j)) = vdy[j];
+#pragma unroll
+      for (int j = 0; j < MAXE_A; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        if (e < nef) {
+          const int row = e / kf4;
+          *reinterpret_cast<float4 *>(lds_a + row * KP + (e - row * kf4) * 4) = va[j];
+        }
+      }
+      if ((int)threadIdx.x < net) {
+        const int row = threadIdx.x / tc;
+        *reinterpret_cast<float4 *>(lds_a + row * KP + KF + (threadIdx.x - row * tc) * 4) = vt;
       }
     }
-    if ((int)threadIdx.x < net) {
-      const int row = threadIdx.x / tc;
-      *reinterpret_cast<float4 *>(lds_a + row * KP + KF + (threadIdx.x - row * tc) * 4) = vt;
-    }
     __syncthreads();
-    if (tile + 1 < t1) fetch(tile + 1);
+    if (tile + 1 < t1) {
+      fetch(tile + 1);
+      fetch_idx(min(tile + 2, t1 - 1));
+    }
+    if (BF) {
+      // contraction over the 32 rows in two 16-row steps; lane (col, half) gathers its column's 8 rows
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const short *pa = ldb_dy + (16 * kb + 8 * half) * RSD + r;
+        const short *pb = ldb_a + (16 * kb + 8 * half) * RSA + r;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          bf16x8 av, bv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            av[j] = pa[j * RSD + off_c[i]];
+            bv[j] = pb[j * RSA + off_k[i]];
+          }
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll 4
     for (int kk = 0; kk < 16; ++kk) {
       const float *pa = lds_dy + (2 * kk + half) * COUT + r;
       const float *pb = lds_a + (2 * kk + half) * KP + r;
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i)
-        if (tile_ok[i])  // wave-uniform
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[off_c[i]], pb[off_k[i]], acc[i], 0, 0, 0);
+      for (int i = 0; i < MAXT; ++i)  // a wave with fewer than MAXT tiles recomputes tile (0,0) into an unused accumulator:
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[off_c[i]], pb[off_k[i]], acc[i], 0, 0, 0);  // no branches
     }
   }
   // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
@@ -863,7 +942,7 @@ int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
   const long long ntiles = w.src.R / 32;
   const long long nblk = (ntiles + w.tiles_per_block - 1) / w.tiles_per_block;
   const dim3 grid((unsigned)nblk);
-  const size_t lds = (size_t)32 * (cout + w.KP) * sizeof(float);
+  const size_t lds = sizeof(T) == 2 ? (size_t)32 * (cout + w.KP + 8) * 2 : (size_t)32 * (cout + w.KP) * sizeof(float);
   if (lds > 64 * 1024) return VLP3D_EINVAL;
   switch (cout) {
     case 64: return launch_wgrad_c<T, LOADER, 64>(w, s, grid, lds);
@@ -984,9 +1063,10 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
   WgradArgs w = {};
   w.src.K = K; w.src.R = R;
   if (gather) {
-    if (!xyz || !new_xyz || !idx || !feat_pm) return VLP3D_EINVAL;
+    if (!xyz || !new_xyz || !idx || !feat_pm || M < 1 || S < 1 || (((long long)M * S) & 31)) return VLP3D_EINVAL;
     w.src.xyz = xyz; w.src.new_xyz = new_xyz; w.src.idx = idx; w.src.feat_pm = feat_pm;
     w.src.N = N; w.src.M = M; w.src.S = S; w.src.C = C; w.src.radius = radius;
+    w.src.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   } else {
     if (!Yprev || !scale || !shift) return VLP3D_EINVAL;
     w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;

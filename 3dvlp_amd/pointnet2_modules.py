@@ -80,7 +80,7 @@ class PointnetSAModuleVotes(nn.Module):
         dtype = self.mlp_dtype or (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
                                    else torch.float32)
         mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
-        if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S):
+        if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S, M):
             pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm.float(), self.radius if self.normalize_xyz else 1.0,
                                           self.mlp_module, dtype == torch.bfloat16)
             return new_xyz, pooled.transpose(1, 2), inds

@@ -20,9 +20,10 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def supported(C, mlp_out, S, R):
+def supported(C, mlp_out, S, R, M=None):
+    """Shapes the fused kernels cover; M*S % 32 == 0 keeps every 32-row tile inside one scene."""
     return C % 4 == 0 and all(c in (64, 128, 256) for c in mlp_out) and len(mlp_out) == 3 and S <= 255 and \
-        R % 32 == 0 and R < 2 ** 31
+        R % 32 == 0 and R < 2 ** 31 and (M is None or (M * S) % 32 == 0)
 
 
 class FusedSAMLP(Function):

@@ -1,7 +1,7 @@
 """Steady-state step of a graph-mode bench trace: main-path vs side-stream (geometry) kernels, idle gaps."""
 import csv, glob, sys
 from collections import defaultdict
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv") + glob.glob(sys.argv[1] + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 mark = "fps_pruned_kernel" if any("fps_pruned_kernel" in r["Kernel_Name"] for r in rows) else "fps_kernel<1024"
