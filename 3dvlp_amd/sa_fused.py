@@ -6,6 +6,8 @@ backward: BatchNorm / ReLU / max-pool backward folded into the loaders and epilo
 Same math as pointnet2_modules.py:233-267 of the reference (training-mode BatchNorm2d statistics over
 B*npoint*nsample rows == batch_norm over the rows of a (rows, C) matrix).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -13,7 +15,15 @@ from . import _lib as _ext
 
 _ext.load()
 
-WGRAD_BLOCKS = int(__import__('os').environ.get('VLP3D_WGRAD_BLOCKS', 512))  # workgroups (= partial dW slabs) of the weight-gradient kernel
+WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 1024))  # most workgroups (= partial dW slabs) of the weight-gradient kernel
+WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
+
+
+def _wgrad_blocks(R, cout, K):
+    """Workgroups of the weight-gradient kernel: enough resident waves to cover the memory latency of the
+    staging loads (light tiles: several workgroups per CU), few enough that the slab sum stays small."""
+    ntiles = R // 32
+    return max(64, min(WGRAD_BLOCKS, ntiles // WGRAD_TILES))
 
 
 def _round_up(x, m):
@@ -110,10 +120,11 @@ class FusedSAMLP(Function):
             _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t[l], tn[l], cout[l], R, int(training), c5, dg, db)
             dparams[3 * l + 1], dparams[3 * l + 2] = dg, db
             dW = torch.empty((cout[l], Ks[l]), dtype=torch.float32, device=dev)
-            part = torch.empty((WGRAD_BLOCKS, cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            nblk = _wgrad_blocks(R, cout[l], Ks[l])
+            part = torch.empty((nblk, cout[l], Ks[l]), dtype=torch.float32, device=dev)
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
-                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, WGRAD_BLOCKS,
+                          vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
                           *(pool if G is None else (None, None, 0)), bf)
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 WT = Wd[l].t().contiguous()
@@ -123,7 +134,7 @@ class FusedSAMLP(Function):
                 G = Gp
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, part, WGRAD_BLOCKS, None, None, 0, bf)
+                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf)
                 dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
                     kpad = _round_up(C + 3, 32)
