@@ -342,6 +342,88 @@ __device__ __forceinline__ uint4 pack8(const float4 &a0, const float4 &a1) {
   return p.u;
 }
 
+
+// ---- 8-column chunk loaders with the per-column constants HOISTED (row_gemm_lds: a lane always works on the same
+// 8 columns, chunk = lane % (K/8) with K/8 dividing 64).  Re-loading the 2 (BN+ReLU) or 5 (BN-backward) constant
+// vectors for every chunk was 5/7 of the kernel's load instructions and, four chunks in flight, 160 VGPRs.
+//   BNRELU: a  = max(0, y*ca + cb)                  ca = scale, cb = shift
+//   BNBWD:  dy = k1*(g - k2 - (y*rstd + nmr)*k3)  = ca*g + (cb*y + cc),  ca = k1, cb = -k1*k3*rstd, cc = -k1*(k2 + k3*nmr)
+struct Raw8 {
+  uint4 y, g;
+  float4 dp0, dp1;
+  uint2 sel;
+};
+
+__device__ __forceinline__ void unpack8(const uint4 &u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+template <int LOADER>
+__device__ __forceinline__ void hoist_consts(const RowGemmArgs &a, int col0, float (&ca)[8], float (&cb)[8], float (&cc)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (LOADER == BNRELU) {
+      ca[i] = a.scale[col0 + i];
+      cb[i] = a.shift[col0 + i];
+      cc[i] = 0.f;
+    } else if (LOADER == BNBWD) {
+      const float k1 = a.k1[col0 + i], k2 = a.k2[col0 + i], k3 = a.k3[col0 + i];
+      ca[i] = k1;
+      cb[i] = -(k1 * k3) * a.rstd[col0 + i];
+      cc[i] = -k1 * (k2 + k3 * a.nmean_rstd[col0 + i]);
+    } else {
+      ca[i] = cb[i] = cc[i] = 0.f;
+    }
+  }
+}
+
+template <int LOADER>
+__device__ __forceinline__ void raw_load8(const RowGemmArgs &a, int row, int col0, Raw8 &w) {
+  w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
+  if (LOADER == BNBWD) {
+    if (a.pool_g != nullptr) {  // kernel-uniform
+      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+      const long long off = (long long)bm * a.ldin + col0;
+      w.dp0 = ld4(a.pool_g + off);
+      w.dp1 = ld4(a.pool_g + off + 4);
+      w.sel = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
+    } else {
+      w.g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0);
+    }
+  }
+}
+
+template <int LOADER>
+__device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Raw8 &w, const float (&ca)[8],
+                                         const float (&cb)[8], const float (&cc)[8]) {
+  float y[8], o[8];
+  unpack8(w.y, y);
+  if (LOADER == BNRELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(0.f, __builtin_fmaf(y[i], ca[i], cb[i]));
+  } else {
+    float g[8];
+    if (a.pool_g != nullptr) {
+      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+      const unsigned sidx = (unsigned)(row - bm * a.pool_S);
+      const float dp[8] = {w.dp0.x, w.dp0.y, w.dp0.z, w.dp0.w, w.dp1.x, w.dp1.y, w.dp1.z, w.dp1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned sb = ((i < 4 ? w.sel.x : w.sel.y) >> (8 * (i & 3))) & 0xffu;
+        g[i] = sb == sidx ? dp[i] : 0.f;
+      }
+    } else {
+      unpack8(w.g, g);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], __builtin_fmaf(cb[i], y[i], cc[i]));
+  }
+  return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
+}
+
 template <int COUT, int LOADER, int EPI>
 __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
   typedef bf16 T;
@@ -371,9 +453,31 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
   for (int ct = 0; ct < NCT; ++ct) s1[ct] = s2[ct] = 0.0;
 
   const int nch = 32 * kc;  // chunks of this wave's tile; 64 lanes take them 64 at a time, 4 batches in flight
+  // kc divides 64 (host-checked): fixed columns per lane.  Wide outputs keep the accumulators' registers instead.
+  constexpr bool HOIST = (LOADER == BNRELU || LOADER == BNBWD) && !(LOADER == BNRELU && COUT >= 256);
+  float ca[8], cb[8], cc[8];
+  hoist_consts<HOIST ? LOADER : GATHER>(a, (lane % kc) * 8, ca, cb, cc);
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
     const int row0 = (int)(tile * 32);
     for (int c0 = 0; c0 < nch; c0 += 256) {
+      if (HOIST) {
+        Raw8 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
+          const int c = min(c0 + 64 * u + lane, nch - 1);
+          const int row = c / kc, ch = c - row * kc;
+          raw_load8<LOADER>(a, row0 + row, ch * 8, raw[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 64 * u + lane;
+          if (c < nch) {
+            const int row = c / kc, ch = c - row * kc;
+            *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish8<LOADER>(a, row0 + row, raw[u], ca, cb, cc);
+          }
+        }
+        continue;
+      }
       float4 v0[4], v1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
@@ -915,7 +1019,8 @@ int launch_bf16(int cout, const RowGemmArgs &a, hipStream_t s) {
   // the LDS form needs K % 16 == 0 (always true for bf16 storage here); fall back to the direct form otherwise
   const bool lds_shape = cout == 64 || cout == 128 || cout == 160 || cout == 256 || cout == 288;
   const size_t need = ((size_t)cout * (a.K + 8) + 128 * (size_t)((a.K > cout ? a.K : cout) + 8)) * 2 + 64 * (size_t)cout;
-  if (lds_shape && a.K % 16 == 0 && need <= 158 * 1024)
+  const bool cols_fixed = LOADER == GATHER || (a.K % 8 == 0 && 64 % (a.K / 8) == 0);  // hoisted per-lane constants
+  if (lds_shape && a.K % 16 == 0 && cols_fixed && need <= 158 * 1024)
     return launch_row_gemm_lds<LOADER, EPI>(cout, a, s);
   return launch_row_gemm_t<bf16, LOADER, EPI>(cout, a, s);
 }
