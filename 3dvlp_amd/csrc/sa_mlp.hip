@@ -632,6 +632,51 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(const float *__restrict_
 // lane (k = 32kt + r) reads A[2kk+half][k] — both conflict-free 128-byte LDS rows.  One workgroup covers the
 // WHOLE dW for its rows, so dY and A are read once.
 // ------------------------------------------------------------------------------------------------
+// Staging loaders of wgrad with the per-column constants hoisted: a thread always stages the same 4 columns of dY
+// (256 % (COUT/4) == 0) and of a BN+ReLU A operand (256 % (K/4) == 0, host-checked).
+template <typename T>
+struct DyConsts {  // fp32: the five vectors, reference evaluation order; bf16: the folded form ca*g + (cb*y + cc)
+  float4 k1, k2, k3, rs, nm;
+  __device__ __forceinline__ void load(const RowGemmArgs &a, int col0) {
+    k1 = ld4(a.k1 + col0); k2 = ld4(a.k2 + col0); k3 = ld4(a.k3 + col0);
+    rs = ld4(a.rstd + col0); nm = ld4(a.nmean_rstd + col0);
+    if (sizeof(T) == 2) {
+      const float4 ca = k1;
+      const float4 cb = make_float4(-(k1.x * k3.x) * rs.x, -(k1.y * k3.y) * rs.y, -(k1.z * k3.z) * rs.z, -(k1.w * k3.w) * rs.w);
+      const float4 cc = make_float4(-k1.x * (k2.x + k3.x * nm.x), -k1.y * (k2.y + k3.y * nm.y), -k1.z * (k2.z + k3.z * nm.z),
+                                    -k1.w * (k2.w + k3.w * nm.w));
+      k1 = ca; k2 = cb; k3 = cc;
+    }
+  }
+  __device__ __forceinline__ float one(float g, float y, float a, float b, float c, float r, float n) const {
+    if (sizeof(T) == 2) return __builtin_fmaf(a, g, __builtin_fmaf(b, y, c));
+    return a * (g - b - (y * r + n) * c);
+  }
+  __device__ __forceinline__ float4 apply(const float4 &g, const float4 &y) const {
+    return make_float4(one(g.x, y.x, k1.x, k2.x, k3.x, rs.x, nm.x), one(g.y, y.y, k1.y, k2.y, k3.y, rs.y, nm.y),
+                       one(g.z, y.z, k1.z, k2.z, k3.z, rs.z, nm.z), one(g.w, y.w, k1.w, k2.w, k3.w, rs.w, nm.w));
+  }
+};
+
+template <typename T, int DYL>
+__device__ __forceinline__ float4 load_dy4(const RowGemmArgs &a, int row, int col0, const DyConsts<T> &k) {
+  const float4 y = ld4(reinterpret_cast<const T *>(a.Yin) + (long long)row * a.ldin + col0);
+  if (DYL == PLAIN) return y;
+  float4 g;
+  if (a.pool_g != nullptr) {  // kernel-uniform
+    const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+    const int sidx = row - bm * a.pool_S;
+    const long long off = (long long)bm * a.ldin + col0;
+    const float4 dp = ld4(a.pool_g + off);
+    const uchar4 sl = *reinterpret_cast<const uchar4 *>(a.pool_sel + off);
+    g = make_float4(sl.x == sidx ? dp.x : 0.f, sl.y == sidx ? dp.y : 0.f, sl.z == sidx ? dp.z : 0.f,
+                    sl.w == sidx ? dp.w : 0.f);
+  } else {
+    g = ld4(reinterpret_cast<const T *>(a.Gin) + (long long)row * a.ldin + col0);
+  }
+  return k.apply(g, y);
+}
+
 struct WgradArgs {
   RowGemmArgs dy;   // BNBWD loader of this layer's dY (Gin, Yin, ldin = COUT, constants)
   RowGemmArgs src;  // loader of A_{l-1} (GATHER or BNRELU), K = src.K valid columns
@@ -682,6 +727,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[NE_DY], va[MAXE_A], vt;
 
+  DyConsts<T> dyk;
+  if (DYL == BNBWD) dyk.load(w.dy, (threadIdx.x % (COUT / 4)) * 4);
+  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;
+  if (LOADER == BNRELU) {
+    const int k0 = (threadIdx.x % kf4) * 4;
+    a_sc = ld4(w.src.scale + k0);
+    a_sh = ld4(w.src.shift + k0);
+  }
   // The gathered operand needs idx[row] before its feature row can be requested: two dependent memory latencies per
   // tile.  The indices therefore run ONE TILE FURTHER AHEAD than the data (pidx/tp hold the next tile's indices).
   int pidx[MAXE_A], tp = 0;
@@ -715,7 +768,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < NE_DY; ++j) {
       const int e = threadIdx.x + 256 * j;
-      vdy[j] = load_a4<T, DYL>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, 0, 0, 0);
+      vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, dyk);
     }
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
@@ -724,6 +777,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       const int rr = row0 + row;
       if (LOADER == GATHER) {
         va[j] = ld4(w.src.feat_pm + (pbase + pidx[j]) * w.src.C + k0);
+      } else if (LOADER == BNRELU) {
+        const float4 y = ld4(reinterpret_cast<const T *>(w.src.Yin) + (long long)rr * w.src.ldin + k0);
+        va[j] = make_float4(fmaxf(0.f, y.x * a_sc.x + a_sh.x), fmaxf(0.f, y.y * a_sc.y + a_sh.y),
+                            fmaxf(0.f, y.z * a_sc.z + a_sh.z), fmaxf(0.f, y.w * a_sc.w + a_sh.w));
       } else {
         va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
@@ -1187,7 +1244,7 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
     w.src.N = N; w.src.M = M; w.src.S = S; w.src.C = C; w.src.radius = radius;
     w.src.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   } else {
-    if (!Yprev || !scale || !shift) return VLP3D_EINVAL;
+    if (!Yprev || !scale || !shift || (256 % (K / 4))) return VLP3D_EINVAL;  // fixed staging columns per thread
     w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;
   }
   w.dy.Gin = G; w.dy.Yin = Y; w.dy.ldin = cout;
