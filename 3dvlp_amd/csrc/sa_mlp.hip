@@ -207,6 +207,12 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ntiles = a.R / 32;
+  if (EPI == BIAS && gridDim.y > 1) {  // column-split launch of a small linear layer: this block owns COUT columns
+    const int c0 = blockIdx.y * COUT;
+    a.W = reinterpret_cast<const T *>(a.W) + (long long)c0 * a.K;
+    if (a.scale) a.scale += c0;
+    a.Yout = reinterpret_cast<T *>(a.Yout) + c0;
+  }
 
   double s1[NCT], s2[NCT];  // per-lane (column) running reductions of the epilogue
 #pragma unroll
@@ -1321,6 +1327,14 @@ extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bia
   if (!X || !W || !Y || R < 32 || (R & 31) || K < 8 || (K & 7)) return VLP3D_EINVAL;
   RowGemmArgs a = {};
   a.Yin = X; a.ldin = K; a.W = W; a.K = K; a.R = R; a.Yout = Y; a.ldout = N; a.scale = bias;
+  if (R <= 65536 && N % 32 == 0 && N >= 64 && N <= 1024) {
+    // few rows: a wave per 32 x 32 output tile (4x..8x more waves than a wave per 32 x N) — these calls are
+    // latency bound, the re-read of the A rows comes from L2
+    hipLaunchKernelGGL((row_gemm_kernel<float, 32, PLAIN, BIAS>), dim3(grid_tiles(R), N / 32), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  }
   return launch_row_gemm_t<float, PLAIN, BIAS>(N, a, (hipStream_t)stream);
 }
 

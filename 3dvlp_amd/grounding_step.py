@@ -124,6 +124,30 @@ def batch_to_device(batch, device):
     return out
 
 
+class _deferred_bn_counters:
+    """While active, training-mode BatchNorm layers with a fixed momentum skip their own
+    ``num_batches_tracked.add_(1)`` (the buffer is hidden, torch.nn.modules.batchnorm then leaves the counter
+    alone); on exit every hidden counter is restored and all are incremented by ONE fused launch.  Layers with
+    ``momentum=None`` need the counter's value during forward and keep their own increment."""
+
+    def __init__(self, model):
+        self.mods = [m for m in model.modules()
+                     if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats
+                     and m.momentum is not None and m.num_batches_tracked is not None]
+
+    def __enter__(self):
+        self.counters = [m.num_batches_tracked for m in self.mods]
+        for m in self.mods:
+            m._buffers["num_batches_tracked"] = None
+
+    def __exit__(self, *exc):
+        for m, c in zip(self.mods, self.counters):
+            m._buffers["num_batches_tracked"] = c
+        if self.counters and exc[0] is None:
+            torch._foreach_add_(self.counters, 1)
+        return False
+
+
 class GroundingStep:
     """Owns model + optimiser + flat gradient bucket; `run(batch)` = fwd + loss + bwd + all-reduce + AdamW.
 
@@ -163,11 +187,12 @@ class GroundingStep:
         d["epoch"] = self.epoch
         if geometry is not None:
             d["backbone_geometry"] = geometry
-        if self.autocast_dtype is not None:
-            with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+        with _deferred_bn_counters(self.model):  # 26 one-element `add_(1)` launches -> one multi-tensor add
+            if self.autocast_dtype is not None:
+                with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+                    d = self.model(d)
+            else:
                 d = self.model(d)
-        else:
-            d = self.model(d)
         return grounding_loss(d, self.model.mean_size_arr), d
 
     @staticmethod

@@ -92,7 +92,8 @@ class PointnetSAModuleVotes(nn.Module):
             x = F.linear(x, w)
             bn = layer.bn.bn
             if bn.training and bn.track_running_stats:
-                bn.num_batches_tracked.add_(1)
+                if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once
+                    bn.num_batches_tracked.add_(1)
                 factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             else:
                 factor = 0.0

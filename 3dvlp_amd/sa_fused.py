@@ -71,7 +71,8 @@ class FusedSAMLP(Function):
             vec = torch.empty((4, cout[l]), dtype=torch.float32, device=dev)
             track = training and bn.track_running_stats
             if track:
-                bn.num_batches_tracked.add_(1)
+                if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once
+                    bn.num_batches_tracked.add_(1)
                 mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             else:
                 mom = 0.0

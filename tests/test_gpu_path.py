@@ -140,9 +140,14 @@ def test_grounding_step_forward_backward_small():
     # OCC/OSC are active (epoch 50); whether they carry gradient at random init depends on IoU>0.25 hits
     assert torch.isfinite(d["lang_con_loss"]) and torch.isfinite(d["iou_con_loss"])
     l0 = float(loss.detach())
+    counters = {n: int(b) for n, b in step.model.named_buffers() if n.endswith("num_batches_tracked")}
+    assert len(counters) > 20 and set(counters.values()) == {1}  # one forward so far, every BatchNorm counted once
     for _ in range(3):
         l1 = float(step.run(batch).detach())
     assert np.isfinite(l1) and l1 < l0  # three AdamW steps on a fixed batch reduce the loss
+    after = {n: int(b) for n, b in step.model.named_buffers() if n.endswith("num_batches_tracked")}
+    ran = {v - counters[n] for n, v in after.items()}
+    assert len(ran) == 1 and ran.pop() >= 3  # all counters advance together (the fused increment, graph replays included)
 
 
 def test_group_rows_forward_backward_vs_oracle():
