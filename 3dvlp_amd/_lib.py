@@ -51,9 +51,9 @@ SIGNATURES = {
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],
     "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
-    "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                       _vp],
+                       _i, _vp],
 }
 
 _lib = None
@@ -266,7 +266,7 @@ def _opt(t):
     return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def sdpa_fwd(q, k, v, H, bias, bias_mode, mask):
+def sdpa_fwd(q, k, v, H, bias, bias_mode, mask, bf16_mma=False):
     """q (B,nq,H*32), k/v (B,nk,H*32) -> (out (B,nq,H*32), lse (B,H,nq))."""
     for name, t in (("q", q), ("k", k), ("v", v)):
         _chk_float(t, name)
@@ -283,11 +283,11 @@ def sdpa_fwd(q, k, v, H, bias, bias_mode, mask):
     lse = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         _check(load().vlp3d_sdpa_fwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), B, H, nq, nk,
-                                     HD // H, _p(out), _p(lse), _stream()), "sdpa_fwd")
+                                     HD // H, _p(out), _p(lse), int(bool(bf16_mma)), _stream()), "sdpa_fwd")
     return out, lse
 
 
-def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias):
+def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias, bf16_mma=False):
     B, nq, HD = q.shape
     nk = k.shape[1]
     _chk_float(dout, "dout")
@@ -297,7 +297,7 @@ def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias):
     with torch.cuda.device(q.device):
         _check(load().vlp3d_sdpa_bwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), _p(out), _p(lse),
                                      _p(dout), B, H, nq, nk, HD // H, _p(dq), _p(dk), _p(dv), _opt(dbias),
-                                     _p(delta), _stream()), "sdpa_bwd")
+                                     _p(delta), int(bool(bf16_mma)), _stream()), "sdpa_bwd")
     return dq, dk, dv, dbias
 
 

@@ -16,6 +16,8 @@
 //     permutation of the summation index.
 // The summation index of the first product is permuted too (half h of the wave covers head
 // dims 16h..16h+15) so that every lane reads 64 contiguous bytes of its row.
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 namespace {
@@ -47,7 +49,31 @@ __device__ __forceinline__ void load_half_row(const float *__restrict__ base, lo
 
 // C(32x32) += A(32x32) * B(32x32)^T-style product where lane (r = lane&31, half) supplies
 // a[kk] = A[r][16*half+kk] and b[kk] = B[r][16*half+kk]:  C[i][j] = sum_d A[i][d] * B[j][d].
-__device__ __forceinline__ f32x16 mfma_rows(const float (&a)[16], const float (&b)[16], f32x16 c) {
+// BF = false: 16 exact-fp32 MFMA steps (v_mfma_f32_32x32x2_f32).  BF = true: the same contraction as two
+// v_mfma_f32_32x32x16_bf16 — the operands are rounded to bf16 in registers, accumulation stays fp32 (1/16 of the
+// matrix-core time; the timing configuration of the step, not the 1e-4 parity configuration).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ short bf16_bits(float v) {
+  __hip_bfloat16 h = __float2bfloat16(v);
+  return *reinterpret_cast<short *>(&h);
+}
+
+template <bool BF, typename VA, typename VB>
+__device__ __forceinline__ f32x16 mfma_rows(const VA &a, const VB &b, f32x16 c) {
+  if (BF) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 av, bv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        av[j] = bf16_bits(a[8 * t + j]);
+        bv[j] = bf16_bits(b[8 * t + j]);
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    }
+    return c;
+  }
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], c, 0, 0, 0);
   return c;
@@ -64,6 +90,7 @@ __device__ __forceinline__ float apply_bias(float raw, int bias_mode, const floa
 // ---------------------------------------------------------------------------------------------
 // forward: wave = 32 queries of one (b,h); loop over key tiles; online softmax.
 // ---------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ v, const float *__restrict__ bias,
                                                       int bias_mode, const float *__restrict__ mask, int H, int nq,
@@ -85,7 +112,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   for (int k0 = 0; k0 < nk; k0 += 32) {
     float kreg[16];
     load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), HD, h, half, kreg);
-    f32x16 s = mfma_rows(kreg, qreg, zero16());  // s[reg] = S[query r][key k0 + acc_row(reg, half)]
+    f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());  // s[reg] = S[query r][key k0 + acc_row(reg, half)]
 
     float tmax = -__builtin_inff();
 #pragma unroll
@@ -113,12 +140,13 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
     l = l * alpha + psum;
     m = m_new;
     // O^T[dim][query] += V^T[dim][key] * P^T[key][query]; step i sums over key k0 + acc_row(i, half)
+    float vcol[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = min(k0 + acc_row(i, half), nk - 1);  // p == 0 beyond nk
-      const float vv = v[((long long)b * nk + key) * HD + h * D + r];
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[i], o, 0, 0, 0);
+      vcol[i] = v[((long long)b * nk + key) * HD + h * D + r];
     }
+    o = mfma_rows<BF>(vcol, s, o);
   }
   l += __shfl_xor(l, 32);
   if (q0 + r < nq) {
@@ -137,6 +165,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // backward 1: wave = 32 queries; writes dQ, delta = rowsum(dO*O) and (optionally) dbias.
 // ---------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
@@ -168,8 +197,8 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
     const long long krow = (long long)b * nk + min(k0 + r, nk - 1);
     load_half_row(k, krow, HD, h, half, kreg);
     load_half_row(v, krow, HD, h, half, vreg);
-    f32x16 s = mfma_rows(kreg, qreg, zero16());    // S^T  [key][query]
-    f32x16 dp = mfma_rows(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
+    f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());    // S^T  [key][query]
+    f32x16 dp = mfma_rows<BF>(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = k0 + acc_row(i, half);
@@ -187,12 +216,13 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
       s[i] = ds;
     }
     // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query]
+    float kcol[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = min(k0 + acc_row(i, half), nk - 1);
-      const float kk = k[((long long)b * nk + key) * HD + h * D + r];
-      dqa = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, s[i], dqa, 0, 0, 0);
+      kcol[i] = k[((long long)b * nk + key) * HD + h * D + r];
     }
+    dqa = mfma_rows<BF>(kcol, s, dqa);
   }
   if (q_ok) {
     float *__restrict__ row = dq + qrow * HD + h * D;
@@ -209,6 +239,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
 // ---------------------------------------------------------------------------------------------
 // backward 2: wave = 32 keys; loops over query tiles; writes dK, dV (no atomics).
 // ---------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
@@ -232,8 +263,8 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
     const long long qrow = (long long)b * nq + min(q0 + r, nq - 1);
     load_half_row(q, qrow, HD, h, half, qreg);
     load_half_row(dout, qrow, HD, h, half, doreg);
-    f32x16 s = mfma_rows(qreg, kreg, zero16());    // S  [query][key], lane = key
-    f32x16 dp = mfma_rows(doreg, vreg, zero16());  // dP [query][key]
+    f32x16 s = mfma_rows<BF>(qreg, kreg, zero16());    // S  [query][key], lane = key
+    f32x16 dp = mfma_rows<BF>(doreg, vreg, zero16());  // dP [query][key]
     f32x16 p;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -252,12 +283,15 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
       s[i] = ds;
     }
     // dV^T[dim][key] += dO^T[dim][query] * P[query][key];  dK^T[dim][key] += Q^T[dim][query] * dS[query][key]
+    float docol[16], qcol[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long long row = ((long long)b * nq + min(q0 + acc_row(i, half), nq - 1)) * HD + h * D + r;
-      dva = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[row], p[i], dva, 0, 0, 0);
-      dka = __builtin_amdgcn_mfma_f32_32x32x2f32(q[row], s[i], dka, 0, 0, 0);
+      docol[i] = dout[row];
+      qcol[i] = q[row];
     }
+    dva = mfma_rows<BF>(docol, p, dva);
+    dka = mfma_rows<BF>(qcol, s, dka);
   }
   if (k_ok) {
     float *__restrict__ rk = dk + krow * HD + h * D;
@@ -282,12 +316,17 @@ bool bad(int B, int H, int nq, int nk, int Dh, int bias_mode) {
 
 extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                               const float *mask, int B, int H, int nq, int nk, int Dh, float *out, float *lse,
-                              void *stream) {
+                              int bf16_mma, void *stream) {
   if (!q || !k || !v || !out || !lse || bad(B, H, nq, nk, Dh, bias_mode) || (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
-  hipLaunchKernelGGL(sdpa_fwd_kernel, dim3(vlp3d_cdiv(nq, 32), H, B), dim3(64), 0, (hipStream_t)stream, q, k, v, bias,
-                     bias_mode, mask, H, nq, nk, scale, out, lse);
+  const dim3 grid(vlp3d_cdiv(nq, 32), H, B);
+  if (bf16_mma)
+    hipLaunchKernelGGL(sdpa_fwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask, H,
+                       nq, nk, scale, out, lse);
+  else
+    hipLaunchKernelGGL(sdpa_fwd_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask,
+                       H, nq, nk, scale, out, lse);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
@@ -295,16 +334,24 @@ extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, co
 extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                               const float *mask, const float *out, const float *lse, const float *dout, int B, int H,
                               int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
-                              void *stream) {
+                              int bf16_mma, void *stream) {
   if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta || bad(B, H, nq, nk, Dh, bias_mode) ||
       (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(sdpa_bwd_dq_kernel, dim3(vlp3d_cdiv(nq, 32), H, B), dim3(64), 0, s, q, k, v, bias, bias_mode, mask,
-                     out, lse, dout, H, nq, nk, scale, dq, dbias, delta);
-  hipLaunchKernelGGL(sdpa_bwd_dkv_kernel, dim3(vlp3d_cdiv(nk, 32), H, B), dim3(64), 0, s, q, k, v, bias, bias_mode,
-                     mask, lse, dout, delta, H, nq, nk, scale, dk, dv);
+  const dim3 gq(vlp3d_cdiv(nq, 32), H, B), gk(vlp3d_cdiv(nk, 32), H, B);
+  if (bf16_mma) {
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
+                       nq, nk, scale, dq, dbias, delta);
+    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
+                       H, nq, nk, scale, dk, dv);
+  } else {
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<false>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
+                       nq, nk, scale, dq, dbias, delta);
+    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<false>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
+                       H, nq, nk, scale, dk, dv);
+  }
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -172,6 +172,8 @@ class GroundingStep:
         for m in self.model.modules():
             if hasattr(m, "mlp_dtype"):
                 m.mlp_dtype = sa_dtype
+            if hasattr(m, "bf16_mma"):  # fused attention cores follow the same switch
+                m.bf16_mma = sa_dtype == torch.bfloat16
         self.use_graph = use_graph
         # geometry pipeline: the backbone's coordinate-only stage (FPS / ball query / three_nn) of the NEXT batch
         # runs on a side stream while the dense layers of the current batch run (one workgroup per scene = 8 CUs)

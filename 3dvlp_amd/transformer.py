@@ -28,6 +28,7 @@ class ScaledDotProductAttention(nn.Module):
         self.fc_o = nn.Linear(h * d_v, d_model)
         self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
         self.impl = impl
+        self.bf16_mma = False  # True: bf16 MFMA operands in the fused core (timing configuration of the step driver)
         for fc in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
             nn.init.xavier_uniform_(fc.weight)
             nn.init.constant_(fc.bias, 0)
@@ -48,7 +49,7 @@ class ScaledDotProductAttention(nn.Module):
         if impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk):
             out = fused_attention.sdpa(q.float(), k.float(), v.float(), self.h,
                                        None if attention_weights is None else attention_weights.float(), way,
-                                       attention_mask)
+                                       attention_mask, bf16_mma=self.bf16_mma)
             return _linear(out, self.fc_o.weight, self.fc_o.bias), None
         if impl == "hip" and not q.is_cuda:
             raise RuntimeError("CPU not supported (impl='hip'); pass impl='torch' explicitly for host-side tests")

@@ -61,7 +61,7 @@ def time_kernel(fn, reps):
 
 
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-PMC_KEYS = ("fps_pruned_kernel", "ball_query_kernel<8>", "row_gemm_%s64, 0, 0>", "sdpa_fwd_kernel")
+PMC_KEYS = ("fps_pruned_kernel", "ball_query_kernel<8>", "row_gemm_%s64, 0, 0>", "sdpa_fwd_kernel<%s>")
 
 
 def attach_pmc_traffic(kernels, bf):
@@ -73,7 +73,10 @@ def attach_pmc_traffic(kernels, bf):
         return
     table = json.load(open(PMC_TRAFFIC))
     for entry, key in zip(kernels, PMC_KEYS):
-        key = key % ("lds_kernel<" if bf else "kernel<float, ") if "%s" in key else key
+        if "row_gemm" in key:
+            key = key % ("lds_kernel<" if bf else "kernel<float, ")
+        elif "sdpa" in key:
+            key = key % ("true" if bf else "false")
         for name, v in table.items():
             if key in name:
                 entry["traffic"] = v["hbm_bytes_corrected"]
@@ -111,7 +114,7 @@ def report(args, world, elapsed, loss, batch, ext):
 
     # match-module self-attention core: (B*L = 64, 256 queries, 256 keys, 4 heads x 32)
     q = torch.randn(B * LANG_NUM, 256, 128, device=xyz.device)
-    att_ms = time_kernel(lambda: fa.sdpa(q, q, q, 4), reps)
+    att_ms = time_kernel(lambda: fa.sdpa(q, q, q, 4, bf16_mma=bf), reps)
 
     esz = 2 if bf else 4
     fps_flops = B * (m - 1) * n * 11.0  # 11 flop per distance-update-compare
@@ -138,8 +141,8 @@ def report(args, world, elapsed, loss, batch, ext):
         entry(("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>") +
               " SA1 layer 1 (gather + 135->64 GEMM + BN sums)", "hbm", g_bytes, PEAK_HBM_GBS,
               "GB/s", g_ms, mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2)),
-        entry("sdpa_fwd_kernel match self-attention 64x(256x256) h4 d32", "hbm", att_bytes, PEAK_HBM_GBS, "GB/s",
-              att_ms, mfma_TFLOPs=round(4.0 * q.shape[0] * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
+        entry("sdpa_fwd_kernel<%s> match self-attention 64x(256x256) h4 d32" % ("bf16 MFMA" if bf else "fp32 MFMA"),
+              "hbm", att_bytes, PEAK_HBM_GBS, "GB/s", att_ms, mfma_TFLOPs=round(4.0 * q.shape[0] * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
     ]
     attach_pmc_traffic(kernels, bf)
     out = {
@@ -153,8 +156,9 @@ def report(args, world, elapsed, loss, batch, ext):
         "config": {"workload": "cfg2: ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
                    "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                    "step": "fwd + reduced loss + bwd + flat grad all-reduce + AdamW",
-                   "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs, fp32 "
-                                 "elsewhere" if bf else "fp32 everywhere (exact-fp32 MFMA)"),
+                   "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs, bf16 MFMA "
+                                 "operands (fp32 I/O, softmax, accumulate) in the attention cores, fp32 elsewhere"
+                                 if bf else "fp32 everywhere (exact-fp32 MFMA)"),
                    "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
                    "geometry": "inline" if args.no_pipeline else
                    "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)",

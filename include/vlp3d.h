@@ -201,15 +201,19 @@ int vlp3d_relation_bias_bwd(const float *centre, const float *params, const floa
  * q (B,nq,H*D), k/v (B,nk,H*D) are the OUTPUTS of fc_q/fc_k/fc_v (head h = columns h*D..h*D+D-1);
  * bias: (B,H,nq,nk) f32 or NULL (bias_mode 0 none, 1 add, 2 mul); mask: (B,nk) f32 or NULL,
  * broadcast over heads and queries (0 -> masked_fill(-10000)).  D must be 32.
- * -> out (B,nq,H*D) f32 (the input of fc_o), lse (B,H,nq) f32 (log-sum-exp, kept for backward). */
+ * -> out (B,nq,H*D) f32 (the input of fc_o), lse (B,H,nq) f32 (log-sum-exp, kept for backward).
+ * bf16_mma: 0 = exact-fp32 MFMA (within fp32 round-off of the reference: the 1e-4 parity configuration);
+ *           1 = operands rounded to bf16 in registers, fp32 accumulation and softmax (timing configuration). */
 int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
-                   const float *mask, int B, int H, int nq, int nk, int D, float *out, float *lse, void *stream);
+                   const float *mask, int B, int H, int nq, int nk, int D, float *out, float *lse, int bf16_mma,
+                   void *stream);
 
 /* backward of vlp3d_sdpa_fwd: dout (B,nq,H*D) -> dq, dk, dv (shapes of q,k,v; fully written),
  * dbias (B,H,nq,nk) or NULL.  delta (B,H,nq) f32 scratch. */
 int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                    const float *mask, const float *out, const float *lse, const float *dout, int B, int H, int nq,
-                   int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, void *stream);
+                   int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, int bf16_mma,
+                   void *stream);
 
 #ifdef __cplusplus
 }

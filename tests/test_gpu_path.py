@@ -59,6 +59,34 @@ def test_fused_sdpa_forward_backward(nq, nk, mode):
             assert (a.double() - b.double()).abs().max().item() < 2e-4 * scale + 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nk,mode", [(256, 256, "add"), (256, 49, None), (70, 33, "mul")])
+def test_fused_sdpa_bf16_mma_close_to_fp32(nq, nk, mode):
+    """bf16 MFMA operands (timing configuration) vs the exact-fp32 core: forward and all gradients within bf16
+    round-off (2^-8 relative to each tensor's scale), never bit-exact by construction."""
+    fa = importlib.import_module("3dvlp_amd.fused_attention")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    b, h = 3, 4
+    q0 = torch.randn(b, nq, h * 32, generator=g).cuda()
+    k0 = torch.randn(b, nk, h * 32, generator=g).cuda()
+    v0 = torch.randn(b, nk, h * 32, generator=g).cuda()
+    w0 = (torch.rand(b, h, nq, nk, generator=g) + 0.5).cuda() if mode else None
+    mask = (torch.rand(b, nk, generator=g) > 0.2).float().cuda().view(b, 1, 1, nk)
+    go = torch.randn(b, nq, h * 32, generator=g).cuda()
+    res = []
+    for bf in (False, True):
+        q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+        w = w0.clone().requires_grad_(True) if mode else None
+        out = fa.sdpa(q, k, v, h, w, mode or "add", mask, bf16_mma=bf)
+        out.backward(go)
+        res.append([out.detach(), q.grad, k.grad, v.grad] + ([w.grad] if mode else []))
+    for a, c in zip(*res):
+        scale = float(a.abs().max())
+        assert float((a - c).abs().max()) < 3e-2 * scale + 1e-6
+        assert float((a - c).norm()) < 1e-2 * float(a.norm()) + 1e-6
+    assert not torch.equal(res[0][0], res[1][0])
+
+
 def test_fused_sdpa_matches_oracle_numpy():
     fa = importlib.import_module("3dvlp_amd.fused_attention")
     rng = np.random.default_rng(0)
