@@ -109,9 +109,21 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   float m = -__builtin_inff(), l = 0.f;
   const long long bias_row = (((long long)b * H + h) * nq + qi) * nk;
 
+  // software pipeline: the K rows and the V column of tile t+1 are requested before tile t is computed (a wave walks
+  // its key tiles alone; without this every tile exposes two full memory latencies)
+  float kreg[16], vcol[16];
+  auto load_tile = [&](int k0, float (&kr)[16], float (&vc)[16]) {
+    load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), HD, h, half, kr);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = min(k0 + acc_row(i, half), nk - 1);  // p == 0 beyond nk
+      vc[i] = v[((long long)b * nk + key) * HD + h * D + r];
+    }
+  };
+  load_tile(0, kreg, vcol);
   for (int k0 = 0; k0 < nk; k0 += 32) {
-    float kreg[16];
-    load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), HD, h, half, kreg);
+    float knext[16], vnext[16];
+    load_tile(min(k0 + 32, nk - 1), knext, vnext);  // clamped: the last prefetch re-reads valid rows and is unused
     f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());  // s[reg] = S[query r][key k0 + acc_row(reg, half)]
 
     float tmax = -__builtin_inff();
@@ -140,13 +152,12 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
     l = l * alpha + psum;
     m = m_new;
     // O^T[dim][query] += V^T[dim][key] * P^T[key][query]; step i sums over key k0 + acc_row(i, half)
-    float vcol[16];
+    o = mfma_rows<BF>(vcol, s, o);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int key = min(k0 + acc_row(i, half), nk - 1);  // p == 0 beyond nk
-      vcol[i] = v[((long long)b * nk + key) * HD + h * D + r];
+      kreg[i] = knext[i];
+      vcol[i] = vnext[i];
     }
-    o = mfma_rows<BF>(vcol, s, o);
   }
   l += __shfl_xor(l, 32);
   if (q0 + r < nq) {
@@ -192,11 +203,21 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
   const long long bias_row = stat * nk;
 
   f32x16 dqa = zero16();
-  for (int k0 = 0; k0 < nk; k0 += 32) {
-    float kreg[16], vreg[16];
+  float kreg[16], vreg[16], kcol[16];
+  auto load_tile = [&](int k0, float (&kr)[16], float (&vr)[16], float (&kc)[16]) {
     const long long krow = (long long)b * nk + min(k0 + r, nk - 1);
-    load_half_row(k, krow, HD, h, half, kreg);
-    load_half_row(v, krow, HD, h, half, vreg);
+    load_half_row(k, krow, HD, h, half, kr);
+    load_half_row(v, krow, HD, h, half, vr);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = min(k0 + acc_row(i, half), nk - 1);
+      kc[i] = k[((long long)b * nk + key) * HD + h * D + r];
+    }
+  };
+  load_tile(0, kreg, vreg, kcol);
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    float knext[16], vnext[16], kcnext[16];  // next tile in flight while this one is computed
+    load_tile(min(k0 + 32, nk - 1), knext, vnext, kcnext);
     f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());    // S^T  [key][query]
     f32x16 dp = mfma_rows<BF>(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
 #pragma unroll
@@ -216,13 +237,13 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
       s[i] = ds;
     }
     // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query]
-    float kcol[16];
+    dqa = mfma_rows<BF>(kcol, s, dqa);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int key = min(k0 + acc_row(i, half), nk - 1);
-      kcol[i] = k[((long long)b * nk + key) * HD + h * D + r];
+      kreg[i] = knext[i];
+      vreg[i] = vnext[i];
+      kcol[i] = kcnext[i];
     }
-    dqa = mfma_rows<BF>(kcol, s, dqa);
   }
   if (q_ok) {
     float *__restrict__ row = dq + qrow * HD + h * D;
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
 // backward 2: wave = 32 keys; loops over query tiles; writes dK, dV (no atomics).
 // ---------------------------------------------------------------------------------------------
 template <bool BF>
-__global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sdpa_bwd_dkv_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
     const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nk, float scale,
@@ -258,11 +279,29 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
   load_half_row(v, krow, HD, h, half, vreg);
 
   f32x16 dka = zero16(), dva = zero16();
-  for (int q0 = 0; q0 < nq; q0 += 32) {
-    float qreg[16], doreg[16];
+  // Rows of the next query tile are prefetched one tile ahead; the column-layout copies and the per-query
+  // statistics of the CURRENT tile are requested at the top of the iteration and consumed after the two S / dP
+  // products (double-buffering them as well costs 64 more VGPRs and drops the kernel to one wave per SIMD).
+  float qreg[16], doreg[16];
+  auto load_rows = [&](int q0, float (&qr)[16], float (&dr)[16]) {
     const long long qrow = (long long)b * nq + min(q0 + r, nq - 1);
-    load_half_row(q, qrow, HD, h, half, qreg);
-    load_half_row(dout, qrow, HD, h, half, doreg);
+    load_half_row(q, qrow, HD, h, half, qr);
+    load_half_row(dout, qrow, HD, h, half, dr);
+  };
+  load_rows(0, qreg, doreg);
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    float qn[16], dn[16], docol[16], qcol[16], lse_t[16], delta_t[16];
+    load_rows(min(q0 + 32, nq - 1), qn, dn);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = min(q0 + acc_row(i, half), nq - 1);
+      const long long row = ((long long)b * nq + qq) * HD + h * D + r;
+      docol[i] = dout[row];
+      qcol[i] = q[row];
+      const long long stat = ((long long)b * H + h) * nq + qq;
+      lse_t[i] = lse[stat];
+      delta_t[i] = delta[stat];
+    }
     f32x16 s = mfma_rows<BF>(qreg, kreg, zero16());    // S  [query][key], lane = key
     f32x16 dp = mfma_rows<BF>(doreg, vreg, zero16());  // dP [query][key]
     f32x16 p;
@@ -275,23 +314,21 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dkv_kernel(
         const float raw = s[i] * scale;
         float x = apply_bias(raw, bias_mode, bias, stat * nk + ki);
         if (masked) x = -10000.f;
-        pv = __expf(x - lse[stat]);
-        ds = masked ? 0.f : pv * (dp[i] - delta[stat]);
+        pv = __expf(x - lse_t[i]);
+        ds = masked ? 0.f : pv * (dp[i] - delta_t[i]);
         if (bias_mode == 2) ds *= bias[stat * nk + ki];
       }
       p[i] = pv;
       s[i] = ds;
     }
     // dV^T[dim][key] += dO^T[dim][query] * P[query][key];  dK^T[dim][key] += Q^T[dim][query] * dS[query][key]
-    float docol[16], qcol[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long row = ((long long)b * nq + min(q0 + acc_row(i, half), nq - 1)) * HD + h * D + r;
-      docol[i] = dout[row];
-      qcol[i] = q[row];
-    }
     dva = mfma_rows<BF>(docol, p, dva);
     dka = mfma_rows<BF>(qcol, s, dka);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      qreg[i] = qn[i];
+      doreg[i] = dn[i];
+    }
   }
   if (k_ok) {
     float *__restrict__ rk = dk + krow * HD + h * D;

@@ -1,0 +1,23 @@
+"""Time the fused attention kernels (fwd, bwd) at the grounding shapes, fp32 and bf16 MFMA."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+fa = importlib.import_module("3dvlp_amd.fused_attention")
+ext = importlib.import_module("3dvlp_amd._lib")
+dev = torch.device("cuda:0")
+def t(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); e.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+for name, b, nq, nk in (("match self", 64, 256, 256), ("match cross", 64, 256, 49), ("relation self+bias", 8, 256, 256)):
+    q = torch.randn(b, nq, 128, device=dev); k = torch.randn(b, nk, 128, device=dev); v = torch.randn(b, nk, 128, device=dev)
+    bias = torch.randn(b, 4, nq, nk, device=dev) if "bias" in name else None
+    go = torch.randn_like(q)
+    for bf in (False, True):
+        out, lse = ext.sdpa_fwd(q, k, v, 4, bias, 1 if bias is not None else 0, None, bf)
+        f = t(lambda: ext.sdpa_fwd(q, k, v, 4, bias, 1 if bias is not None else 0, None, bf))
+        bw = t(lambda: ext.sdpa_bwd(q, k, v, 4, bias, 1 if bias is not None else 0, None, out, lse, go, bias is not None, bf))
+        print(f"{name:20s} bf16_mma={bf!s:5s} fwd {f:7.1f} us   bwd (dq+dkv) {bw:7.1f} us")
