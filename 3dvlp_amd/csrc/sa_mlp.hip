@@ -56,7 +56,7 @@ __device__ __forceinline__ short bf16_bits(float v) {
 }
 
 enum Loader { GATHER = 0, BNRELU = 1, BNBWD = 2, PLAIN = 3 };
-enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2, BIAS = 3 };
+enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2, BIAS = 3, BIAS_WT = 4 };  // BIAS_WT: BIAS with a K-major weight
 
 // Per-column constants, all fp32 vectors of length >= K (loader) / >= COUT (epilogue).
 struct RowGemmArgs {
@@ -92,6 +92,7 @@ struct RowGemmArgs {
   const unsigned char *pool_sel;
   int pool_S, pool_shift;  // pool_shift = log2(pool_S) when it is a power of two, else -1
   int S_shift;             // GATHER in wgrad: log2(S) when S is a power of two, else -1
+  int ldw;                 // BIAS_WT: the weight is given K-major, (K x ldw) row-major (dX = dY W without a transpose)
 };
 
 template <typename T, int LOADER>
@@ -139,7 +140,7 @@ struct Mma;
 template <int NCT>
 struct Mma<float, NCT> {
   static constexpr int G = 8;  // lane half h covers columns 8g+4h .. +3 (4 k-steps of the 32x32x2 MFMA)
-  template <int LOADER>
+  template <int LOADER, bool WT = false>
   static __device__ __forceinline__ void step(const RowGemmArgs &a, f32x16 (&acc)[NCT], int g, int r, int half,
                                               long long row, long long gb, long long xb, long long cb) {
     const int col0 = 8 * g + 4 * half;
@@ -147,7 +148,13 @@ struct Mma<float, NCT> {
     const float *W = reinterpret_cast<const float *>(a.W);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      const float4 bv = ld4(W + (long long)(32 * ct + r) * a.K + col0);
+      float4 bv;
+      if (WT) {  // K-major weight: four dword loads, each coalesced over the 32 output columns of the lanes
+        const float *wp = W + (long long)col0 * a.ldw + 32 * ct + r;
+        bv = make_float4(wp[0], wp[a.ldw], wp[2 * a.ldw], wp[3 * a.ldw]);
+      } else {
+        bv = ld4(W + (long long)(32 * ct + r) * a.K + col0);
+      }
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[ct], 0, 0, 0);
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[ct], 0, 0, 0);
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[ct], 0, 0, 0);
@@ -159,9 +166,10 @@ struct Mma<float, NCT> {
 template <int NCT>
 struct Mma<bf16, NCT> {
   static constexpr int G = 16;  // lane half h covers columns 16g+8h .. +7 (one 32x32x16 MFMA)
-  template <int LOADER>
+  template <int LOADER, bool WT = false>
   static __device__ __forceinline__ void step(const RowGemmArgs &a, f32x16 (&acc)[NCT], int g, int r, int half,
                                               long long row, long long gb, long long xb, long long cb) {
+    static_assert(!WT, "K-major weights are an fp32-only form");
     const int col0 = 16 * g + 8 * half;
     const float4 a0 = load_a4<bf16, LOADER>(a, row, col0, gb, xb, cb);
     const float4 a1 = load_a4<bf16, LOADER>(a, row, col0 + 4, gb, xb, cb);
@@ -207,9 +215,9 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ntiles = a.R / 32;
-  if (EPI == BIAS && gridDim.y > 1) {  // column-split launch of a small linear layer: this block owns COUT columns
-    const int c0 = blockIdx.y * COUT;
-    a.W = reinterpret_cast<const T *>(a.W) + (long long)c0 * a.K;
+  if ((EPI == BIAS || EPI == BIAS_WT) && gridDim.y > 1) {  // column-split launch of a small linear layer
+    const int c0 = blockIdx.y * COUT;                       // this block owns COUT of the output columns
+    a.W = reinterpret_cast<const T *>(a.W) + (EPI == BIAS_WT ? (long long)c0 : (long long)c0 * a.K);
     if (a.scale) a.scale += c0;
     a.Yout = reinterpret_cast<T *>(a.Yout) + c0;
   }
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
     const int ngroups = a.K / Mma<T, NCT>::G;
-    for (int g = 0; g < ngroups; ++g) Mma<T, NCT>::template step<LOADER>(a, acc, g, r, half, row, gb, xb, cb);
+    for (int g = 0; g < ngroups; ++g)
+      Mma<T, NCT>::template step<LOADER, EPI == BIAS_WT>(a, acc, g, r, half, row, gb, xb, cb);
 
     // ---- epilogue: acc[ct][i] is element (row = tile*32 + acc_row(i,half), col = 32ct + r) ----
     if (EPI == STORE) {
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
         s1[ct] += (double)ps;
         s2[ct] += (double)pq;
       }
-    } else if (EPI == BIAS) {  // plain linear layer: Y = A W^T + bias (bias may be NULL), no statistics
+    } else if (EPI == BIAS || EPI == BIAS_WT) {  // plain linear layer: Y = A W^T + bias (bias may be NULL), no statistics
       T *Y = reinterpret_cast<T *>(a.Yout);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -687,8 +696,9 @@ struct WgradArgs {
   RowGemmArgs dy;   // BNBWD loader of this layer's dY (Gin, Yin, ldin = COUT, constants)
   RowGemmArgs src;  // loader of A_{l-1} (GATHER or BNRELU), K = src.K valid columns
   int KP;           // K rounded up to a multiple of 32
-  float *partials;  // (gridDim.x x COUT x K) fp32 scratch: one slab per workgroup
+  float *partials;  // (gridDim.x x slab) fp32 scratch: one slab per workgroup, slab = COUT*K (+ COUT with colsum)
   long long tiles_per_block;
+  int colsum;       // fp32 only: also reduce the columns of dY (the bias gradient of a linear layer) into slab[COUT*K..]
 };
 
 template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD>  // MAXT = output tiles per wave
@@ -708,6 +718,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   short *ldb_a = ldb_dy + 32 * RSD;
 
   f32x16 acc[MAXT];
+  float csum = 0.f;
   int off_c[MAXT], off_k[MAXT];  // this wave's output tiles: t = wave + 4i -> (ct, kt), hoisted out of the hot loop
   bool tile_ok[MAXT];
 #pragma unroll
@@ -848,6 +859,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       fetch(tile + 1);
       fetch_idx(min(tile + 2, t1 - 1));
     }
+    if (!BF && w.colsum && (int)threadIdx.x < COUT) {
+#pragma unroll 8
+      for (int row = 0; row < 32; ++row) csum += lds_dy[row * COUT + threadIdx.x];
+    }
     if (BF) {
       // contraction over the 32 rows in two 16-row steps; lane (col, half) gathers its column's 8 rows
 #pragma unroll
@@ -878,7 +893,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   }
   // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
   // thousands of workgroups atomically adding into the same 36 KB matrix run an order of magnitude slower
-  float *slab = w.partials + (long long)blockIdx.x * COUT * K;
+  float *slab = w.partials + (long long)blockIdx.x * (COUT * K + (w.colsum ? COUT : 0));
+  if (!BF && w.colsum && (int)threadIdx.x < COUT) slab[COUT * K + threadIdx.x] = csum;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = wave + 4 * i;
@@ -1338,13 +1354,27 @@ extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bia
   return launch_row_gemm_t<float, PLAIN, BIAS>(N, a, (hipStream_t)stream);
 }
 
+// dX (R x K) = dY (R x N) * W, W (N x K) row-major as stored by nn.Linear — no transposed copy of the weight.
+extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream) {
+  if (!dY || !W || !dX || R < 32 || (R & 31) || N < 8 || (N & 7) || K < 32 || (K & 31)) return VLP3D_EINVAL;
+  RowGemmArgs a = {};
+  a.Yin = dY; a.ldin = N; a.W = W; a.K = N; a.ldw = K; a.R = R; a.Yout = dX; a.ldout = K;
+  hipLaunchKernelGGL((row_gemm_kernel<float, 32, PLAIN, BIAS_WT>), dim3(grid_tiles(R), K / 32), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
 // dW (N x K) = dY^T X   (dY (R x N), X (R x K));  partials: max_blocks * N * K floats of scratch.
+// with_bias != 0: dW has N*K + N elements, the last N are the bias gradient sum_r dY[r][:]; partials then holds
+// max_blocks * (N*K + N) floats.
 extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                                  int max_blocks, void *stream) {
+                                  int max_blocks, int with_bias, void *stream) {
   if (!dY || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
       (N & 31))
     return VLP3D_EINVAL;
   WgradArgs w = {};
+  w.colsum = with_bias != 0;
   w.src.K = K; w.src.R = R; w.src.Yin = X; w.src.ldin = K;
   w.dy.Yin = dY; w.dy.ldin = N;
   w.KP = (K + 31) & ~31;
@@ -1366,7 +1396,7 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
     default: return VLP3D_EINVAL;
   }
   if (st != VLP3D_OK) return st;
-  const int n = N * K;
+  const int n = N * K + (with_bias ? N : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

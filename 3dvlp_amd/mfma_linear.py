@@ -48,14 +48,22 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, K), dtype=torch.float32, device=dy.device)
-            _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx)
+            if K % 32 == 0:
+                _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx)  # reads W (N,K) as stored: no transposed copy
+            else:
+                _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx)
             dx = dx.view(ctx.xshape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
+            dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy.device)
             nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
-            part = torch.empty((nblk, N, K), dtype=torch.float32, device=dy.device)
-            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dw, part, nblk)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
+            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db))
+            dw = dwb[:N * K].view(N, K)
+            if want_db:
+                db = dwb[N * K:]
+        elif want_db:
             db = dy2.sum(0)
         return dx, dw, db
 

@@ -178,12 +178,15 @@ int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, 
 /* ---- plain linear layers on the grouped-MLP kernels (fp32, exact-fp32 MFMA) -----------------------------------
  * replace nn.Linear forward / weight-gradient of the attention projections, FFNs and heads on this path
  * (models/transformer/attention.py:22-25, mmattention.py:40-41, match_module.py:30-40): Y = X W^T + bias.
- * R % 32 == 0, K % 8 == 0, N in {32,64,128,160,256,288} (fwd) / {64,128,256} (wgrad).  The input gradient
- * dX = dY W is vlp3d_linear_fwd(dY, W^T, NULL, ...). */
+ * R % 32 == 0, K % 8 == 0, N in {32,64,128,160,256,288} (fwd) / {64,128,256} (wgrad).
+ * vlp3d_linear_dgrad: dX (R,K) = dY (R,N) W with W (N,K) as nn.Linear stores it (no transposed copy); K % 32 == 0.
+ * vlp3d_linear_wgrad: dW (N,K) = dY^T X; with_bias != 0 appends the bias gradient: dW then has N*K + N floats and
+ * `partials` max_blocks * (N*K + N). */
 int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
                      void *stream);
+int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream);
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                       int max_blocks, void *stream);
+                       int max_blocks, int with_bias, void *stream);
 
 /* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
  * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
