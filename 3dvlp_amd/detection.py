@@ -179,6 +179,43 @@ def box_corners(box_size, heading, center):
     return rotated + center.unsqueeze(-2)
 
 
+class _BoxDecode(torch.autograd.Function):
+    """Fused decode_pred_box + get_3d_box_batch (csrc/box_decode.hip, vlp3d_box_decode_fwd/bwd):
+    (vote_xyz (B,K,3), heading_scores (B,K,NH), heading_residuals (B,K,NH), rois (B,K,6)) ->
+    (heading (B,K), size (B,K,3), centre (B,K,3), corners (B,K,8,3) [no gradient, as in the reference])."""
+
+    @staticmethod
+    def forward(ctx, vote_xyz, heading_scores, heading_residuals, rois):
+        vote_xyz, heading_scores = vote_xyz.contiguous().float(), heading_scores.contiguous().float()
+        heading_residuals, rois = heading_residuals.contiguous().float(), rois.contiguous().float()
+        B, K, NH = heading_scores.shape
+        dev = vote_xyz.device
+        heading = torch.empty((B, K), dtype=torch.float32, device=dev)
+        size = torch.empty((B, K, 3), dtype=torch.float32, device=dev)
+        centre = torch.empty((B, K, 3), dtype=torch.float32, device=dev)
+        corners = torch.empty((B, K, 8, 3), dtype=torch.float32, device=dev)
+        cls = torch.empty((B, K), dtype=torch.int32, device=dev)
+        _ext.call("vlp3d_box_decode_fwd", vote_xyz, heading_scores, heading_residuals, rois, B * K, NH, heading, size,
+                  centre, corners, cls)
+        ctx.save_for_backward(rois, heading, cls)
+        ctx.nh = NH
+        ctx.mark_non_differentiable(corners)
+        return heading, size, centre, corners
+
+    @staticmethod
+    def backward(ctx, d_heading, d_size, d_centre, _d_corners):
+        rois, heading, cls = ctx.saved_tensors
+        B, K = heading.shape
+        d_rois = torch.empty_like(rois)
+        nh = ctx.nh
+        d_res = torch.empty((B, K, nh), dtype=torch.float32, device=rois.device)
+        d_xyz = torch.empty((B, K, 3), dtype=torch.float32, device=rois.device)
+        opt = lambda g: None if g is None else g.contiguous().float()
+        _ext.call("vlp3d_box_decode_bwd", rois, heading, cls, opt(d_heading), opt(d_size), opt(d_centre), B * K, nh, d_rois,
+                  d_res, d_xyz)
+        return d_xyz, None, d_res, d_rois
+
+
 class ProposalModule(nn.Module):
     """Vote clustering (an SA layer on the votes) + ROI heads + box decode."""
 
@@ -189,6 +226,7 @@ class ProposalModule(nn.Module):
         self.mean_size_arr = mean_size_arr
         self.num_proposal, self.sampling, self.seed_feat_dim = num_proposal, sampling, seed_feat_dim
         self.mask_box, self.use_kl_loss, self.use_vote_weight = mask_box, use_kl_loss, use_vote_weight
+        self.fused_decode = True  # csrc/box_decode.hip; False = the op-by-op restatement below (host tests)
         self.vote_aggregation = PointnetSAModuleVotes(npoint=self.num_proposal, radius=0.3, nsample=16,
                                                       mlp=[self.seed_feat_dim, 128, 128, 128], use_xyz=True,
                                                       normalize_xyz=True)
@@ -211,6 +249,17 @@ class ProposalModule(nn.Module):
 
     def decode_pred_box(self, data_dict):
         agg_xyz = data_dict["aggregated_vote_xyz"]
+        if self.fused_decode and agg_xyz.is_cuda:  # one kernel each way instead of ~30 element-wise launches
+            pred_heading, pred_box_size, pred_center, corners = _BoxDecode.apply(
+                agg_xyz, data_dict["heading_scores"], data_dict["heading_residuals"], data_dict["rois"])
+            data_dict["pred_heading"] = pred_heading
+            if self.mask_box and self.training:
+                pred_center, pred_box_size = self.mask(pred_center, pred_box_size)
+                corners = box_corners(pred_box_size.detach(), pred_heading.detach(), pred_center.detach())
+            data_dict["pred_size"] = pred_box_size
+            data_dict["pred_center"] = pred_center
+            data_dict["pred_bbox_corner"] = corners
+            return data_dict
         heading_class = torch.argmax(data_dict["heading_scores"], -1)
         heading_residual = torch.gather(data_dict["heading_residuals"], 2, heading_class.unsqueeze(-1))
         rois = data_dict["rois"]

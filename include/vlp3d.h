@@ -188,6 +188,21 @@ int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int 
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, void *stream);
 
+/* ---- box decode of the proposal module (csrc/box_decode.hip) ------------------------------------------------
+ * Replaces decode_pred_box (models/proposal_module/proposal_module_fcos.py:94-144) + get_3d_box_batch
+ * (utils/box_util.py:361-385) for n = B*num_proposal proposals, NH heading bins:
+ *   vote_xyz (n,3), heading_scores (n,NH), heading_residuals (n,NH), rois (n,6: distances to the 6 faces)
+ *   -> heading (n), size (n,3), centre (n,3), corners (n,8,3), heading_class (n) int32 (kept for backward).
+ * bwd: d_heading (n) / d_size (n,3) / d_centre (n,3), any of them NULL = zero
+ *   -> d_rois (n,6), d_residuals (n,NH), d_vote_xyz (n,3), all fully written.  corners carry no gradient
+ *   (the reference builds them from .detach().cpu().numpy() values). */
+int vlp3d_box_decode_fwd(const float *vote_xyz, const float *heading_scores, const float *heading_residuals,
+                         const float *rois, int n, int NH, float *heading, float *size, float *centre, float *corners,
+                         int *heading_class, void *stream);
+int vlp3d_box_decode_bwd(const float *rois, const float *heading, const int *heading_class, const float *d_heading,
+                         const float *d_size, const float *d_centre, int n, int NH, float *d_rois, float *d_residuals,
+                         float *d_vote_xyz, void *stream);
+
 /* ---- pairwise-geometry attention bias of the relation module (csrc/relation_bias.hip) ------------------
  * Replaces models/proposal_module/relation_module.py:72-92 per layer: out[b,c,i,j] = MLP([c_j - c_i, |c_j - c_i|])[c]
  * with MLP = Linear(4,32) ReLU LayerNorm(32) Linear(32,32) ReLU LayerNorm(32) Linear(32,4) (:26-37).

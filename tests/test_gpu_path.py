@@ -340,3 +340,31 @@ def test_mfma_linear_equals_f_linear(R, K, N):
     exp = torch.autograd.grad(ref, [x, w, b], g.double())
     for a, e in zip(got, exp):
         assert (a.double() - e.double()).abs().max().item() < 1e-4 * e.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("NH", [1, 12])
+def test_box_decode_fused_equals_op_sequence(NH):
+    """csrc/box_decode.hip vs the op-by-op restatement of decode_pred_box + get_3d_box_batch: same values (fp32
+    round-off of cos/sin only) and the same gradients w.r.t. rois, heading residuals and vote centres."""
+    det = importlib.import_module("3dvlp_amd.detection")
+    g = torch.Generator(device="cpu").manual_seed(3 + NH)
+    B, K = 3, 256
+    base = {"aggregated_vote_xyz": torch.randn(B, K, 3, generator=g) * 2,
+            "heading_scores": torch.randn(B, K, NH, generator=g),
+            "heading_residuals": torch.randn(B, K, NH, generator=g) * 0.2,
+            "rois": torch.randn(B, K, 6, generator=g).mul(0.5).exp()}
+    base["heading_scores"][0, 0, :] = 0.25  # a tie: the first maximum wins
+    weights = [torch.randn(B, K, generator=g), torch.randn(B, K, 3, generator=g), torch.randn(B, K, 3, generator=g)]
+    res = []
+    for fused in (False, True):
+        pm = det.ProposalModule(18, NH, 18, np.ones((18, 3), np.float32), K, "vote_fps").cuda()
+        pm.fused_decode = fused
+        d = {k: v.clone().cuda().requires_grad_(k != "heading_scores") for k, v in base.items()}
+        out = pm.decode_pred_box(dict(d))
+        loss = sum((out[k] * w.cuda()).sum() for k, w in zip(("pred_heading", "pred_size", "pred_center"), weights))
+        loss.backward()
+        assert not out["pred_bbox_corner"].requires_grad
+        res.append(([out[k].detach() for k in ("pred_heading", "pred_size", "pred_center", "pred_bbox_corner")],
+                    [d[k].grad for k in ("aggregated_vote_xyz", "heading_residuals", "rois")]))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
