@@ -46,6 +46,7 @@ SIGNATURES = {
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_sa_pool_tstats": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
+    "vlp3d_sa_prep_weights": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "vlp3d_box_decode_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_box_decode_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_linear_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],

@@ -98,6 +98,39 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(const float
   }
 }
 
+// LDS-privatised form for m <= 2048 known points: a workgroup owns CPB channels of one scene, accumulates their m
+// gradients in LDS (ds_add_f32; the global-atomic form runs ~6 colliding adds per address through L2: 103 us at
+// (8,256,1024)->(8,256,512)) and writes every output exactly once — no memset, no global atomics.
+template <int CPB>
+__global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(const float *__restrict__ grad_out,
+                                                                         const int *__restrict__ idx,
+                                                                         const float *__restrict__ weight, int C, int n,
+                                                                         int m, float *__restrict__ grad_points) {
+  extern __shared__ float acc[];  // [CPB][m]
+  const int b = blockIdx.y, c0 = blockIdx.x * CPB;
+  for (int i = threadIdx.x; i < CPB * m; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int *__restrict__ id = idx + ((size_t)b * n + j) * 3;
+    const float *__restrict__ w = weight + ((size_t)b * n + j) * 3;
+    const int i1 = id[0], i2 = id[1], i3 = id[2];
+    const float w1 = w[0], w2 = w[1], w3 = w[2];
+#pragma unroll
+    for (int cc = 0; cc < CPB; ++cc) {
+      if (c0 + cc >= C) break;
+      const float g = grad_out[((size_t)b * C + c0 + cc) * n + j];
+      atomicAdd(acc + cc * m + i1, g * w1);
+      atomicAdd(acc + cc * m + i2, g * w2);
+      atomicAdd(acc + cc * m + i3, g * w3);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CPB * m; i += 256) {
+    const int cc = i / m;
+    if (c0 + cc < C) grad_points[((size_t)b * C + c0 + cc) * m + (i - cc * m)] = acc[i];
+  }
+}
+
 int pick_c_per_block(int C, long long blocks_xz) {
   int split = (int)((2048 + blocks_xz - 1) / blocks_xz);
   if (split < 1) split = 1;
@@ -132,6 +165,13 @@ extern "C" int vlp3d_three_interpolate_grad(const float *grad_out, const int *id
   if (!grad_out || !idx || !weight || !grad_points || B < 1 || B > 65535 || C < 1 || m < 1 || n < 1)
     return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (m <= 2048) {
+    constexpr int CPB = 4;
+    hipLaunchKernelGGL(three_interpolate_grad_lds_kernel<CPB>, dim3(vlp3d_cdiv(C, CPB), B), dim3(256),
+                       sizeof(float) * CPB * m, s, grad_out, idx, weight, C, n, m, grad_points);
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  }
   hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * m, s);
   if (e != hipSuccess) return (int)e;
   const int gx = vlp3d_cdiv(n, 256);

@@ -1425,6 +1425,64 @@ extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bia
   return launch_row_gemm_t<float, PLAIN, BIAS>(N, a, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// All weight layouts of one fused SA layer stack in ONE launch (was: cat + zero-fill + 3 casts forward, two
+// transposes + zero-fill + slice copy backward — nine tiny launches per SA module and step):
+//   W1p (c0 x K1)  = [W1[:, 3:3+C] | W1[:, 0:3] | 0]      (first-layer weight in the row layout [features | xyz | 0])
+//   W2d (c1 x c0), W3d (c2 x c1)                           (cast only)
+//   WT1 (kpad x c0) = W1p^T zero-padded to kpad rows,  WT2 (c0 x c1) = W2^T,  WT3 (c1 x c2) = W3^T   (backward)
+// `out` is one buffer holding the six matrices back to back in that order.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sa_prep_weights_kernel(const float *__restrict__ W1, const float *__restrict__ W2,
+                                                              const float *__restrict__ W3, int C, int c0, int c1, int c2,
+                                                              int K1, int kpad, T *__restrict__ out) {
+  const int n1 = c0 * K1, n2 = c1 * c0, n3 = c2 * c1, n4 = kpad * c0, n5 = c0 * c1, n6 = c1 * c2;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n1 + n2 + n3 + n4 + n5 + n6) return;
+  const int o = i;
+  float v;
+  auto w1p = [&](int row, int k) -> float {  // W1p[row][k]
+    if (k < C) return W1[row * (C + 3) + 3 + k];
+    if (k < C + 3) return W1[row * (C + 3) + (k - C)];
+    return 0.f;
+  };
+  if (i < n1) {
+    v = w1p(i / K1, i % K1);
+  } else if ((i -= n1) < n2) {
+    v = W2[i];
+  } else if ((i -= n2) < n3) {
+    v = W3[i];
+  } else if ((i -= n3) < n4) {
+    const int k = i / c0, row = i - k * c0;  // WT1[k][row] = W1p[row][k]
+    v = k < K1 ? w1p(row, k) : 0.f;
+  } else if ((i -= n4) < n5) {
+    const int k = i / c1, row = i - k * c1;  // WT2[k][row] = W2[row][k]
+    v = W2[row * c0 + k];
+  } else {
+    i -= n5;
+    const int k = i / c2, row = i - k * c2;  // WT3[k][row] = W3[row][k]
+    v = W3[row * c1 + k];
+  }
+  st1(out + o, v);
+}
+
+extern "C" int vlp3d_sa_prep_weights(const float *W1, const float *W2, const float *W3, int C, int c0, int c1, int c2,
+                                     int K1, int kpad, void *out, int bf16_io, void *stream) {
+  if (!W1 || !W2 || !W3 || !out || C < 1 || c0 < 1 || c1 < 1 || c2 < 1 || K1 < C + 3 || kpad < K1) return VLP3D_EINVAL;
+  const long long total = (long long)c0 * K1 + (long long)c1 * c0 + (long long)c2 * c1 + (long long)kpad * c0 +
+                          (long long)c0 * c1 + (long long)c1 * c2;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (bf16_io)
+    hipLaunchKernelGGL(sa_prep_weights_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, W1, W2, W3, C, c0, c1, c2,
+                       K1, kpad, (bf16 *)out);
+  else
+    hipLaunchKernelGGL(sa_prep_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, W1, W2, W3, C, c0, c1, c2,
+                       K1, kpad, (float *)out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
 // dX (R x K) = dY (R x N) * W, W (N x K) row-major as stored by nn.Linear — no transposed copy of the weight.
 extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream) {
   if (!dY || !W || !dX || R < 32 || (R & 31) || N < 8 || (N & 7) || K < 32 || (K & 31)) return VLP3D_EINVAL;

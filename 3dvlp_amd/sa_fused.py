@@ -51,10 +51,15 @@ class FusedSAMLP(Function):
         dev = xyz.device
         cout = [w.shape[0] for w in W]
         K1 = _round_up(C + 4, 16 if use_bf16 else 8)
-        w1 = W[0][:, :, 0, 0]
-        # first-layer weight in the row layout [features | xyz | 0-pad]
-        W1p = torch.cat([w1[:, 3:], w1[:, :3], w1.new_zeros(cout[0], K1 - C - 3)], dim=1)
-        Wd = [W1p.to(dt).contiguous(), W[1][:, :, 0, 0].to(dt).contiguous(), W[2][:, :, 0, 0].to(dt).contiguous()]
+        kpad = _round_up(C + 3, 32)
+        # every weight layout of the stack (forward operands + the transposes backward needs) from one launch
+        sizes = [cout[0] * K1, cout[1] * cout[0], cout[2] * cout[1], kpad * cout[0], cout[0] * cout[1], cout[1] * cout[2]]
+        wbuf = torch.empty((sum(sizes),), dtype=dt, device=dev)
+        _ext.call("vlp3d_sa_prep_weights", W[0].contiguous(), W[1].contiguous(), W[2].contiguous(), C, cout[0], cout[1],
+                  cout[2], K1, kpad, wbuf, bf)
+        parts = torch.split(wbuf, sizes)
+        Wd = [parts[0].view(cout[0], K1), parts[1].view(cout[1], cout[0]), parts[2].view(cout[2], cout[1])]
+        WTs = [parts[3].view(kpad, cout[0]), parts[4].view(cout[0], cout[1]), parts[5].view(cout[1], cout[2])]
         Ks = [K1, cout[0], cout[1]]
         nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))  # one [sum | sumsq] slab per workgroup, no atomics
         Y, vecs = [], []
@@ -84,7 +89,7 @@ class FusedSAMLP(Function):
         out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
         sel = torch.empty((B * M, cout[2]), dtype=torch.uint8, device=dev)
         _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf)
-        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *Wd, *gam, *bet)
+        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet)
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
         return out
 
@@ -93,7 +98,7 @@ class FusedSAMLP(Function):
         B, N, M, S, C, R, radius, bf, dt, cout, Ks, training = ctx.cfg
         sv = ctx.saved_tensors
         xyz, new_xyz, idx, feat_pm, out, sel = sv[:6]
-        Y, vecs, Wd, gam, bet = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21]
+        Y, vecs, WTs, gam, bet = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21]
         dev = xyz.device
         dP = dP.contiguous().float()
         need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
@@ -128,9 +133,8 @@ class FusedSAMLP(Function):
                           vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
                           *(pool if G is None else (None, None, 0)), bf)
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
-                WT = Wd[l].t().contiguous()
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
-                _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WT, cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
+                _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WTs[l], cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
                           t[l - 1], *(pool if G is None else (None, None, 0)), bf)
                 G = Gp
             else:
@@ -138,13 +142,11 @@ class FusedSAMLP(Function):
                           feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf)
                 dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
-                    kpad = _round_up(C + 3, 32)
-                    WT = torch.zeros((kpad, cout[0]), dtype=dt, device=dev)
-                    WT[:Ks[0]] = Wd[0].t()
+                    kpad = WTs[0].shape[0]
                     dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dev) if need[3] else None
                     dxyz = torch.zeros((B, N, 3), dtype=torch.float32, device=dev) if need[0] else None
                     dnew = torch.zeros((B, M, 3), dtype=torch.float32, device=dev) if need[1] else None
-                    _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WT, kpad, idx, B, N, M, S, C, radius, dfeat,
+                    _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
                               dxyz, dnew, bf)
         return (dxyz, dnew, None, dfeat, None, None, None, None, *dparams)
 

@@ -175,6 +175,12 @@ int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t
 int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,
                          double *t, float *gsel, void *stream);
 
+/* Weight layouts of one fused SA stack in one launch.  W1 (c0, C+3) [xyz | features] as the reference's first
+ * conv stores it, W2 (c1, c0), W3 (c2, c1), all fp32.  out (bf16 or fp32 by bf16_io) receives, back to back:
+ * W1p (c0,K1) = [features | xyz | 0], W2 (c1,c0), W3 (c2,c1), W1p^T zero-padded (kpad,c0), W2^T (c0,c1), W3^T (c1,c2). */
+int vlp3d_sa_prep_weights(const float *W1, const float *W2, const float *W3, int C, int c0, int c1, int c2, int K1,
+                          int kpad, void *out, int bf16_io, void *stream);
+
 /* ---- plain linear layers on the grouped-MLP kernels (fp32, exact-fp32 MFMA) -----------------------------------
  * replace nn.Linear forward / weight-gradient of the attention projections, FFNs and heads on this path
  * (models/transformer/attention.py:22-25, mmattention.py:40-41, match_module.py:30-40): Y = X W^T + bias.
