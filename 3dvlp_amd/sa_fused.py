@@ -19,11 +19,16 @@ WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 1024))  # most workgroup
 WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
 
 
+WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 1024))  # cap on the partial-dW slabs of one launch
+
+
 def _wgrad_blocks(R, cout, K):
     """Workgroups of the weight-gradient kernel: enough resident waves to cover the memory latency of the
-    staging loads (light tiles: several workgroups per CU), few enough that the slab sum stays small."""
+    staging loads (light tiles: several workgroups per CU), few enough that writing and re-reading the
+    per-workgroup dW slabs (cout*K floats each) stays small against the operands themselves."""
     ntiles = R // 32
-    return max(64, min(WGRAD_BLOCKS, ntiles // WGRAD_TILES))
+    by_slab = int(WGRAD_SLAB_MB * 2 ** 20 / (cout * K * 4))
+    return max(64, min(WGRAD_BLOCKS, ntiles // WGRAD_TILES, by_slab))
 
 
 def _round_up(x, m):
