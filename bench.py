@@ -45,19 +45,22 @@ def cpu_baseline(batch_np):
                       ", ".join(f"{k} {v:.2f}" for k, v in parts.items())}
 
 
-def time_kernel(fn, reps):
-    """Mean duration (ms) of `fn` (one hand-written kernel launch) bracketed by event pairs on the launch stream."""
+def time_kernel(fn, reps, inner=8):
+    """Mean duration (ms) of `fn` (one hand-written kernel launch): event pairs on the launch stream around `inner`
+    back-to-back launches (the kernels serialise on the stream; a pair around a single 30 us kernel would mostly
+    measure the launch path), averaged over `reps` such groups."""
     fn()
     torch.cuda.synchronize()
     total = 0.0
     for _ in range(reps):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e.record()
         e.synchronize()
         total += s.elapsed_time(e)
-    return total / reps
+    return total / (reps * inner)
 
 
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -96,7 +99,7 @@ def report(args, world, elapsed, loss, batch, ext):
     xyz = pc[..., :3].contiguous()
     feat_pm = pc[..., 3:].contiguous()
 
-    fps_ms = time_kernel(lambda: pu.furthest_point_sample(xyz, m), reps)
+    fps_ms = time_kernel(lambda: pu.furthest_point_sample(xyz, m), reps, inner=1)
     inds = pu.furthest_point_sample(xyz, m)
     new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
     bq_ms = time_kernel(lambda: pu.ball_query(0.2, 64, xyz, new_xyz), reps)
