@@ -5,15 +5,18 @@
 // Idea: after j samples every running minimum temp[p] is <= r_j^2 (the current max-min distance), so the new
 // sample q can only lower temp[p] for points within r_j of q.  Points are first sorted by a 15-bit Morton cell
 // (counting sort, 4 small kernels), so that a "slot" = 64 consecutive sorted points (one per lane of one wave)
-// is spatially compact.  Lane i of a wave keeps the metadata of the wave's slot i: its exact bounding box and
-// its current (max temp, tie key) as the same 64-bit key the dense kernel reduces.  Per iteration a lane tests
-// its slot:  box_distance^2(q) * (1 - 1e-5)  <  slot max  — if not, NO point of the slot can change
-// (computed d >= box distance up to a few ulp, the margin covers fp32 rounding) and the slot is skipped
-// wholesale; its cached key still takes part in the argmax.  Active slots (ballot -> scalar loop over set bits)
-// stream their 64 points (x,y,z,temp as one float4, L2 resident), update temp, and recompute the slot key with
-// one wave reduction.  The block argmax then runs over 16 x nslots cached keys instead of n points.
-// Tie order, skip rule (|p|^2 <= 1e-3 -> never a candidate) and the fp32 distance expression are those of the
-// dense kernel; the original index needed by the tie key travels with the point (perm).
+// is spatially compact.  Lane i of a wave keeps the state of the wave's slot i: its exact bounding box, its
+// current maximum temp and that point's lane and coordinates.  Per iteration a lane tests its slot:
+//     box_distance^2(q) * (1 - 1e-5)  <  slot max
+// — if not, NO point of the slot can change (computed d >= box distance up to a few ulp, the margin covers fp32
+// rounding) and the slot is skipped wholesale; its cached maximum still takes part in the argmax.  On the bench
+// scenes ~14 of the 640 (slot, wave) pairs are active per iteration (2.2 %).  Active slots (ballot -> scalar loop)
+// read their 64 points (x,y,z,temp as one float4; LDS for the first 9 slots of every wave, L2 for the rest),
+// update temp, and recompute the slot maximum with one 32-bit wave reduction.
+// Tie order (the reference's reduction tree prefers the smallest (bitrev_P(k mod P), k) among equal values), skip
+// rule (|p|^2 <= 1e-3 -> never a candidate) and the fp32 distance expression are those of the dense kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -153,11 +156,42 @@ __global__ __launch_bounds__(256) void fps_scatter_kernel(const float *__restric
   perm[(size_t)b * N + pos] = k;
 }
 
-// ---- main kernel ------------------------------------------------------------------------------------------
+// ---- main kernel ------------------------------------------------------------------------------------------------
+// One workgroup (16 waves) per scene.  The per-iteration dependency chain is what bounds it, so:
+//  * the cached per-slot state is (max value, winner lane, winner coordinates); the reference's tie order among
+//    EQUAL values is resolved exactly but lazily — only when a 32-bit max is attained more than once do the tied
+//    lanes look up their original indices (perm) and compare the reference's tie key; a hierarchical max that breaks
+//    ties by the same total order at every level returns the same winner as the flat 64-bit key reduction;
+//  * reductions are 32-bit DPP reductions (the 64-bit form costs three times the instructions);
+//  * the winner's COORDINATES travel with the candidate (slot -> wave -> block through LDS), so the next iteration
+//    starts without a dependent global load of xyz[old]; idx[j] = perm[pos] is written off the critical path;
+//  * the first L slots of every wave live in LDS (x,y,z,temp as float4, 16 KB per slot), the rest stays in L2.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // result is wave-uniform
+  v = dpp_max_u32<0xB1>(v);
+  v = dpp_max_u32<0x4E>(v);
+  v = dpp_max_u32<0x141>(v);
+  v = dpp_max_u32<0x140>(v);
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restrict__ xyz_all, float4 *__restrict__ pts_all,
-                                                          const int *__restrict__ perm_all, int *__restrict__ idx_all,
-                                                          int N, int m, int log2P) {
-  __shared__ unsigned long long s_best[3];
+                                                           const int *__restrict__ perm_all, int *__restrict__ idx_all,
+                                                           int N, int m, int log2P, int L, int m_lds) {
+  extern __shared__ float4 lpts[];  // [L][1024]: slots 0..L-1 of every wave; then int s_out[m_lds]: sorted positions
+  int *s_out = reinterpret_cast<int *>(lpts + (size_t)L * 1024);  // of the samples (idx = perm[pos], written at the end)
+  __shared__ unsigned s_val[2][16], s_pos[2][16];
+  __shared__ float s_xyz[2][16][3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
@@ -165,25 +199,34 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   float4 *__restrict__ pts = pts_all + (size_t)b * N;
   const int *__restrict__ perm = perm_all + (size_t)b * N;
   int *__restrict__ idx = idx_all + (size_t)b * m;
-  const int nslots = (N + 1023) / 1024;  // <= 64: lane i of a wave holds the metadata of the wave's slot i
+  const int nslots = (N + 1023) / 1024;  // <= 64: lane i of a wave holds the state of the wave's slot i
   const unsigned Pm1 = (1u << log2P) - 1u;
-  const unsigned lowmask = (unsigned)((1ull << (32 - log2P)) - 1ull);
 
-  auto make_key = [&](float t, int orig, bool valid) -> unsigned long long {
-    if (!(valid && t >= 0.f)) return 0ull;
+  // larger = preferred by the reference's reduction tree among equal values (see fps.hip)
+  auto tiekey = [&](int orig) -> unsigned {
     const unsigned k = (unsigned)orig;
-    const unsigned tie = __brev(k & Pm1) | (k >> log2P);
-    return ((unsigned long long)(__float_as_uint(t) + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+    return 0xFFFFFFFFu - (__brev(k & Pm1) | (k >> log2P));
+  };
+  auto value_of = [](float t, bool valid) -> unsigned { return (valid && t >= 0.f) ? __float_as_uint(t) + 1u : 0u; };
+  // winner lane of a slot given every lane's value v (0 = not a candidate); vmax = wave max of v, > 0
+  auto winner_lane = [&](unsigned v, unsigned vmax, int pos) -> int {
+    const unsigned long long w = __ballot(v == vmax);
+    if (__popcll(w) == 1) return __builtin_ctzll(w);
+    const unsigned tk = (v == vmax) ? tiekey(perm[pos]) : 0u;  // exact tie: the reference's order decides
+    const unsigned tmax = wave_max_u32(tk);
+    return __builtin_ctzll(__ballot(v == vmax && tk == tmax));
   };
 
-  // per-lane metadata of slot `lane`: exact bounding box + cached 64-bit key
   float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};
-  unsigned long long mykey = 0ull;
+  unsigned sval = 0u;
+  int swl = 0;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
   for (int i = 0; i < nslots; ++i) {
     const int pos = i * 1024 + wave * 64 + lane;
     const bool valid = pos < N;
-    const float4 p = pts[valid ? pos : N - 1];
-    const int o = perm[valid ? pos : N - 1];
+    float4 p = pts[valid ? pos : N - 1];
+    if (!valid) p.w = -1.f;
+    if (i < L) lpts[i * 1024 + tid] = p;
     float lo[3], hi[3];
     const float c[3] = {p.x, p.y, p.z};
 #pragma unroll
@@ -191,36 +234,35 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
       lo[a] = wave_minmax_f32<false>(valid ? c[a] : 3.0e38f);
       hi[a] = wave_minmax_f32<true>(valid ? c[a] : -3.0e38f);
     }
-    const unsigned long long k = wave_max_u64(make_key(p.w, o, valid));
+    const unsigned v = value_of(p.w, valid);
+    const unsigned vmax = wave_max_u32(v);
+    int wl = 0;
+    if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
+    const float wx = readlane_f32(p.x, wl), wy = readlane_f32(p.y, wl), wz = readlane_f32(p.z, wl);
     if (lane == i) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         blo[a] = lo[a];
         bhi[a] = hi[a];
       }
-      mykey = k;
+      sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz;
     }
   }
-  if (tid < 3) s_best[tid] = 0ull;
   if (tid == 0) idx[0] = 0;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  int par = 0;
   __syncthreads();
 
-  int old = 0, slot = 1;
   for (int j = 1; j < m; ++j) {
-    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
-    // squared distance from the new sample to my slot's box; a slot whose bound exceeds its max is untouched
     const float ex = fmaxf(0.f, fmaxf(blo[0] - x1, x1 - bhi[0]));
     const float ey = fmaxf(0.f, fmaxf(blo[1] - y1, y1 - bhi[1]));
     const float ez = fmaxf(0.f, fmaxf(blo[2] - z1, z1 - bhi[2]));
     const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
-    const unsigned vk = (unsigned)(mykey >> 32);
-    const bool active = (lane < nslots) && (vk != 0u) && (lb2 < __uint_as_float(vk - 1u));
+    const bool active = (lane < nslots) && (sval != 0u) && (lb2 < __uint_as_float(sval - 1u));
     unsigned long long todo = __ballot(active);
-    while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time:
-      // all global loads of a batch are issued before the first wave reduction, so their latency overlaps
+    while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time
       int si[4];
       float4 p[4];
-      int o[4];
       int nb = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -229,10 +271,16 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
           si[u] = __builtin_ctzll(todo);
           todo &= todo - 1ull;
           nb = u + 1;
-          const int pos = si[u] * 1024 + wave * 64 + lane;
-          const int pc = pos < N ? pos : N - 1;
-          p[u] = pts[pc];
-          o[u] = perm[pc];
+          if (si[u] < L) {
+            p[u] = lpts[si[u] * 1024 + tid];
+          } else {
+            // the barrier below does not wait for global stores any more: order this read after the wave's own
+            // older temp stores to the slot (they were issued iterations ago; the wait is free in practice)
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) only (gfx9 encoding: expcnt/lgkmcnt fields left at max)
+            const int pos = si[u] * 1024 + wave * 64 + lane;
+            p[u] = pts[pos < N ? pos : N - 1];
+            if (pos >= N) p[u].w = -1.f;
+          }
         }
       }
 #pragma unroll
@@ -242,26 +290,55 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
           const bool valid = pos < N;
           const float d = vlp3d_sumsq3(p[u].x - x1, p[u].y - y1, p[u].z - z1);
           const float t = vmin(d, p[u].w);
-          if (valid) pts[pos].w = t;
-          const unsigned long long k = wave_max_u64(make_key(t, o[u], valid));
-          if (lane == si[u]) mykey = k;
+          if (si[u] < L) lpts[si[u] * 1024 + tid].w = t;
+          else if (valid) pts[pos].w = t;
+          const unsigned v = value_of(t, valid);
+          const unsigned vmax = wave_max_u32(v);
+          int wl = 0;
+          if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
+          const float wx = readlane_f32(p[u].x, wl), wy = readlane_f32(p[u].y, wl), wz = readlane_f32(p[u].z, wl);
+          if (lane == si[u]) { sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz; }
         }
       }
     }
-    const unsigned long long cand = wave_max_u64(mykey);
-    if (lane == 0) atomicMax(&s_best[slot], cand);
-    const int nslot = slot == 2 ? 0 : slot + 1;
-    if (tid == 0) s_best[nslot] = 0ull;
-    __syncthreads();
-    const unsigned long long g = s_best[slot];
-    slot = nslot;
-    unsigned k = 0u;
-    if ((unsigned)(g >> 32) != 0u) {
-      const unsigned tie = 0xFFFFFFFFu - (unsigned)g;
-      k = ((tie & lowmask) << log2P) | __brev(tie & ~lowmask);
+    // wave candidate = best slot (ties between slots by the reference's order of their winners)
+    const unsigned mine = lane < nslots ? sval : 0u;
+    const unsigned vw = wave_max_u32(mine);
+    int cl = 0;
+    if (vw != 0u) cl = winner_lane(mine, vw, min(lane * 1024 + wave * 64 + swl, N - 1));
+    const int cwl = __builtin_amdgcn_readlane(swl, cl);
+    const float cx = readlane_f32(sx, cl), cy = readlane_f32(sy, cl), cz = readlane_f32(sz, cl);
+    if (lane == 0) {
+      s_val[par][wave] = vw;
+      s_pos[par][wave] = (unsigned)(cl * 1024 + wave * 64 + cwl);
+      s_xyz[par][wave][0] = cx; s_xyz[par][wave][1] = cy; s_xyz[par][wave][2] = cz;
     }
-    old = __builtin_amdgcn_readfirstlane((int)k);
-    if (tid == 0) idx[j] = old;
+    // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait ~1 us for the acknowledgement of the
+    // temp stores of global slots and of the sample list — nobody else reads those before the kernel ends
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // block winner, computed redundantly by every wave from the 16 candidates (no second barrier)
+    const unsigned bv = lane < 16 ? s_val[par][lane] : 0u;
+    const unsigned bpos = lane < 16 ? s_pos[par][lane] : 0u;
+    const unsigned bmax = wave_max_u32(bv);
+    if (bmax != 0u) {
+      const int wi = winner_lane(bv, bmax, (int)min(bpos, (unsigned)(N - 1)));
+      x1 = s_xyz[par][wi][0]; y1 = s_xyz[par][wi][1]; z1 = s_xyz[par][wi][2];
+      if (tid == 0) {
+        if (m_lds) s_out[j] = (int)s_pos[par][wi];
+        else idx[j] = perm[s_pos[par][wi]];
+      }
+    } else {  // no candidate left (every point skipped): the reference returns index 0
+      x1 = xyz[0]; y1 = xyz[1]; z1 = xyz[2];
+      if (tid == 0) {
+        if (m_lds) s_out[j] = -1;
+        else idx[j] = 0;
+      }
+    }
+    par ^= 1;
+  }
+  if (m_lds) {  // sorted position -> original index, all threads
+    __syncthreads();
+    for (int j = 1 + tid; j < m; j += 1024) idx[j] = s_out[j] < 0 ? 0 : perm[s_out[j]];
   }
 }
 
@@ -306,7 +383,21 @@ extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int
   hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist);
   hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
   hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
-  hipLaunchKernelGGL(fps_pruned_kernel, dim3(B), dim3(1024), 0, s, xyz, pts, perm, idx, N, m, reference_log2_block(N));
+  static const int l_env = getenv("VLP3D_FPS_LDS_SLOTS") ? atoi(getenv("VLP3D_FPS_LDS_SLOTS")) : 9;
+  const int nslots = (N + 1023) / 1024;
+  int L = l_env < 0 ? 0 : (l_env > 9 ? 9 : l_env);  // 9 x 16 KB of the 160 KB LDS hold slots 0..8 of every wave
+  if (L > nslots) L = nslots;
+  const int m_lds = m <= 2048 ? m : 0;  // the sample list is collected in LDS (8 KB) and written out at the end
+  const size_t lds = (size_t)L * 1024 * sizeof(float4) + (size_t)m_lds * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)fps_pruned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       9 * 1024 * (int)sizeof(float4) + 2048 * (int)sizeof(int));
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fps_pruned_kernel, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N),
+                     L, m_lds);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

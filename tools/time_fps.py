@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pu = importlib.import_module("3dvlp_amd.pointnet2_utils")
 synth = importlib.import_module("3dvlp_amd.synth")
 xyz_full = torch.from_numpy(np.stack([synth.make_scene(1000 + i, 45000)["xyz"] for i in range(8)])).cuda()
-for N, m in ((16384, 2048), (24576, 2048), (33792, 2048), (36864, 2048), (40000, 2048), (45000, 2048), (2048, 1024), (1024, 512), (512, 256)):
+for N, m in [(int(a.split(",")[0]), int(a.split(",")[1])) for a in sys.argv[1:]] or ((16384, 2048), (24576, 2048), (33792, 2048), (36864, 2048), (40000, 2048), (45000, 2048), (2048, 1024), (1024, 512), (512, 256)):
     x = xyz_full[:, :N].contiguous()
     for _ in range(2): pu.furthest_point_sample(x, m)
     torch.cuda.synchronize()
