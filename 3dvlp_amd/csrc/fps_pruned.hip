@@ -15,8 +15,6 @@
 // update temp, and recompute the slot maximum with one 32-bit wave reduction.
 // Tie order (the reference's reduction tree prefers the smallest (bitrev_P(k mod P), k) among equal values), skip
 // rule (|p|^2 <= 1e-3 -> never a candidate) and the fp32 distance expression are those of the dense kernel.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -383,10 +381,8 @@ extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int
   hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist);
   hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
   hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
-  static const int l_env = getenv("VLP3D_FPS_LDS_SLOTS") ? atoi(getenv("VLP3D_FPS_LDS_SLOTS")) : 9;
   const int nslots = (N + 1023) / 1024;
-  int L = l_env < 0 ? 0 : (l_env > 9 ? 9 : l_env);  // 9 x 16 KB of the 160 KB LDS hold slots 0..8 of every wave
-  if (L > nslots) L = nslots;
+  const int L = nslots < 9 ? nslots : 9;  // 9 x 16 KB of the 160 KB LDS hold slots 0..8 of every wave
   const int m_lds = m <= 2048 ? m : 0;  // the sample list is collected in LDS (8 KB) and written out at the end
   const size_t lds = (size_t)L * 1024 * sizeof(float4) + (size_t)m_lds * sizeof(int);
   static bool attr_set = false;

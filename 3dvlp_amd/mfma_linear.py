@@ -12,8 +12,8 @@ from . import _lib as _ext
 
 _ext.load()
 
-_ROWS_PER_BLOCK = int(__import__('os').environ.get('VLP3D_LIN_RPB', 64))
-WGRAD_BLOCKS = 256
+_ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
+WGRAD_BLOCKS = 256     # at most this many workgroups (= partial [dW | db] slabs)
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256)
 
