@@ -1,0 +1,73 @@
+"""out = LayerNorm(x + dropout(y)) — the add & norm closing every attention / FFN block
+(models/transformer/attention.py:128-130, mmattention.py:84-86) — on the fused HIP kernels of csrc/add_norm.hip.
+
+The dropout mask is a counter-based hash of (seed word, call id, element index) recomputed in backward, never stored.
+`seed` is one int64 in device memory per device: `advance(device)` adds 1 (the step driver does that once per step,
+inside the replayed graph, so replays draw fresh masks); `call_id` is a process-wide counter that distinguishes call
+sites (baked into a captured graph, ever increasing in eager mode).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as _ext
+
+_ext.load()
+
+_STATE = {}
+_CALLS = [0]
+_DIMS = (64, 128, 256)
+
+
+def state(device):
+    """The device's dropout seed word (created from torch's default generator, so torch.manual_seed controls it)."""
+    key = torch.device(device)
+    if key.index is None:
+        key = torch.device(key.type, torch.cuda.current_device())
+    if key not in _STATE:
+        _STATE[key] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(key)
+    return _STATE[key]
+
+
+def advance(device):
+    state(device).add_(1)
+
+
+def supported(x, y, norm):
+    D = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape and D in _DIMS
+            and tuple(norm.normalized_shape) == (D,) and norm.elementwise_affine and norm.bias is not None
+            and x.numel() < 2 ** 32)
+
+
+class _AddNorm(Function):
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, p, eps, call_id, seed, mask):
+        D = x.shape[-1]
+        x2, y2 = x.reshape(-1, D).contiguous(), y.reshape(-1, D).contiguous()
+        R = x2.shape[0]
+        out, xhat = torch.empty_like(x2), torch.empty_like(x2)
+        rstd = torch.empty((R,), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_add_norm_fwd", x2, y2, gamma.contiguous(), beta.contiguous(), R, D, float(p), seed, call_id,
+                  float(eps), out, xhat, rstd, mask)
+        ctx.save_for_backward(xhat, rstd, gamma, seed)
+        ctx.cfg = (R, D, float(p), call_id, x.shape)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, gamma, seed = ctx.saved_tensors
+        R, D, p, call_id, shape = ctx.cfg
+        d2 = dout.reshape(R, D).contiguous()
+        dx, dy = torch.empty_like(d2), torch.empty_like(d2)
+        nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
+        part = torch.empty((nblk, 2, D), dtype=torch.float32, device=dout.device)
+        dgb = torch.empty((2, D), dtype=torch.float32, device=dout.device)
+        _ext.call("vlp3d_add_norm_bwd", d2, xhat, rstd, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part, dgb)
+        return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None, None, None
+
+
+def add_norm(x, y, norm, p=0.0, training=True, mask_out=None):
+    """LayerNorm `norm` of x + dropout_p(y).  mask_out: optional uint8 tensor like x receiving the keep mask (tests)."""
+    p = float(p) if training else 0.0
+    _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
+    return _AddNorm.apply(x, y, norm.weight, norm.bias, p, norm.eps, _CALLS[0], state(x.device), mask_out)

@@ -1,0 +1,209 @@
+// out = LayerNorm(x + dropout(y)) — the "add & norm" that closes every attention / FFN block of the reference
+// (models/transformer/attention.py:128-130 `self.layer_norm(queries + self.dropout(out))`, mmattention.py:84-86
+// `self.norm(self.dropout(self.ffn(x)) + x)`) — as ONE kernel forward and one (+ a tiny slab sum) backward, instead
+// of dropout / add / layer-norm forward and five-six launches in autograd's backward.
+//
+// One wave per row (D = 64*EPL columns, EPL consecutive columns per lane -> coalesced 8/16-byte accesses), row
+// statistics by DPP-free shuffles in fp32.  The dropout mask is never stored: it is a counter-based hash of
+// (seed, call id, element index), recomputed bit-for-bit in the backward kernel.  `seed` lives in device memory
+// (one 64-bit word the step driver advances once per step, inside the replayed graph), `call_id` distinguishes the
+// call sites of a step.  Kept for backward: xhat (the normalised rows) and rstd.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned pcg_hash(unsigned x) {
+  x = x * 747796405u + 2891336453u;
+  const unsigned w = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+
+// keep-probability test of element `e` of call `call_id` under `seed`; 24 random bits against the threshold
+__device__ __forceinline__ bool keep_element(unsigned seed_mix, unsigned e, unsigned thresh24) {
+  return (pcg_hash(e ^ seed_mix) >> 8) >= thresh24;
+}
+
+__device__ __forceinline__ unsigned seed_mix_of(const unsigned long long *__restrict__ seed, int call_id) {
+  const unsigned long long s = *seed;
+  return pcg_hash((unsigned)s ^ pcg_hash((unsigned)(s >> 32) + 0x9E3779B9u * (unsigned)(call_id + 1)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, long long R, float p,
+                                                           const unsigned long long *__restrict__ seed, int call_id,
+                                                           float eps, float *__restrict__ out,
+                                                           float *__restrict__ xhat, float *__restrict__ rstd,
+                                                           unsigned char *__restrict__ mask) {
+  constexpr int D = 64 * EPL;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int c0 = lane * EPL;
+  const unsigned thresh = (unsigned)(p * 16777216.0f);
+  const unsigned mix = p > 0.f ? seed_mix_of(seed, call_id) : 0u;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float r[EPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const long long e = row * D + c0 + i;
+    float yv = y[e];
+    if (p > 0.f) {
+      const bool keep = keep_element(mix, (unsigned)e, thresh);
+      yv = keep ? yv * inv_keep : 0.f;
+      if (mask) mask[e] = keep ? 1 : 0;
+    }
+    r[i] = x[e] + yv;
+    s += r[i];
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const float d = r[i] - mean;
+    q += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const long long e = row * D + c0 + i;
+    const float h = (r[i] - mean) * rs;
+    xhat[e] = h;
+    out[e] = h * gamma[c0 + i] + beta[c0 + i];
+  }
+  if (lane == 0) rstd[row] = rs;
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * gamma;   dy = dx * mask / (1 - p);
+// per-workgroup partial sums of dgamma = sum_rows dout * xhat and dbeta = sum_rows dout go to slab [blockIdx][2][D].
+template <int EPL>
+__global__ __launch_bounds__(256) void add_norm_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ xhat,
+                                                           const float *__restrict__ rstd,
+                                                           const float *__restrict__ gamma, long long R, float p,
+                                                           const unsigned long long *__restrict__ seed, int call_id,
+                                                           int rows_per_wave, float *__restrict__ dx,
+                                                           float *__restrict__ dy, float *__restrict__ partials) {
+  constexpr int D = 64 * EPL;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * EPL;
+  const unsigned thresh = (unsigned)(p * 16777216.0f);
+  const unsigned mix = p > 0.f ? seed_mix_of(seed, call_id) : 0u;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float gm[EPL], dg[EPL], db[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    gm[i] = gamma[c0 + i];
+    dg[i] = db[i] = 0.f;
+  }
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int k = 0; k < rows_per_wave; ++k) {
+    const long long row = row0 + k;
+    if (row >= R) break;
+    float g[EPL], h[EPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const long long e = row * D + c0 + i;
+      const float d = dout[e];
+      h[i] = xhat[e];
+      g[i] = d * gm[i];
+      dg[i] += d * h[i];
+      db[i] += d;
+      s1 += g[i];
+      s2 += g[i] * h[i];
+    }
+    const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+    const float rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const long long e = row * D + c0 + i;
+      const float v = rs * (g[i] - m1 - h[i] * m2);
+      dx[e] = v;
+      float w = v;
+      if (p > 0.f) w = keep_element(mix, (unsigned)e, thresh) ? v * inv_keep : 0.f;
+      dy[e] = w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    red[wave][0][c0 + i] = dg[i];
+    red[wave][1][c0 + i] = db[i];
+  }
+  __syncthreads();
+  float *slab = partials + (long long)blockIdx.x * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int which = i / D, c = i - which * D;
+    slab[i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
+// out[i] = sum_b partials[b][i]
+__global__ __launch_bounds__(256) void add_norm_slab_sum_kernel(const float *__restrict__ partials, int nblk, int n,
+                                                                float *__restrict__ out) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (i < n)
+    for (int b = grp; b < nblk; b += 4) s += partials[(long long)b * n + i];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+}  // namespace
+
+extern "C" int vlp3d_add_norm_blocks(long long R) {  // workgroups (= partial slabs) of the backward kernel
+  const long long waves = (R + 15) / 16;             // 16 rows per wave
+  long long blocks = (waves + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+extern "C" int vlp3d_add_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R,
+                                  int D, float p, const unsigned long long *seed, int call_id, float eps, float *out,
+                                  float *xhat, float *rstd, unsigned char *mask, void *stream) {
+  if (!x || !y || !gamma || !beta || !out || !xhat || !rstd || R < 1 || p < 0.f || p >= 1.f || (p > 0.f && !seed) ||
+      R * (long long)D >= (1ll << 32))
+    return VLP3D_EINVAL;
+  const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 64: hipLaunchKernelGGL(add_norm_fwd_kernel<1>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
+    case 128: hipLaunchKernelGGL(add_norm_fwd_kernel<2>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
+    case 256: hipLaunchKernelGGL(add_norm_fwd_kernel<4>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
+    default: return VLP3D_EINVAL;
+  }
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const float *rstd, const float *gamma,
+                                  long long R, int D, float p, const unsigned long long *seed, int call_id, float *dx,
+                                  float *dy, float *partials, float *dgamma_dbeta, void *stream) {
+  if (!dout || !xhat || !rstd || !gamma || !dx || !dy || !partials || !dgamma_dbeta || R < 1 || p < 0.f || p >= 1.f ||
+      (p > 0.f && !seed) || R * (long long)D >= (1ll << 32))
+    return VLP3D_EINVAL;
+  const int nblk = vlp3d_add_norm_blocks(R);
+  const dim3 grid((unsigned)nblk), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 64: hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
+    case 128: hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
+    case 256: hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
+    default: return VLP3D_EINVAL;
+  }
+  hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
+                     dgamma_dbeta);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import synth
+from . import add_norm, synth
 from .ddp import FlatGradBucket
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
 from .grounding import ContrastModule, MatchModule
@@ -174,6 +174,8 @@ class GroundingStep:
                 m.mlp_dtype = sa_dtype
             if hasattr(m, "bf16_mma"):  # fused attention cores follow the same switch
                 m.bf16_mma = sa_dtype == torch.bfloat16
+            if hasattr(m, "fused_norm"):  # dropout + residual + LayerNorm kernels; their seed word advances per step
+                m.fused_norm = True
         self.use_graph = use_graph
         # geometry pipeline: the backbone's coordinate-only stage (FPS / ball query / three_nn) of the NEXT batch
         # runs on a side stream while the dense layers of the current batch run (one workgroup per scene = 8 CUs)
@@ -223,6 +225,7 @@ class GroundingStep:
         loss, _ = self.forward_loss(batch, geometry)
         loss.backward()
         self.bucket.collect()
+        add_norm.advance(self.device)  # fresh dropout masks next step (also when this is a captured graph)
         if self.pipeline:
             torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()
@@ -260,6 +263,7 @@ class GroundingStep:
             loss, _ = self.forward_loss(self._static_batch, self._geom_cur)
             loss.backward()
             self.bucket.collect()
+            add_norm.advance(self.device)
             self._static_loss = loss.detach()
         self._graph = self._gM
 

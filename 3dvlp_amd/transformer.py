@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import fused_attention
+from . import add_norm, fused_attention
 from .mfma_linear import linear as _linear
 
 DEFAULT_IMPL = "hip"
@@ -76,6 +76,8 @@ class MultiHeadAttention(nn.Module):
         self.attention = ScaledDotProductAttention(d_model=d_model, d_k=d_k, d_v=d_v, h=h, impl=impl)
         self.dropout = nn.Dropout(p=dropout)
         self.layer_norm = nn.LayerNorm(d_model)
+        self.fused_norm = False  # True: dropout + residual + LayerNorm in one HIP kernel (add_norm.py); the owner of
+        # the training loop must then call add_norm.advance(device) once per step (GroundingStep does)
 
     def forward(self, queries, keys, values, attention_mask=None, attention_weights=None, way="add",
                 output_attn=False):
@@ -87,7 +89,10 @@ class MultiHeadAttention(nn.Module):
         else:
             out, att = self.attention(queries, keys, values, attention_mask, attention_weights, way,
                                       need_att=output_attn)
-            out = self.layer_norm(queries + self.dropout(out))
+            if self.fused_norm and add_norm.supported(queries, out, self.layer_norm):
+                out = add_norm.add_norm(queries, out, self.layer_norm, self.dropout.p, self.training)
+            else:
+                out = self.layer_norm(queries + self.dropout(out))
         return (out, att) if output_attn else out
 
 
@@ -116,8 +121,12 @@ class CrossAttentionDecoderLayer(nn.Module):
         self.norm = nn.LayerNorm(hidden_size)
         self.dropout = nn.Dropout(p=drop_prob)
         self.head = head
+        self.fused_norm = False  # see MultiHeadAttention.fused_norm
 
     def forward(self, query, key, value, src_mask=None, src_trg_mask=None):
         x = self.self_attention(query, query, query, attention_mask=src_mask)
         x = self.enc_dec_attention(x, key, value, attention_mask=src_trg_mask)
-        return self.norm(self.dropout(self.ffn(x)) + x)
+        f = self.ffn(x)
+        if self.fused_norm and add_norm.supported(x, f, self.norm):
+            return add_norm.add_norm(x, f, self.norm, self.dropout.p, self.training)
+        return self.norm(self.dropout(f) + x)

@@ -194,6 +194,22 @@ int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int 
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, void *stream);
 
+/* ---- add & norm of the attention / FFN blocks (csrc/add_norm.hip) ------------------------------------------
+ * out = LayerNorm(x + dropout(y)) as in models/transformer/attention.py:128-130 and mmattention.py:84-86, one
+ * kernel forward, one + a slab sum backward.  x, y, out, xhat: (R, D) f32, D in {64,128,256}; rstd: (R).
+ * p = dropout probability (0: none / eval).  The mask is a counter-based hash of (*seed, call_id, element index),
+ * recomputed in backward: pass the same seed word and call_id to both; advance *seed between steps.
+ * mask (R,D) u8 or NULL: optional copy of the keep mask (tests).
+ * bwd: dx = d(out)/d(x), dy = dx * mask/(1-p); dgamma_dbeta (2,D) = [sum dout*xhat | sum dout];
+ * partials: vlp3d_add_norm_blocks(R) * 2 * D floats of scratch. */
+int vlp3d_add_norm_blocks(long long R);
+int vlp3d_add_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R, int D,
+                       float p, const unsigned long long *seed, int call_id, float eps, float *out, float *xhat,
+                       float *rstd, unsigned char *mask, void *stream);
+int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const float *rstd, const float *gamma, long long R, int D,
+                       float p, const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
+                       float *dgamma_dbeta, void *stream);
+
 /* ---- box decode of the proposal module (csrc/box_decode.hip) ------------------------------------------------
  * Replaces decode_pred_box (models/proposal_module/proposal_module_fcos.py:94-144) + get_3d_box_batch
  * (utils/box_util.py:361-385) for n = B*num_proposal proposals, NH heading bins:

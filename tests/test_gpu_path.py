@@ -368,3 +368,39 @@ def test_box_decode_fused_equals_op_sequence(NH):
                     [d[k].grad for k in ("aggregated_vote_xyz", "heading_residuals", "rois")]))
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
         torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,D,p", [(2048, 128, 0.1), (16384, 128, 0.1), (70, 64, 0.5), (33, 256, 0.0)])
+def test_add_norm_fused_equals_torch_with_same_mask(R, D, p):
+    """csrc/add_norm.hip vs LayerNorm(x + y*mask/(1-p)) evaluated by torch with the kernel's own keep mask: outputs and
+    all four gradients; the backward kernel must regenerate exactly that mask; advancing the seed redraws it."""
+    an = importlib.import_module("3dvlp_amd.add_norm")
+    torch.manual_seed(R + D)
+    norm = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(R // 1 if R < 100 else R // 32, 1 if R < 100 else 32, D, device="cuda", requires_grad=True)
+    y = torch.randn_like(x, requires_grad=True)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+    out = an.add_norm(x, y, norm, p, True, mask_out=mask)
+    go = torch.randn_like(out)
+    got = torch.autograd.grad(out, [x, y, norm.weight, norm.bias], go)
+    keep = mask.double() if p > 0 else torch.ones_like(x, dtype=torch.double)
+    xd, yd = x.detach().double().requires_grad_(True), y.detach().double().requires_grad_(True)
+    wd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd + yd * keep / (1.0 - p), (D,), wd, bd, norm.eps)
+    exp = torch.autograd.grad(ref, [xd, yd, wd, bd], go.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    for a, e in zip(got, exp):
+        assert (a.double() - e).abs().max().item() < 1e-4 * e.abs().max().item() + 1e-5
+    if p > 0:
+        frac = mask.float().mean().item()
+        assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / mask.numel()) ** 0.5 + 1e-3  # Bernoulli(1-p) keep rate
+        m2 = torch.empty_like(mask)
+        an.add_norm(x, y, norm, p, True, mask_out=m2)      # another call id: another mask
+        assert not torch.equal(mask, m2)
+    # eval mode: no dropout at all
+    ev = an.add_norm(x, y, norm, p, False)
+    torch.testing.assert_close(ev, torch.nn.functional.layer_norm(x + y, (D,), norm.weight, norm.bias, norm.eps),
+                               rtol=1e-5, atol=1e-5)
