@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as _ext
 from .mfma_linear import linear as _linear
 from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
 
@@ -125,6 +126,38 @@ class NCELoss(nn.Module):
         self.clamp = clamp
 
 
+class _ContrastCore(torch.autograd.Function):
+    """Fused OCC/OSC core (csrc/contrast.hip): normalised (text, box, boxi) + boxes -> (lang_con_loss, iou_con_loss)."""
+
+    @staticmethod
+    def forward(ctx, text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num):
+        text, box, boxi = text.contiguous().float(), box.contiguous().float(), boxi.contiguous().float()
+        cf = lambda t: t.contiguous().float()
+        obj, gt_center, gt_size, pred_center, pred_size = cf(obj), cf(gt_center), cf(gt_size), cf(pred_center), cf(pred_size)
+        lang_num = lang_num.contiguous().to(torch.int64)
+        B, L, D = text.shape
+        K = box.shape[1]
+        out = torch.empty((2,), dtype=torch.float32, device=text.device)
+        lse = torch.empty((B, L + K), dtype=torch.float32, device=text.device)
+        _ext.call("vlp3d_contrast_fwd", text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num,
+                  B, L, K, D, out, lse)
+        ctx.save_for_backward(text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num, lse)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_occ, g_osc):
+        text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num, lse = ctx.saved_tensors
+        B, L, D = text.shape
+        K = box.shape[1]
+        dev = text.device
+        dS = torch.empty((B, L + K, K), dtype=torch.float32, device=dev)
+        dtext, dbox, dboxi = torch.empty_like(text), torch.empty_like(box), torch.empty_like(boxi)
+        opt = lambda g: None if g is None else g.contiguous().float()
+        _ext.call("vlp3d_contrast_bwd", text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num,
+                  B, L, K, D, lse, opt(g_occ), opt(g_osc), dS, dtext, dbox, dboxi)
+        return dtext, dbox, dboxi, None, None, None, None, None, None
+
+
 class ContrastModule(nn.Module):
     """OCC (sentence vs proposals) and OSC (proposal vs proposal) InfoNCE, all (scene, sentence) pairs
     at once instead of the reference's Python double loop with host syncs.
@@ -146,6 +179,7 @@ class ContrastModule(nn.Module):
         self.bce_loss = nn.BCEWithLogitsLoss()
         self.pc_proj_iou = nn.Sequential(nn.Linear(hidden, hidden, bias=False))
         self._mean_size = None  # device copy of config.mean_size_arr (not a parameter/buffer: keeps the state_dict)
+        self.fused = True  # csrc/contrast.hip on CUDA tensors; False = the batched op-by-op form below (host tests)
 
     def forward(self, data_dict):
         if data_dict["epoch"] < 50:
@@ -163,6 +197,14 @@ class ContrastModule(nn.Module):
         gt_size = mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
         lang_emb = data_dict["lang_emb"].view(B, -1, data_dict["lang_emb"].shape[-1])[:, :L]
         obj = data_dict["objectness_scores"].max(2)[1].float()  # (B,K) 1 = takes part
+        if self.fused and features.is_cuda and K <= 1024 and L <= 64 and features.shape[-1] % 4 == 0:
+            # three launches (csrc/contrast.hip) instead of ~45 + ~45 in autograd's backward
+            text = F.normalize(_linear(lang_emb.contiguous(), self.text_proj.weight), dim=-1)
+            box = F.normalize(_linear(features, self.pc_proj.weight), dim=-1)
+            boxi = F.normalize(_linear(features, self.pc_proj_iou[0].weight), dim=-1)
+            data_dict["lang_con_loss"], data_dict["iou_con_loss"] = _ContrastCore.apply(
+                text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, data_dict["lang_num"])
+            return data_dict
         P = obj.sum(1)  # (B,) proposals taking part
         lang_ok = (torch.arange(L, device=features.device)[None, :] < data_dict["lang_num"][:, None]).float()
         lang_ok = lang_ok * (P > 0).float()[:, None]  # the reference's try/except skips empty scenes

@@ -194,6 +194,22 @@ int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int 
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, void *stream);
 
+/* ---- OCC / OSC InfoNCE of the contrast module (csrc/contrast.hip) ------------------------------------------
+ * Core of models/constrast_module/constrast_module.py:53-131 for all (scene, sentence) pairs at once.
+ * text (B,L,D), box (B,K,D), boxi (B,K,D): L2-normalised text_proj / pc_proj / pc_proj_iou outputs; obj (B,K) f32 in
+ * {0,1} (objectness argmax); gt_center, gt_size (B,L,3) (size grown by 1e-2 inside, as the reference does);
+ * pred_center, pred_size (B,K,3); lang_num (B) int64.  K <= 1024, L <= 64, D % 4 == 0.
+ * fwd -> out2 = [lang_con_loss (OCC), iou_con_loss (OSC)], lse (B, L+K) (kept for backward).
+ * bwd: g_occ / g_osc = device scalars d(loss)/d(out2[0]) / d(out2[1]) (NULL = 0) -> dtext (B,L,D), dbox (B,K,D),
+ * dboxi (B,K,D), all fully written; dS (B, L+K, K) f32 scratch. */
+int vlp3d_contrast_fwd(const float *text, const float *box, const float *boxi, const float *obj,
+                       const float *gt_center, const float *gt_size, const float *pred_center, const float *pred_size,
+                       const long long *lang_num, int B, int L, int K, int D, float *out2, float *lse, void *stream);
+int vlp3d_contrast_bwd(const float *text, const float *box, const float *boxi, const float *obj,
+                       const float *gt_center, const float *gt_size, const float *pred_center, const float *pred_size,
+                       const long long *lang_num, int B, int L, int K, int D, const float *lse, const float *g_occ,
+                       const float *g_osc, float *dS, float *dtext, float *dbox, float *dboxi, void *stream);
+
 /* ---- add & norm of the attention / FFN blocks (csrc/add_norm.hip) ------------------------------------------
  * out = LayerNorm(x + dropout(y)) as in models/transformer/attention.py:128-130 and mmattention.py:84-86, one
  * kernel forward, one + a slab sum backward.  x, y, out, xhat: (R, D) f32, D in {64,128,256}; rstd: (R).

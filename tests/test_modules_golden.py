@@ -184,6 +184,48 @@ def test_contrast_module_matches_oracle_loop():
     assert float(d0["con_loss"]) == 0.0  # no-op before epoch 50 (constrast_module.py:54-56)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,L,seed", [(3, 40, 4, 3), (8, 256, 8, 11), (2, 300, 5, 12)])
+def test_contrast_fused_kernel_equals_batched_ops(B, K, L, seed):
+    """csrc/contrast.hip (3 launches) vs the batched op-by-op ContrastModule (itself tested against the oracle's
+    literal loop above): both losses and the gradients of the three projection weights and of the features."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    gr = importlib.import_module("3dvlp_amd.grounding")
+    rng = np.random.default_rng(seed)
+    cfg = gs.GroundingNet(use_con=False).dataset_config
+    torch.manual_seed(seed)
+    cm = gr.ContrastModule(cfg).cuda()
+    pred_center = rng.uniform(0, 3, (B, K, 3)).astype(np.float32)
+    pred_size = rng.uniform(0.4, 1.5, (B, K, 3)).astype(np.float32)
+    ref_center = pred_center[:, :L] + rng.normal(0, 0.1, (B, L, 3)).astype(np.float32)
+    size_class = rng.integers(0, 18, (B, L))
+    size_res = (pred_size[:, :L] - cfg.mean_size_arr[size_class]).astype(np.float32)
+    obj = rng.normal(size=(B, K, 2)).astype(np.float32)
+    obj[B - 1, :, 1] = -10  # a scene without any positive proposal is skipped
+    lang_num = rng.integers(1, L + 1, (B,))
+    lang_num[0] = L
+    base = {"epoch": 50, "pred_center": pred_center, "pred_size": pred_size, "objectness_scores": obj,
+            "ref_center_label_list": ref_center, "ref_size_class_label_list": size_class,
+            "ref_size_residual_label_list": size_res, "lang_emb": rng.normal(size=(B * L, 128)).astype(np.float32),
+            "lang_num": lang_num}
+    feat = rng.normal(size=(B, K, 128)).astype(np.float32)
+    res = []
+    for fused in (False, True):
+        cm.fused = fused
+        cm.zero_grad()
+        d = {k: (torch.from_numpy(np.asarray(v)).cuda() if not isinstance(v, int) else v) for k, v in base.items()}
+        f = torch.from_numpy(feat).cuda().requires_grad_(True)
+        d["bbox_feature"] = f
+        d = cm(d)
+        (1.3 * d["lang_con_loss"] + 0.7 * d["iou_con_loss"]).backward()
+        res.append([d["lang_con_loss"].detach(), d["iou_con_loss"].detach(), f.grad.clone(),
+                    cm.pc_proj.weight.grad.clone(), cm.text_proj.weight.grad.clone(),
+                    cm.pc_proj_iou[0].weight.grad.clone()])
+    assert float(res[0][0]) > 0 and float(res[0][1]) > 0
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item() + 1e-6
+
+
 def test_copy_paste_device_formulation_equals_reference_loop():
     """MatchModule._copy_paste (fixed-shape gather, no host sync) == the reference's host loop
     (models/refnet/match_module.py:97-121) restated literally."""
