@@ -47,6 +47,8 @@ SIGNATURES = {
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_sa_pool_tstats": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "vlp3d_sa_prep_weights": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "vlp3d_grounding_loss_fwd": [_vp] * 11 + [_i] * 6 + [_f] * 7 + [_vp, _vp, _vp],
+    "vlp3d_grounding_loss_bwd": [_vp] * 11 + [_i] * 6 + [_f] * 7 + [_vp] * 6 + [_vp],
     "vlp3d_contrast_fwd": [_vp] * 9 + [_i] * 4 + [_vp, _vp, _vp],
     "vlp3d_contrast_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 7 + [_vp],
     "vlp3d_add_norm_blocks": [ctypes.c_longlong],

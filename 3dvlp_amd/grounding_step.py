@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as _ext
 from . import add_norm, synth
 from .ddp import FlatGradBucket
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
@@ -96,7 +97,60 @@ def compute_objectness_loss(d):
     return torch.sum(ce * mask) / (torch.sum(mask) + 1e-6), label, mask, ind1
 
 
+class _LossCore(torch.autograd.Function):
+    """Fused vote + objectness + centre + reference loss (csrc/grounding_loss.hip): one forward kernel (+ finalize)
+    and one backward kernel.  Returns out5 = [vote, objectness, centre, reference, weighted total]; only the total
+    carries gradient (to vote_xyz, objectness_scores, pred_center, cluster_ref)."""
+    CONSTS = (NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS[0], OBJECTNESS_CLS_WEIGHTS[1], 0.15, 0.1, 0.3)
+
+    @staticmethod
+    def forward(ctx, vote_xyz, obj_scores, pred_center, cluster_ref, seed_xyz, seed_inds, vote_label, vote_mask,
+                agg_xyz, center_label, ref_center):
+        cf = lambda t: t.contiguous().float()
+        vote_xyz, obj_scores, pred_center, cluster_ref = cf(vote_xyz), cf(obj_scores), cf(pred_center), cf(cluster_ref)
+        seed_xyz, vote_label, vote_mask, agg_xyz = cf(seed_xyz), cf(vote_label), cf(vote_mask), cf(agg_xyz)
+        center_label, ref_center = cf(center_label), cf(ref_center)
+        seed_inds = seed_inds.contiguous().int()
+        B, S = seed_inds.shape
+        N, K, G, L = vote_mask.shape[1], agg_xyz.shape[1], center_label.shape[1], ref_center.shape[1]
+        sums = torch.empty((7,), dtype=torch.float64, device=vote_xyz.device)
+        out = torch.empty((5,), dtype=torch.float32, device=vote_xyz.device)
+        args = (vote_xyz, seed_xyz, seed_inds, vote_label, vote_mask, agg_xyz, center_label, obj_scores, pred_center,
+                cluster_ref, ref_center, B, S, N, K, G, L, *_LossCore.CONSTS)
+        _ext.call("vlp3d_grounding_loss_fwd", *args, sums, out)
+        ctx.save_for_backward(vote_xyz, seed_xyz, seed_inds, vote_label, vote_mask, agg_xyz, center_label, obj_scores,
+                              pred_center, cluster_ref, ref_center, sums)
+        ctx.dims = (B, S, N, K, G, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sv = ctx.saved_tensors
+        sums = sv[11]
+        vote_xyz, obj_scores, pred_center, cluster_ref = sv[0], sv[7], sv[8], sv[9]
+        g = gout[4:5].contiguous()  # only the total is differentiable (the components are reporting values)
+        d_vote, d_obj = torch.empty_like(vote_xyz), torch.empty_like(obj_scores)
+        d_center, d_ref = torch.empty_like(pred_center), torch.empty_like(cluster_ref)
+        _ext.call("vlp3d_grounding_loss_bwd", *sv[:11], *ctx.dims, *_LossCore.CONSTS, sums, g, d_vote, d_obj, d_center,
+                  d_ref)
+        return d_vote, d_obj, d_center, d_ref, None, None, None, None, None, None, None
+
+
+FUSED_LOSS = True  # csrc/grounding_loss.hip on CUDA tensors; False = the op-by-op form below (host tests)
+
+
 def grounding_loss(d, mean_size_arr):
+    if FUSED_LOSS and d["vote_xyz"].is_cuda and d["vote_xyz"].shape[1] == d["seed_xyz"].shape[1]:
+        out = _LossCore.apply(d["vote_xyz"], d["objectness_scores"], d["pred_center"], d["cluster_ref"], d["seed_xyz"],
+                              d["seed_inds"], d["vote_label"], d["vote_label_mask"], d["aggregated_vote_xyz"],
+                              d["center_label"][:, :, 0:3], d["ref_center_label_list"][..., 0:3])
+        loss = out[4]
+        if "lang_con_loss" in d:
+            loss = loss + 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]  # loss_joint.py:208
+        comp = out.detach()
+        d["vote_loss"], d["objectness_loss"], d["center_loss"], d["ref_loss"] = comp[0], comp[1], comp[2], comp[3]
+        d["loss"] = loss
+        return loss
     vote_loss = compute_vote_loss(d)
     obj_loss, obj_label, _, assign = compute_objectness_loss(d)
     B, K = obj_label.shape

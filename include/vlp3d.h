@@ -194,6 +194,30 @@ int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int 
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, void *stream);
 
+/* ---- reduced detection + reference loss of the grounding step (csrc/grounding_loss.hip) --------------------
+ * vote loss and objectness loss as lib/loss_helper/loss_detection.py:24-110 (both on the nearest-neighbour
+ * distances of utils/nn_distance.py), Huber(huber_delta) centre regression of the near proposals against their
+ * assigned GT centre, cross-entropy of cluster_ref (B*L,K) against the proposal nearest to ref_center (B,L,3).
+ * vote_xyz, seed_xyz (B,S,3); seed_inds (B,S) i32 into the N input points; vote_label (B,N,9), vote_mask (B,N) f32;
+ * agg_xyz (B,K,3); center_label (B,G,3); obj_scores (B,K,2); pred_center (B,K,3).
+ * fwd -> out5 = [vote, objectness, centre, reference, vote + w_obj*objectness + centre + w_ref*reference];
+ *        sums: 7 doubles (numerators / denominators), kept for backward.
+ * bwd: gout = device scalar d/d(out5[4]) (NULL = 1) -> d_vote (B,S,3), d_obj (B,K,2), d_center (B,K,3),
+ *      d_ref (B*L,K), all fully written. */
+int vlp3d_grounding_loss_fwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds, const float *vote_label,
+                             const float *vote_mask, const float *agg_xyz, const float *center_label,
+                             const float *obj_scores, const float *pred_center, const float *cluster_ref,
+                             const float *ref_center, int B, int S, int N, int K, int G, int L, float near_thr,
+                             float far_thr, float w0, float w1, float huber_delta, float w_obj, float w_ref, double *sums,
+                             float *out5, void *stream);
+int vlp3d_grounding_loss_bwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds, const float *vote_label,
+                             const float *vote_mask, const float *agg_xyz, const float *center_label,
+                             const float *obj_scores, const float *pred_center, const float *cluster_ref,
+                             const float *ref_center, int B, int S, int N, int K, int G, int L, float near_thr,
+                             float far_thr, float w0, float w1, float huber_delta, float w_obj, float w_ref,
+                             const double *sums, const float *gout, float *d_vote, float *d_obj, float *d_center,
+                             float *d_ref, void *stream);
+
 /* ---- OCC / OSC InfoNCE of the contrast module (csrc/contrast.hip) ------------------------------------------
  * Core of models/constrast_module/constrast_module.py:53-131 for all (scene, sentence) pairs at once.
  * text (B,L,D), box (B,K,D), boxi (B,K,D): L2-normalised text_proj / pc_proj / pc_proj_iou outputs; obj (B,K) f32 in

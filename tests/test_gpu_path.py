@@ -404,3 +404,39 @@ def test_add_norm_fused_equals_torch_with_same_mask(R, D, p):
     ev = an.add_norm(x, y, norm, p, False)
     torch.testing.assert_close(ev, torch.nn.functional.layer_norm(x + y, (D,), norm.weight, norm.bias, norm.eps),
                                rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,S,N,K,G,L", [(3, 64, 500, 40, 16, 4), (8, 1024, 40000, 256, 128, 8)])
+def test_grounding_loss_fused_equals_op_sequence(B, S, N, K, G, L):
+    """csrc/grounding_loss.hip vs the op-by-op reduced loss (nn_distance + torch ops): the four components, the total,
+    and the gradients w.r.t. vote_xyz, objectness_scores, pred_center and cluster_ref."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + K)
+    r = lambda *sh: torch.rand(*sh, generator=g)
+    centers = r(B, G, 3) * 4
+    agg = centers[:, torch.randint(0, G, (K,), generator=g)] + (r(B, K, 3) - 0.5) * 1.6  # near, far and in between
+    seed_inds = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(B)]).int()
+    base = {"seed_xyz": r(B, S, 3) * 4, "seed_inds": seed_inds, "vote_label": (r(B, N, 9) - 0.5),
+            "vote_label_mask": (r(B, N) > 0.4).long(), "aggregated_vote_xyz": agg, "center_label": centers,
+            "ref_center_label_list": centers[:, :L].clone()}
+    diff = {"vote_xyz": base["seed_xyz"] + (r(B, S, 3) - 0.5), "objectness_scores": torch.randn(B, K, 2, generator=g),
+            "pred_center": agg + (r(B, K, 3) - 0.5) * 0.4, "cluster_ref": torch.randn(B * L, K, generator=g)}
+    res = []
+    for fused in (False, True):
+        gs.FUSED_LOSS = fused
+        try:
+            d = {k: v.clone().cuda() for k, v in base.items()}
+            for k, v in diff.items():
+                d[k] = v.clone().cuda().requires_grad_(True)
+            d["pred_size"] = torch.ones(B, K, 3, device="cuda")
+            loss = gs.grounding_loss(d, None)
+            loss.backward()
+            res.append([loss.detach()] + [d[k].grad.clone() for k in diff])
+            if fused:
+                comp = [float(d[k]) for k in ("vote_loss", "objectness_loss", "center_loss", "ref_loss")]
+        finally:
+            gs.FUSED_LOSS = True
+    assert all(c > 0 for c in comp)  # every component is exercised (near and far proposals, masked seeds)
+    assert abs(float(res[0][0]) - (comp[0] + 0.1 * comp[1] + comp[2] + 0.3 * comp[3])) < 1e-5 * float(res[0][0])
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item() + 1e-7
