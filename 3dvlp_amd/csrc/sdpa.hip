@@ -174,6 +174,122 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, bf16-MFMA form with the head's K and V shared through LDS: a workgroup = 4 waves = 128 queries of one
+// (b,h).  In the one-wave form every 32-query wave re-reads its head's K and V from L2 (PMC traffic 2.4x the
+// algorithmic bytes, 20 dependent loads per key tile).  Here K and V are converted to bf16 ONCE while staging:
+// K row-major [key][32 + 8] (a lane's MFMA operand = two ds_read_b128), V transposed [dim][nk + 4] (the operand of the
+// second product = four ds_read_b64 in the accumulator's row order) — six LDS reads per key tile, no conversions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                           const float *__restrict__ v, const float *__restrict__ bias,
+                                                           int bias_mode, const float *__restrict__ mask, int H, int nq,
+                                                           int nk, int nkp, float scale, float *__restrict__ out,
+                                                           float *__restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) short sm_kv[];
+  constexpr int KS = D + 8;        // K row stride (shorts): 80 B -> conflict-free b128 phases
+  const int VS = nkp + 4;          // V^T row stride (shorts): (nkp/2 + 2) dwords -> conflict-free b64 phases
+  short *sK = sm_kv;               // [nkp][KS]
+  short *sV = sm_kv + nkp * KS;    // [D][VS]
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D;
+  // ---- stage K, V of head (b,h): rows beyond nk are zero (their scores are masked out below)
+  for (int c = threadIdx.x; c < nkp * (D / 4); c += 256) {
+    const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (key < nk) {
+      const long long off = ((long long)b * nk + key) * HD + h * D + d4;
+      kv = *reinterpret_cast<const float4 *>(k + off);
+      vv = *reinterpret_cast<const float4 *>(v + off);
+    }
+    short4 kb;
+    kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
+    *reinterpret_cast<short4 *>(sK + key * KS + d4) = kb;
+    sV[(d4 + 0) * VS + key] = bf16_bits(vv.x);
+    sV[(d4 + 1) * VS + key] = bf16_bits(vv.y);
+    sV[(d4 + 2) * VS + key] = bf16_bits(vv.z);
+    sV[(d4 + 3) * VS + key] = bf16_bits(vv.w);
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  if (q0 >= nq) return;  // whole wave (no barrier after this point)
+  const int qi = min(q0 + r, nq - 1);
+  const long long qrow = (long long)b * nq + qi;
+  float qreg[16];
+  load_half_row(q, qrow, HD, h, half, qreg);
+  bf16x8 qa[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qa[t][j] = bf16_bits(qreg[8 * t + j]);
+
+  f32x16 o = zero16();
+  float m = -__builtin_inff(), l = 0.f;
+  const long long bias_row = (((long long)b * H + h) * nq + qi) * nk;
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    f32x16 s = zero16();
+    const short *kr = sK + (k0 + r) * KS + 16 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(kr + 8 * t);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qa[t], s, 0, 0, 0);  // s[reg] = S[query r][key k0 + acc_row]
+    }
+    float tmax = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      float x = -__builtin_inff();
+      if (key < nk) {
+        x = apply_bias(s[i] * scale, bias_mode, bias, bias_row + key);
+        if (mask != nullptr && mask[(long long)b * nk + key] == 0.f) x = -10000.f;
+      }
+      s[i] = x;
+      tmax = fmaxf(tmax, x);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(s[i] - m_new);
+      s[i] = p;
+      psum += p;
+      o[i] *= alpha;
+    }
+    l = l * alpha + psum;
+    m = m_new;
+    // O^T[dim][query] += V^T[dim][key] * P^T[key][query]: K-step t sums over keys k0 + acc_row(8t + j, half), i.e. the
+    // two 4-key groups k0 + 16t + 4*half + {0..3} and + 8 + {0..3} of V^T row `r`
+    const short *vr = sV + r * VS + k0 + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 va, pb;
+      const short4 g0 = *reinterpret_cast<const short4 *>(vr + 16 * t);
+      const short4 g1 = *reinterpret_cast<const short4 *>(vr + 16 * t + 8);
+      va[0] = g0.x; va[1] = g0.y; va[2] = g0.z; va[3] = g0.w;
+      va[4] = g1.x; va[5] = g1.y; va[6] = g1.z; va[7] = g1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = bf16_bits(s[8 * t + j]);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o, 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32);
+  if (q0 + r < nq) {
+    const float inv = 1.f / l;
+    float *__restrict__ orow = out + qrow * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = dims 8g + 4*half + 0..3
+      float4 w;
+      w.x = o[4 * g + 0] * inv; w.y = o[4 * g + 1] * inv; w.z = o[4 * g + 2] * inv; w.w = o[4 * g + 3] * inv;
+      *reinterpret_cast<float4 *>(orow + 8 * g + 4 * half) = w;
+    }
+    if (half == 0) lse[((long long)b * H + h) * nq + q0 + r] = m + __logf(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward 1: wave = 32 queries; writes dQ, delta = rowsum(dO*O) and (optionally) dbias.
 // ---------------------------------------------------------------------------------------------
 template <bool BF>
@@ -358,7 +474,12 @@ extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, co
     return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   const dim3 grid(vlp3d_cdiv(nq, 32), H, B);
-  if (bf16_mma)
+  if (bf16_mma && nk <= 384) {  // K/V of a head shared by 4 waves through LDS (<= 55 KB)
+    const int nkp = (nk + 31) & ~31;
+    const size_t lds = ((size_t)nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
+    hipLaunchKernelGGL(sdpa_fwd_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, (hipStream_t)stream, q, k, v,
+                       bias, bias_mode, mask, H, nq, nk, nkp, scale, out, lse);
+  } else if (bf16_mma)
     hipLaunchKernelGGL(sdpa_fwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask, H,
                        nq, nk, scale, out, lse);
   else
