@@ -24,6 +24,10 @@ constexpr int O_W1 = 0, O_B1 = 128, O_G1 = 160, O_E1 = 192, O_W2 = 224, O_B2 = 1
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Keeps the weight reads of one output feature next to their use: without it the scheduler hoists all 1476 LDS
+// reads to the top and holds the weights in 450 VGPRs (one wave per SIMD, scratch spills).
+#define ROW_FENCE() asm volatile("" ::: "memory")
+
 // LayerNorm(32) of v (biased variance, eps 1e-5): n = (v-mean)*rstd ; returns rstd
 __device__ __forceinline__ float layer_norm32(const float (&v)[HID], float (&n)[HID]) {
   float mean = 0.f;
@@ -45,7 +49,7 @@ __device__ __forceinline__ float layer_norm32(const float (&v)[HID], float (&n)[
 struct Fwd {
   float x[4];
   unsigned m1, m2;  // relu masks of z1, z2
-  float n1[HID], n2[HID], h1[HID], h2[HID];
+  float n1[HID], n2[HID];  // h = n*gamma + beta is recomputed where needed (64 fewer live registers in backward)
   float rstd1, rstd2;
   float o[4];
 };
@@ -60,11 +64,13 @@ __device__ __forceinline__ void pair_input(const float *__restrict__ centre, int
   x[3] = sqrtf(s + x[2] * x[2]);
 }
 
+template <bool FENCE>
 __device__ __forceinline__ void mlp_forward(const float *__restrict__ P, Fwd &f) {
   float r[HID];
   f.m1 = 0u;
 #pragma unroll
   for (int i = 0; i < HID; ++i) {
+    if (FENCE && (i & 7) == 0) ROW_FENCE();
     float z = P[O_B1 + i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) z += P[O_W1 + i * 4 + k] * f.x[k];
@@ -72,32 +78,42 @@ __device__ __forceinline__ void mlp_forward(const float *__restrict__ P, Fwd &f)
     r[i] = fmaxf(z, 0.f);
   }
   f.rstd1 = layer_norm32(r, f.n1);
+  float h1[HID], h2[HID];
 #pragma unroll
-  for (int i = 0; i < HID; ++i) f.h1[i] = f.n1[i] * P[O_G1 + i] + P[O_E1 + i];
+  for (int i = 0; i < HID; ++i) h1[i] = f.n1[i] * P[O_G1 + i] + P[O_E1 + i];
   f.m2 = 0u;
 #pragma unroll
   for (int i = 0; i < HID; ++i) {
+    if (FENCE) ROW_FENCE();
     float z = P[O_B2 + i];
 #pragma unroll
-    for (int k = 0; k < HID; ++k) z += P[O_W2 + i * HID + k] * f.h1[k];
+    for (int k = 0; k < HID; ++k) z += P[O_W2 + i * HID + k] * h1[k];
     if (z > 0.f) f.m2 |= 1u << i;
     r[i] = fmaxf(z, 0.f);
   }
   f.rstd2 = layer_norm32(r, f.n2);
 #pragma unroll
-  for (int i = 0; i < HID; ++i) f.h2[i] = f.n2[i] * P[O_G2 + i] + P[O_E2 + i];
+  for (int i = 0; i < HID; ++i) h2[i] = f.n2[i] * P[O_G2 + i] + P[O_E2 + i];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    if (FENCE) ROW_FENCE();
     float z = P[O_B3 + c];
 #pragma unroll
-    for (int k = 0; k < HID; ++k) z += P[O_W3 + c * HID + k] * f.h2[k];
+    for (int k = 0; k < HID; ++k) z += P[O_W3 + c * HID + k] * h2[k];
     f.o[c] = z;
   }
 }
 
 __global__ __launch_bounds__(256) void relation_bias_fwd_kernel(const float *__restrict__ centre,
-                                                                const float *__restrict__ P, int B, int K,
+                                                                const float *__restrict__ Pg, int B, int K,
                                                                 float *__restrict__ out) {
+  // The 1476 weights are read through LDS (same address in every lane: broadcast ds_read_b128).  Reading them as
+  // wave-uniform scalars made the compiler load all of them up front and spill the SGPRs through VGPR lanes: 3100
+  // v_readlane/v_writelane per forward, one per multiply-add.
+  __shared__ __attribute__((aligned(16))) float sp[NPARAM];
+  for (int i = threadIdx.x; i < NPARAM; i += 256) sp[i] = Pg[i];
+  __syncthreads();
+  const float *P = sp;
   const long long total = (long long)B * K * K;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int j = (int)(t % K);
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(256) void relation_bias_fwd_kernel(const float *__r
     const int b = (int)(t / ((long long)K * K));
     Fwd f;
     pair_input(centre, b, i, j, K, f.x);
-    mlp_forward(P, f);
+    mlp_forward<true>(P, f);
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[(((long long)b * 4 + c) * K + i) * K + j] = f.o[c];
   }
@@ -148,10 +164,13 @@ __device__ __forceinline__ float column_sum(const float *__restrict__ A, int r, 
 }
 
 __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__restrict__ centre,
-                                                                const float *__restrict__ P,
+                                                                const float *__restrict__ Pg,
                                                                 const float *__restrict__ dout, int B, int K,
                                                                 float *__restrict__ slabs) {
   extern __shared__ float lds[];  // per wave: two [64][LDT] tiles
+  // Backward keeps ~250 values live per thread, so the weights stay wave-uniform SCALAR operands here (through LDS
+  // they would each need a VGPR: 4 KB of scratch per thread, 4x slower).
+  const float *__restrict__ P = Pg;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *TA = lds + wave * 2 * 64 * LDT;
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
     const int b = (int)(tc / ((long long)K * K));
     Fwd f;
     pair_input(centre, b, i, j, K, f.x);
-    mlp_forward(P, f);
+    mlp_forward<false>(P, f);
     float dO[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dO[c] = ok ? dout[(((long long)b * 4 + c) * K + i) * K + j] : 0.f;
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
 #pragma unroll
     for (int k = 0; k < HID; ++k) {
       TA[lane * LDT + k] = k < 4 ? dO[k] : 0.f;
-      TB[lane * LDT + k] = f.h2[k];
+      TB[lane * LDT + k] = f.n2[k] * P[O_G2 + k] + P[O_E2 + k];  // h2
       d[k] = P[O_W3 + k] * dO[0] + P[O_W3 + HID + k] * dO[1] + P[O_W3 + 2 * HID + k] * dO[2] +
              P[O_W3 + 3 * HID + k] * dO[3];
     }
@@ -205,16 +224,20 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
     for (int k = 0; k < HID; ++k) {
       dr[k] = ((f.m2 >> k) & 1u) ? dr[k] : 0.f;
       TA[lane * LDT + k] = dr[k];
-      TB[lane * LDT + k] = f.h1[k];
+      TB[lane * LDT + k] = f.n1[k] * P[O_G1 + k] + P[O_E1 + k];  // h1
     }
     accW2 = rank64_update(TA, TB, r, half, accW2);
     s_b2 += column_sum(TA, r, half);
+    // dh1[k] = sum_q W2[q][k] dz2[q]: rows of W2 in the outer loop — contiguous scalar loads (s_load_dwordx8) consumed
+    // at once.  The column-wise form (k outer) issued 1024 strided one-dword scalar loads whose results the compiler
+    // kept in SGPRs and spilled through VGPR lanes (5700 v_readlane/v_writelane, 256 VGPRs, one wave per SIMD).
+    // Same summation order per k (q ascending): bit-identical.
 #pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      float a = 0.f;
+    for (int k = 0; k < HID; ++k) d[k] = 0.f;
 #pragma unroll
-      for (int q = 0; q < HID; ++q) a += P[O_W2 + q * HID + k] * dr[q];
-      d[k] = a;
+    for (int q = 0; q < HID; ++q) {
+#pragma unroll
+      for (int k = 0; k < HID; ++k) d[k] += P[O_W2 + q * HID + k] * dr[q];
     }
     // ---- LN1 affine grads, through LN1 and ReLU
 #pragma unroll
