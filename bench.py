@@ -64,7 +64,7 @@ def time_kernel(fn, reps, inner=8):
 
 
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-PMC_KEYS = ("fps_pruned_kernel", "ball_query_kernel<8>", "row_gemm_%s64, 0, 0>", "sdpa_fwd_kernel<%s>")
+PMC_KEYS = ("fps_pruned_kernel", "ball_query_kernel<8>", "row_gemm_%s64, 0, 0>", "sdpa_fwd_%s")
 
 
 def attach_pmc_traffic(kernels, bf):
@@ -79,7 +79,7 @@ def attach_pmc_traffic(kernels, bf):
         if "row_gemm" in key:
             key = key % ("lds_kernel<" if bf else "kernel<float, ")
         elif "sdpa" in key:
-            key = key % ("true" if bf else "false")
+            key = key % ("lds_kernel" if bf else "kernel<false>")
         for name, v in table.items():
             if key in name:
                 entry["traffic"] = v["hbm_bytes_corrected"]
@@ -144,7 +144,8 @@ def report(args, world, elapsed, loss, batch, ext):
         entry(("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>") +
               " SA1 layer 1 (gather + 135->64 GEMM + BN sums)", "hbm", g_bytes, PEAK_HBM_GBS,
               "GB/s", g_ms, mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2)),
-        entry("sdpa_fwd_kernel<%s> match self-attention 64x(256x256) h4 d32" % ("bf16 MFMA" if bf else "fp32 MFMA"),
+        entry(("sdpa_fwd_lds_kernel (bf16 MFMA, K/V shared through LDS)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
+              " match self-attention 64x(256x256) h4 d32",
               "hbm", att_bytes, PEAK_HBM_GBS, "GB/s", att_ms, mfma_TFLOPs=round(4.0 * q.shape[0] * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
     ]
     attach_pmc_traffic(kernels, bf)
