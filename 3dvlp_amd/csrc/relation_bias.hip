@@ -10,7 +10,9 @@
 // forward per pair, back-propagates in registers and reduces the parameter gradients per wave:
 // rank-64 updates dW += dZ^T A on the matrix cores (fp32 MFMA, operands read back from a padded LDS tile
 // where lane = output feature, k = pair) and column sums for biases / LayerNorm affine parameters.
-// The geometry input carries no gradient (the reference detaches it, :86-87).
+// The geometry input carries no gradient (the reference detaches it, :86-87).  The file is compiled with
+// -ffp-contract=off like the rest of the library; the dot products use explicit fused multiply-adds (as a BLAS GEMM
+// does) — half the VALU instructions of separate multiplies and adds.
 #include "common.h"
 
 namespace {
@@ -73,7 +75,7 @@ __device__ __forceinline__ void mlp_forward(const float *__restrict__ P, Fwd &f)
     if (FENCE && (i & 7) == 0) ROW_FENCE();
     float z = P[O_B1 + i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) z += P[O_W1 + i * 4 + k] * f.x[k];
+    for (int k = 0; k < 4; ++k) z = __builtin_fmaf(P[O_W1 + i * 4 + k], f.x[k], z);
     if (z > 0.f) f.m1 |= 1u << i;
     r[i] = fmaxf(z, 0.f);
   }
@@ -84,10 +86,12 @@ __device__ __forceinline__ void mlp_forward(const float *__restrict__ P, Fwd &f)
   f.m2 = 0u;
 #pragma unroll
   for (int i = 0; i < HID; ++i) {
-    if (FENCE) ROW_FENCE();
     float z = P[O_B2 + i];
 #pragma unroll
-    for (int k = 0; k < HID; ++k) z += P[O_W2 + i * HID + k] * h1[k];
+    for (int k = 0; k < HID; ++k) {
+      if (FENCE && (k & 7) == 0) ROW_FENCE();  // at most 8 weights (two ds_read_b128) in flight per thread
+      z = __builtin_fmaf(P[O_W2 + i * HID + k], h1[k], z);
+    }
     if (z > 0.f) f.m2 |= 1u << i;
     r[i] = fmaxf(z, 0.f);
   }
@@ -96,10 +100,12 @@ __device__ __forceinline__ void mlp_forward(const float *__restrict__ P, Fwd &f)
   for (int i = 0; i < HID; ++i) h2[i] = f.n2[i] * P[O_G2 + i] + P[O_E2 + i];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    if (FENCE) ROW_FENCE();
     float z = P[O_B3 + c];
 #pragma unroll
-    for (int k = 0; k < HID; ++k) z += P[O_W3 + c * HID + k] * h2[k];
+    for (int k = 0; k < HID; ++k) {
+      if (FENCE && (k & 7) == 0) ROW_FENCE();
+      z = __builtin_fmaf(P[O_W3 + c * HID + k], h2[k], z);
+    }
     f.o[c] = z;
   }
 }
@@ -168,9 +174,11 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
                                                                 const float *__restrict__ dout, int B, int K,
                                                                 float *__restrict__ slabs) {
   extern __shared__ float lds[];  // per wave: two [64][LDT] tiles
-  // Backward keeps ~250 values live per thread, so the weights stay wave-uniform SCALAR operands here (through LDS
-  // they would each need a VGPR: 4 KB of scratch per thread, 4x slower).
+  // Backward keeps ~250 values live per thread and stays on wave-uniform SCALAR weights: through LDS (even in fenced
+  // chunks of 8) the register allocation collapses to 512 VGPRs + 3.7 KB of scratch per thread (4x slower, measured).
+  // The scalar form pays ~4000 v_readlane/v_writelane SGPR spills per 64 pairs instead.
   const float *__restrict__ P = Pg;
+  const float *__restrict__ sW2 = Pg + O_W2;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *TA = lds + wave * 2 * 64 * LDT;
@@ -204,8 +212,9 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
     for (int k = 0; k < HID; ++k) {
       TA[lane * LDT + k] = k < 4 ? dO[k] : 0.f;
       TB[lane * LDT + k] = f.n2[k] * P[O_G2 + k] + P[O_E2 + k];  // h2
-      d[k] = P[O_W3 + k] * dO[0] + P[O_W3 + HID + k] * dO[1] + P[O_W3 + 2 * HID + k] * dO[2] +
-             P[O_W3 + 3 * HID + k] * dO[3];
+      d[k] = __builtin_fmaf(P[O_W3 + 3 * HID + k], dO[3],
+                            __builtin_fmaf(P[O_W3 + 2 * HID + k], dO[2],
+                                           __builtin_fmaf(P[O_W3 + HID + k], dO[1], P[O_W3 + k] * dO[0])));
     }
     accW3 = rank64_update(TA, TB, r, half, accW3);
     s_b3 += column_sum(TA, r, half);
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
 #pragma unroll
     for (int q = 0; q < HID; ++q) {
 #pragma unroll
-      for (int k = 0; k < HID; ++k) d[k] += P[O_W2 + q * HID + k] * dr[q];
+      for (int k = 0; k < HID; ++k) d[k] = __builtin_fmaf(sW2[q * HID + k], dr[q], d[k]);
     }
     // ---- LN1 affine grads, through LN1 and ReLU
 #pragma unroll
