@@ -84,6 +84,35 @@ def test_fps_pruned_ties_and_skip_rule(ext, N):
     assert (ext.furthest_point_sampling(dev(skipped), 10, "pruned").cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("kind,N,m", [("lattice", 12345, 700), ("dups", 16384, 512), ("plane", 20000, 256),
+                                      ("line", 9000, 300), ("skip", 40000, 400)])
+def test_fps_pruned_degenerate_sets_equal_dense_and_oracle(ext, kind, N, m):
+    """Point sets built to stress the lazy tie resolution and the bounding-box test of the pruned kernel (duplicates,
+    lattices with exact distance ties, flat / collinear boxes, many points inside the skip ball); tools/fuzz_fps.py
+    runs the same generators at scale."""
+    rng = np.random.default_rng(N + m)
+    B = 2
+    if kind == "lattice":
+        p = rng.integers(0, 12, (B, N, 3)).astype(np.float64) * 0.25 + 0.5
+    elif kind == "dups":
+        base = rng.uniform(-2, 2, (B, N // 8 + 1, 3))
+        p = base[:, rng.integers(0, N // 8 + 1, N)]
+    elif kind == "plane":
+        p = rng.uniform(-3, 3, (B, N, 3))
+        p[..., 2] = 1.0
+    elif kind == "line":
+        t = rng.uniform(-5, 5, (B, N, 1))
+        p = np.concatenate([t, 0.5 * t + 1, np.full_like(t, 0.3)], -1)
+    else:
+        p = rng.uniform(-1, 1, (B, N, 3))
+        p[:, rng.integers(0, N, N // 10)] *= 0.01
+    xyz = p.astype(np.float32)
+    pruned = ext.furthest_point_sampling(dev(xyz), m, "pruned").cpu().numpy()
+    dense = ext.furthest_point_sampling(dev(xyz), m, "dense").cpu().numpy()
+    assert (pruned == dense).all()
+    assert (pruned == orc.furthest_point_sampling(xyz, m)).all()
+
+
 def test_fps_all_points_skipped(pu):
     xyz = np.full((2, 100, 3), 0.001, np.float32)
     got = pu.furthest_point_sample(dev(xyz), 10).cpu().numpy()
