@@ -374,6 +374,120 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward 1, bf16-MFMA form with the head's K and V shared through LDS (same staging idea as sdpa_fwd_lds_kernel):
+// K row-major (S^T = K Q^T), V row-major (dP^T = V dO^T) and K transposed (dQ^T += K^T dS^T), all bf16, converted once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, int nkp, float scale,
+    float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
+  extern __shared__ __attribute__((aligned(16))) short sm_kv[];
+  constexpr int KS = D + 8;
+  const int TS = nkp + 4;
+  short *sK = sm_kv;                 // [nkp][KS]
+  short *sV = sK + nkp * KS;         // [nkp][KS]
+  short *sKt = sV + nkp * KS;        // [D][TS]
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D;
+  for (int c = threadIdx.x; c < nkp * (D / 4); c += 256) {
+    const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (key < nk) {
+      const long long off = ((long long)b * nk + key) * HD + h * D + d4;
+      kv = *reinterpret_cast<const float4 *>(k + off);
+      vv = *reinterpret_cast<const float4 *>(v + off);
+    }
+    short4 kb, vb;
+    kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
+    vb.x = bf16_bits(vv.x); vb.y = bf16_bits(vv.y); vb.z = bf16_bits(vv.z); vb.w = bf16_bits(vv.w);
+    *reinterpret_cast<short4 *>(sK + key * KS + d4) = kb;
+    *reinterpret_cast<short4 *>(sV + key * KS + d4) = vb;
+    sKt[(d4 + 0) * TS + key] = kb.x;
+    sKt[(d4 + 1) * TS + key] = kb.y;
+    sKt[(d4 + 2) * TS + key] = kb.z;
+    sKt[(d4 + 3) * TS + key] = kb.w;
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  if (q0 >= nq) return;
+  const int qi = min(q0 + r, nq - 1);
+  const long long qrow = (long long)b * nq + qi;
+  const bool q_ok = q0 + r < nq;
+  float qreg[16], doreg[16], oreg[16];
+  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(dout, qrow, HD, h, half, doreg);
+  load_half_row(out, qrow, HD, h, half, oreg);
+  float dl = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dl += doreg[i] * oreg[i];
+  dl += __shfl_xor(dl, 32);
+  const long long stat = ((long long)b * H + h) * nq + qi;
+  if (q_ok && half == 0) delta[stat] = dl;
+  const float lse_q = lse[stat];
+  const long long bias_row = stat * nk;
+  bf16x8 qa[2], da[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qa[t][j] = bf16_bits(qreg[8 * t + j]);
+      da[t][j] = bf16_bits(doreg[8 * t + j]);
+    }
+  f32x16 dqa = zero16();
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    f32x16 s = zero16(), dp = zero16();
+    const short *kr = sK + (k0 + r) * KS + 16 * half, *vr = sV + (k0 + r) * KS + 16 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(kr + 8 * t), qa[t], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(vr + 8 * t), da[t], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      float ds = 0.f;
+      if (key < nk) {
+        const float raw = s[i] * scale;
+        float x = apply_bias(raw, bias_mode, bias, bias_row + key);
+        const bool masked = mask != nullptr && mask[(long long)b * nk + key] == 0.f;
+        if (masked) x = -10000.f;
+        const float p = __expf(x - lse_q);
+        ds = masked ? 0.f : p * (dp[i] - dl);
+        if (dbias != nullptr && q_ok) dbias[bias_row + key] = bias_mode == 2 ? ds * raw : ds;
+        if (bias_mode == 2) ds *= bias[bias_row + key];
+      }
+      s[i] = ds;
+    }
+    // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query], keys in the accumulator's row order (see the forward)
+    const short *kt = sKt + r * TS + k0 + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 ka, sb;
+      const short4 g0 = *reinterpret_cast<const short4 *>(kt + 16 * t);
+      const short4 g1 = *reinterpret_cast<const short4 *>(kt + 16 * t + 8);
+      ka[0] = g0.x; ka[1] = g0.y; ka[2] = g0.z; ka[3] = g0.w;
+      ka[4] = g1.x; ka[5] = g1.y; ka[6] = g1.z; ka[7] = g1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sb[j] = bf16_bits(s[8 * t + j]);
+      dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, sb, dqa, 0, 0, 0);
+    }
+  }
+  if (q_ok) {
+    float *__restrict__ row = dq + qrow * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = dqa[4 * g + 0] * scale; w.y = dqa[4 * g + 1] * scale; w.z = dqa[4 * g + 2] * scale;
+      w.w = dqa[4 * g + 3] * scale;
+      *reinterpret_cast<float4 *>(row + 8 * g + 4 * half) = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward 2: wave = 32 keys; loops over query tiles; writes dK, dV (no atomics).
 // ---------------------------------------------------------------------------------------------
 template <bool BF>
@@ -500,8 +614,15 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(vlp3d_cdiv(nq, 32), H, B), gk(vlp3d_cdiv(nk, 32), H, B);
   if (bf16_mma) {
-    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
-                       nq, nk, scale, dq, dbias, delta);
+    if (nk <= 288 && (long long)B * H >= 64) {  // K, V and K^T of a head staged once in LDS (<= 63 KB) and shared by
+      // four query waves; with few (batch, head) pairs the one-wave form keeps more CUs busy
+      const int nkp = (nk + 31) & ~31;
+      const size_t lds = ((size_t)2 * nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
+      hipLaunchKernelGGL(sdpa_bwd_dq_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, s, q, k, v, bias,
+                         bias_mode, mask, out, lse, dout, H, nq, nk, nkp, scale, dq, dbias, delta);
+    } else
+      hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
+                         nq, nk, scale, dq, dbias, delta);
     hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
                        H, nq, nk, scale, dk, dv);
   } else {
