@@ -6,9 +6,9 @@
 // layer (+ LayerNorm statistics) and runs six skinny GEMMs with 524 288 rows through the BLAS library.
 //
 // Here one thread owns one (b,i,j) pair and carries the whole 4->32->32->4 MLP in registers (weights are
-// wave-uniform: scalar loads); nothing but the (B,4,K,K) bias is written.  The backward recomputes the
-// forward per pair, back-propagates in registers and reduces the parameter gradients per wave:
-// rank-64 updates dW += dZ^T A on the matrix cores (fp32 MFMA, operands read back from a padded LDS tile
+// read through LDS); nothing but the (B,4,K,K) bias is written.  The backward recomputes the forward per pair with
+// two lanes per pair (16 features each), runs the two 32x32 layer products on the matrix cores, and reduces the
+// parameter gradients per wave: rank-32 updates dW += dZ^T A (fp32 MFMA, operands read back from a padded LDS tile
 // where lane = output feature, k = pair) and column sums for biases / LayerNorm affine parameters.
 // The geometry input carries no gradient (the reference detaches it, :86-87).  The file is compiled with
 // -ffp-contract=off like the rest of the library; the dot products use explicit fused multiply-adds (as a BLAS GEMM
@@ -133,56 +133,58 @@ __global__ __launch_bounds__(256) void relation_bias_fwd_kernel(const float *__r
   }
 }
 
-// LayerNorm backward on 32 features: dn -> d(input of LN) ; n = normalised value
-__device__ __forceinline__ void layer_norm32_bwd(const float (&dn)[HID], const float (&n)[HID], float rstd,
-                                                 float (&dr)[HID]) {
-  float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < HID; ++i) {
-    m1 += dn[i];
-    m2 += dn[i] * n[i];
-  }
-  m1 *= (1.f / HID);
-  m2 *= (1.f / HID);
-#pragma unroll
-  for (int i = 0; i < HID; ++i) dr[i] = rstd * (dn[i] - m1 - n[i] * m2);
-}
-
 constexpr int LDT = HID + 1;  // padded LDS row: lane = pair writes its 32 features without bank conflicts
 
-// acc (32x32) += A^T B over the 64 pairs of a wave tile: A, B are [64][LDT] LDS tiles (row = pair).
-__device__ __forceinline__ f32x16 rank64_update(const float *__restrict__ A, const float *__restrict__ Bm, int r,
-                                                int half, f32x16 acc) {
+// ------------------------------------------------------------------------------------------------------------------
+// Backward: TWO lanes per pair.  Lane (j = lane & 31, h = lane >> 5) of a wave holds, for pair j of the
+// current 32-pair tile, the 16 features F(e,h) = acc_row(e,h) — exactly the rows an MFMA accumulator lane holds.
+// That halves the per-thread state (a one-lane-per-pair backward needs ~250 live values and spilled its scalar
+// weights through VGPR lanes: 278 us per layer against 202 us here) and puts the two 32x32 layer products on the matrix cores in exact fp32:
+//   Z2^T (feature x pair) = W2 * H1^T        A operand = W2 columns permuted to F(kk,h), B operand = h1[kk] (registers)
+//   dH1^T                 = W2^T * dZ2^T     A operand = W2 rows    permuted to F(kk,h), B operand = dz2[kk]
+// the output lands in the same split layout (accumulator-as-next-operand, as in sdpa.hip) — no transposes.  Per-pair
+// LayerNorm statistics need one exchange with lane ^ 32.  Parameter gradients as before: rank-32 MFMA updates over
+// the pairs of a tile (operands through a padded LDS tile) + column sums, per-wave slabs.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 rank32_update(const float *__restrict__ A, const float *__restrict__ Bm, int r, int half,
+                                                f32x16 acc) {
 #pragma unroll 8
-  for (int kk = 0; kk < 32; ++kk) {
+  for (int kk = 0; kk < 16; ++kk) {
     const int row = 2 * kk + half;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[row * LDT + r], Bm[row * LDT + r], acc, 0, 0, 0);
   }
   return acc;
 }
-
-// sum over the 64 rows of column (lane & 31); both halves of the wave end up with the full sum
-__device__ __forceinline__ float column_sum(const float *__restrict__ A, int r, int half) {
+__device__ __forceinline__ float column_sum32(const float *__restrict__ A, int r, int half) {
   float s = 0.f;
 #pragma unroll 8
-  for (int k = 0; k < 32; ++k) s += A[(half * 32 + k) * LDT + r];
+  for (int k = 0; k < 16; ++k) s += A[(half * 16 + k) * LDT + r];
   return s + __shfl_xor(s, 32);
 }
 
 __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__restrict__ centre,
-                                                                const float *__restrict__ Pg,
-                                                                const float *__restrict__ dout, int B, int K,
-                                                                float *__restrict__ slabs) {
-  extern __shared__ float lds[];  // per wave: two [64][LDT] tiles
-  // Backward keeps ~250 values live per thread and stays on wave-uniform SCALAR weights: through LDS (even in fenced
-  // chunks of 8) the register allocation collapses to 512 VGPRs + 3.7 KB of scratch per thread (4x slower, measured).
-  // The scalar form pays ~4000 v_readlane/v_writelane SGPR spills per 64 pairs instead.
-  const float *__restrict__ P = Pg;
-  const float *__restrict__ sW2 = Pg + O_W2;
+                                                                 const float *__restrict__ Pg,
+                                                                 const float *__restrict__ dout, int B, int K,
+                                                                 float *__restrict__ slabs) {
+  extern __shared__ float lds[];
+  float *sp = lds;                   // [NPARAM] plain parameters
+  float *A2 = sp + NPARAM + 4;       // [(h*16+kk)*32 + i] = W2[i][F(kk,h)]
+  float *A2T = A2 + HID * HID;       // [(h*16+kk)*32 + k] = W2[F(kk,h)][k]
+  float *tiles = A2T + HID * HID;    // per wave: two [32][LDT] tiles
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *TA = lds + wave * 2 * 64 * LDT;
-  float *TB = TA + 64 * LDT;
+  float *TA = tiles + wave * 2 * 32 * LDT;
+  float *TB = TA + 32 * LDT;
+  for (int i = threadIdx.x; i < NPARAM; i += 256) sp[i] = Pg[i];
+  for (int i = threadIdx.x; i < HID * HID; i += 256) {
+    const int hh = i >> 9, kk = (i >> 5) & 15, c = i & 31;
+    const int f = acc_row(kk, hh);
+    A2[i] = Pg[O_W2 + c * HID + f];
+    A2T[i] = Pg[O_W2 + f * HID + c];
+  }
+  __syncthreads();
+  const int fo = 4 * half;  // F(e,h) = (e & 3) + 8 * (e >> 2) + 4h: compile-time part + fo
+#define FEAT(e) (((e) & 3) + 8 * ((e) >> 2))
 
   f32x16 accW2, accW3, accW1;
 #pragma unroll
@@ -190,93 +192,163 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
   float s_b3 = 0.f, s_g2 = 0.f, s_e2 = 0.f, s_b2 = 0.f, s_g1 = 0.f, s_e1 = 0.f, s_b1 = 0.f;
 
   const long long total = (long long)B * K * K;
-  const long long ntiles = (total + 63) / 64;
+  const long long ntiles = (total + 31) / 32;
   const long long gwave = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
   for (long long tile = gwave; tile < ntiles; tile += nwaves) {
-    const long long t = tile * 64 + lane;
+    const long long t = tile * 32 + r;
     const bool ok = t < total;
     const long long tc = ok ? t : total - 1;
     const int j = (int)(tc % K);
     const int i = (int)((tc / K) % K);
     const int b = (int)(tc / ((long long)K * K));
-    Fwd f;
-    pair_input(centre, b, i, j, K, f.x);
-    mlp_forward<false>(P, f);
+    float x[4];
+    pair_input(centre, b, i, j, K, x);
+    // ---- forward, layer 1 (K = 4: vector unit) + LN1
+    float n1[16], n2[16], v[16];
+    unsigned m1 = 0u, m2 = 0u;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      const float4 w = *reinterpret_cast<const float4 *>(sp + O_W1 + 4 * f);
+      float z = sp[O_B1 + f];
+      z = __builtin_fmaf(w.x, x[0], z); z = __builtin_fmaf(w.y, x[1], z);
+      z = __builtin_fmaf(w.z, x[2], z); z = __builtin_fmaf(w.w, x[3], z);
+      if (z > 0.f) m1 |= 1u << e;
+      v[e] = fmaxf(z, 0.f);
+      sum += v[e];
+    }
+    sum += __shfl_xor(sum, 32);
+    float mean = sum * (1.f / HID), var = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float d0 = v[e] - mean;
+      var += d0 * d0;
+    }
+    var += __shfl_xor(var, 32);
+    const float rstd1 = rsqrtf(var * (1.f / HID) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) n1[e] = (v[e] - mean) * rstd1;
+    // ---- layer 2 on the matrix cores: Z2^T = W2 H1^T
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int f = FEAT(kk) + fo;
+      const float h1 = __builtin_fmaf(n1[kk], sp[O_G1 + f], sp[O_E1 + f]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[(half * 16 + kk) * 32 + r], h1, acc, 0, 0, 0);
+    }
+    sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float z = acc[e] + sp[O_B2 + FEAT(e) + fo];
+      if (z > 0.f) m2 |= 1u << e;
+      v[e] = fmaxf(z, 0.f);
+      sum += v[e];
+    }
+    sum += __shfl_xor(sum, 32);
+    mean = sum * (1.f / HID);
+    var = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float d0 = v[e] - mean;
+      var += d0 * d0;
+    }
+    var += __shfl_xor(var, 32);
+    const float rstd2 = rsqrtf(var * (1.f / HID) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) n2[e] = (v[e] - mean) * rstd2;
+
+    // ---- backward.  dO of this lane's pair
     float dO[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dO[c] = ok ? dout[(((long long)b * 4 + c) * K + i) * K + j] : 0.f;
-
-    // ---- layer 3: dW3 (4x32, zero-padded to 32x32) += dO^T h2 ; db3 ; dh2 = W3^T dO
-    float d[HID], dn[HID], dr[HID];
+    // layer 3: dW3 (4x32, zero-padded) += dO^T h2 ; db3 ; dh2 = W3^T dO
+    float d[16], dn[16];
+    float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      TA[lane * LDT + k] = k < 4 ? dO[k] : 0.f;
-      TB[lane * LDT + k] = f.n2[k] * P[O_G2 + k] + P[O_E2 + k];  // h2
-      d[k] = __builtin_fmaf(P[O_W3 + 3 * HID + k], dO[3],
-                            __builtin_fmaf(P[O_W3 + 2 * HID + k], dO[2],
-                                           __builtin_fmaf(P[O_W3 + HID + k], dO[1], P[O_W3 + k] * dO[0])));
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      TA[r * LDT + f] = (half == 0 && e < 4) ? dO[e & 3] : 0.f;  // feature f < 4 only for (h = 0, e < 4), where f = e
+      TB[r * LDT + f] = __builtin_fmaf(n2[e], sp[O_G2 + f], sp[O_E2 + f]);  // h2
+      d[e] = __builtin_fmaf(sp[O_W3 + 3 * HID + f], dO[3],
+                            __builtin_fmaf(sp[O_W3 + 2 * HID + f], dO[2],
+                                           __builtin_fmaf(sp[O_W3 + HID + f], dO[1], sp[O_W3 + f] * dO[0])));
     }
-    accW3 = rank64_update(TA, TB, r, half, accW3);
-    s_b3 += column_sum(TA, r, half);
-    // ---- LN2 affine grads (dg2 = sum dh2*n2, dbe2 = sum dh2), then through LN2 and ReLU
+    accW3 = rank32_update(TA, TB, r, half, accW3);
+    s_b3 += column_sum32(TA, r, half);
+    // LN2 affine grads, then through LN2 and ReLU
 #pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      TA[lane * LDT + k] = d[k] * f.n2[k];
-      TB[lane * LDT + k] = d[k];
-      dn[k] = d[k] * P[O_G2 + k];
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      TA[r * LDT + f] = d[e] * n2[e];
+      TB[r * LDT + f] = d[e];
+      dn[e] = d[e] * sp[O_G2 + f];
+      a1 += dn[e];
+      a2 += dn[e] * n2[e];
     }
-    s_g2 += column_sum(TA, r, half);
-    s_e2 += column_sum(TB, r, half);
-    layer_norm32_bwd(dn, f.n2, f.rstd2, dr);
-    // ---- layer 2: dz2 ; dW2 += dz2^T h1 ; db2 ; dh1 = W2^T dz2
+    s_g2 += column_sum32(TA, r, half);
+    s_e2 += column_sum32(TB, r, half);
+    a1 += __shfl_xor(a1, 32);
+    a2 += __shfl_xor(a2, 32);
+    a1 *= (1.f / HID);
+    a2 *= (1.f / HID);
+    // layer 2: dz2 ; dW2 += dz2^T h1 ; db2
 #pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      dr[k] = ((f.m2 >> k) & 1u) ? dr[k] : 0.f;
-      TA[lane * LDT + k] = dr[k];
-      TB[lane * LDT + k] = f.n1[k] * P[O_G1 + k] + P[O_E1 + k];  // h1
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      const float g = rstd2 * (dn[e] - a1 - n2[e] * a2);
+      v[e] = ((m2 >> e) & 1u) ? g : 0.f;  // dz2
+      TA[r * LDT + f] = v[e];
+      TB[r * LDT + f] = __builtin_fmaf(n1[e], sp[O_G1 + f], sp[O_E1 + f]);  // h1
     }
-    accW2 = rank64_update(TA, TB, r, half, accW2);
-    s_b2 += column_sum(TA, r, half);
-    // dh1[k] = sum_q W2[q][k] dz2[q]: rows of W2 in the outer loop — contiguous scalar loads (s_load_dwordx8) consumed
-    // at once.  The column-wise form (k outer) issued 1024 strided one-dword scalar loads whose results the compiler
-    // kept in SGPRs and spilled through VGPR lanes (5700 v_readlane/v_writelane, 256 VGPRs, one wave per SIMD).
-    // Same summation order per k (q ascending): bit-identical.
+    accW2 = rank32_update(TA, TB, r, half, accW2);
+    s_b2 += column_sum32(TA, r, half);
+    // dH1^T = W2^T dZ2^T on the matrix cores
 #pragma unroll
-    for (int k = 0; k < HID; ++k) d[k] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int q = 0; q < HID; ++q) {
+    for (int kk = 0; kk < 16; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2T[(half * 16 + kk) * 32 + r], v[kk], acc, 0, 0, 0);
+    // LN1 affine grads, through LN1 and ReLU
+    a1 = a2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < HID; ++k) d[k] = __builtin_fmaf(sW2[q * HID + k], dr[q], d[k]);
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      d[e] = acc[e];
+      TA[r * LDT + f] = d[e] * n1[e];
+      TB[r * LDT + f] = d[e];
+      dn[e] = d[e] * sp[O_G1 + f];
+      a1 += dn[e];
+      a2 += dn[e] * n1[e];
     }
-    // ---- LN1 affine grads, through LN1 and ReLU
+    s_g1 += column_sum32(TA, r, half);
+    s_e1 += column_sum32(TB, r, half);
+    a1 += __shfl_xor(a1, 32);
+    a2 += __shfl_xor(a2, 32);
+    a1 *= (1.f / HID);
+    a2 *= (1.f / HID);
+    // layer 1: dz1 ; dW1 (32x4, zero-padded) += dz1^T x ; db1
 #pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      TA[lane * LDT + k] = d[k] * f.n1[k];
-      TB[lane * LDT + k] = d[k];
-      dn[k] = d[k] * P[O_G1 + k];
+    for (int e = 0; e < 16; ++e) {
+      const int f = FEAT(e) + fo;
+      const float g = rstd1 * (dn[e] - a1 - n1[e] * a2);
+      TA[r * LDT + f] = ((m1 >> e) & 1u) ? g : 0.f;
+      TB[r * LDT + f] = (half == 0 && e < 4) ? x[e & 3] : 0.f;
     }
-    s_g1 += column_sum(TA, r, half);
-    s_e1 += column_sum(TB, r, half);
-    layer_norm32_bwd(dn, f.n1, f.rstd1, dr);
-    // ---- layer 1: dz1 ; dW1 (32x4, zero-padded) += dz1^T x ; db1
-#pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      TA[lane * LDT + k] = ((f.m1 >> k) & 1u) ? dr[k] : 0.f;
-      TB[lane * LDT + k] = k < 4 ? f.x[k] : 0.f;
-    }
-    accW1 = rank64_update(TA, TB, r, half, accW1);
-    s_b1 += column_sum(TA, r, half);
+    accW1 = rank32_update(TA, TB, r, half, accW1);
+    s_b1 += column_sum32(TA, r, half);
   }
+#undef FEAT
 
-  // ---- this wave's partial parameter gradients -> its slab (summed on the host side of the ABI call)
   float *S = slabs + gwave * NPARAM;
-  // accumulators: element (row = acc_row(e,half) = A-feature, col = r = B-feature)
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int a = acc_row(e, half);
-    S[O_W2 + a * HID + r] = accW2[e];                 // dW2[i=a][k=r]
-    if (a < 4) S[O_W3 + a * HID + r] = accW3[e];      // dW3[c=a][k=r]
-    if (r < 4) S[O_W1 + a * 4 + r] = accW1[e];        // dW1[i=a][k=r]
+    S[O_W2 + a * HID + r] = accW2[e];
+    if (a < 4) S[O_W3 + a * HID + r] = accW3[e];
+    if (r < 4) S[O_W1 + a * 4 + r] = accW1[e];
   }
   if (half == 0) {
     if (r < 4) S[O_B3 + r] = s_b3;
@@ -321,11 +393,11 @@ extern "C" int vlp3d_relation_bias_fwd(const float *centre, const float *params,
 extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
                                        float *dparams, float *slabs, int nblocks, void *stream) {
   if (!centre || !params || !dout || !dparams || !slabs || B < 1 || K < 1 || nblocks < 1) return VLP3D_EINVAL;
-  const long long ntiles = ((long long)B * K * K + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+  const long long ntiles = ((long long)B * K * K + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > nblocks) blocks = nblocks;
-  const size_t lds = (size_t)4 * 2 * 64 * LDT * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)(NPARAM + 4 + 2 * HID * HID + 4 * 2 * 32 * LDT) * sizeof(float);
   hipLaunchKernelGGL(relation_bias_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
                      slabs);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 63) / 64), dim3(256), 0, s, slabs, (int)blocks * 4, NPARAM,
