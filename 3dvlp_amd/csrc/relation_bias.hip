@@ -342,19 +342,26 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
   }
 #undef FEAT
 
-  float *S = slabs + gwave * NPARAM;
+  // ---- the four waves' partial parameter gradients are combined through LDS: ONE slab per workgroup
+  __syncthreads();  // every wave is done with the staged weights and its tiles
+  float *S = lds + wave * NPARAM;
+  for (int i = lane; i < NPARAM; i += 64) S[i] = 0.f;  // entries the scatter below does not touch (none today)
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int a = acc_row(e, half);
-    S[O_W2 + a * HID + r] = accW2[e];
-    if (a < 4) S[O_W3 + a * HID + r] = accW3[e];
-    if (r < 4) S[O_W1 + a * 4 + r] = accW1[e];
+    S[O_W2 + a * HID + r] = accW2[e];                 // dW2[i=a][k=r]
+    if (a < 4) S[O_W3 + a * HID + r] = accW3[e];      // dW3[c=a][k=r]
+    if (r < 4) S[O_W1 + a * 4 + r] = accW1[e];        // dW1[i=a][k=r]
   }
   if (half == 0) {
     if (r < 4) S[O_B3 + r] = s_b3;
     S[O_G2 + r] = s_g2; S[O_E2 + r] = s_e2; S[O_B2 + r] = s_b2;
     S[O_G1 + r] = s_g1; S[O_E1 + r] = s_e1; S[O_B1 + r] = s_b1;
   }
+  __syncthreads();
+  float *G = slabs + (long long)blockIdx.x * NPARAM;
+  for (int i = threadIdx.x; i < NPARAM; i += 256)
+    G[i] = (lds[i] + lds[NPARAM + i]) + (lds[2 * NPARAM + i] + lds[3 * NPARAM + i]);
 }
 
 // out[i] = sum_k slabs[k][i]: 256 threads = 4 slab-groups x 64 consecutive elements
@@ -389,7 +396,7 @@ extern "C" int vlp3d_relation_bias_fwd(const float *centre, const float *params,
   return VLP3D_OK;
 }
 
-// dout (B,4,K,K) -> dparams (NPARAM); slabs: scratch of nblocks*4*NPARAM floats (nblocks >= 1).
+// dout (B,4,K,K) -> dparams (NPARAM); slabs: scratch of at least nblocks*NPARAM floats (nblocks >= 1).
 extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
                                        float *dparams, float *slabs, int nblocks, void *stream) {
   if (!centre || !params || !dout || !dparams || !slabs || B < 1 || K < 1 || nblocks < 1) return VLP3D_EINVAL;
@@ -400,8 +407,7 @@ extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params,
   const size_t lds = (size_t)(NPARAM + 4 + 2 * HID * HID + 4 * 2 * 32 * LDT) * sizeof(float);
   hipLaunchKernelGGL(relation_bias_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
                      slabs);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 63) / 64), dim3(256), 0, s, slabs, (int)blocks * 4, NPARAM,
-                     dparams);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 63) / 64), dim3(256), 0, s, slabs, (int)blocks, NPARAM, dparams);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

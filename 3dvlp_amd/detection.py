@@ -308,7 +308,7 @@ class ProposalModule(nn.Module):
 
 class _RelationBias(torch.autograd.Function):
     """Fused pairwise-geometry bias MLP (csrc/relation_bias.hip): centre (B,K,3), packed params -> (B,4,K,K)."""
-    SLAB_BLOCKS = 256  # workgroups of the backward kernel (4 partial-gradient slabs each)
+    SLAB_BLOCKS = 256  # workgroups of the backward kernel (one partial-gradient slab each)
 
     @staticmethod
     def forward(ctx, centre, params):
@@ -326,7 +326,7 @@ class _RelationBias(torch.autograd.Function):
         B, K, _ = centre.shape
         n = params.numel()
         dparams = torch.empty_like(params)
-        slabs = torch.empty((_RelationBias.SLAB_BLOCKS * 4, n), dtype=torch.float32, device=centre.device)
+        slabs = torch.empty((_RelationBias.SLAB_BLOCKS, n), dtype=torch.float32, device=centre.device)
         _ext.call("vlp3d_relation_bias_bwd", centre, params, dout.contiguous().float(), B, K, dparams, slabs,
                   _RelationBias.SLAB_BLOCKS)
         return None, dparams

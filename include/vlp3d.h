@@ -272,7 +272,7 @@ int vlp3d_box_decode_bwd(const float *rois, const float *heading, const int *hea
  * (the order of nn.Sequential.parameters()).  centre (B,K,3) -> out (B,4,K,K). */
 int vlp3d_relation_bias_nparam(void);
 int vlp3d_relation_bias_fwd(const float *centre, const float *params, int B, int K, float *out, void *stream);
-/* dout (B,4,K,K) -> dparams (nparam, fully written); slabs: scratch of nblocks*4*nparam floats. */
+/* dout (B,4,K,K) -> dparams (nparam, fully written); slabs: scratch of nblocks*nparam floats (one partial per workgroup). */
 int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
                             float *dparams, float *slabs, int nblocks, void *stream);
 

@@ -13,7 +13,7 @@ out = torch.empty(B, 4, K, K, device=dev)
 dout = torch.randn_like(out)
 dpar = torch.empty_like(params)
 nb = det._RelationBias.SLAB_BLOCKS
-slabs = torch.empty(nb * 4, n, device=dev)
+slabs = torch.empty(nb, n, device=dev)
 def t(fn, reps=20):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
