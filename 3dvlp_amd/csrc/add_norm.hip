@@ -146,18 +146,32 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(const float *__restri
   }
 }
 
-// out[i] = sum_b partials[b][i]
+// out[i] = sum_b partials[b][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups (each
+// thread nblk/16 independent 16-byte loads), then folds the groups through LDS.  n % 4 == 0.
 __global__ __launch_bounds__(256) void add_norm_slab_sum_kernel(const float *__restrict__ partials, int nblk, int n,
                                                                 float *__restrict__ out) {
-  __shared__ float red[4][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (i < n)
-    for (int b = grp; b < nblk; b += 4) s += partials[(long long)b * n + i];
-  red[grp][col] = s;
+  __shared__ float4 red[16][16];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 64 + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+#pragma unroll 4
+    for (int b = grp; b < nblk; b += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(partials + (long long)b * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[grp][q] = s;
   __syncthreads();
-  if (grp == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (grp == 0 && i < n) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {
+      const float4 v = red[g][q];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + i) = t;
+  }
 }
 
 }  // namespace
