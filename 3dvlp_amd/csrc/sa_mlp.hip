@@ -998,27 +998,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // Per-channel bookkeeping of the fused layer (each replaces ~20 tiny framework kernels per BatchNorm):
 // ------------------------------------------------------------------------------------------------
-// Sum the per-workgroup slabs [nslab][2][C] for 16 columns per block: 256 threads = 16 slab-groups x 16 columns.
-// Returns (sum of [0][c], sum of [1][c]) to the threads of group 0 (threadIdx.x < 16); c = blockIdx.x*16 + col.
+// Sum the per-workgroup slabs [nslab][2][C] for SUMC columns per block: 256 threads = 64 slab-groups x 4 columns (a
+// thread adds nslab/64 slabs: with 16 groups the 64 dependent fp64 loads per thread made these kernels 15 us each).
+// Returns (sum of [0][c], sum of [1][c]) to the threads of group 0 (threadIdx.x < SUMC); c = blockIdx.x*SUMC + col.
+constexpr int SUMC = 4;
 __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int nslab, int C, double &s0, double &s1) {
-  __shared__ double red[2][16][16];
-  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + col;
+  __shared__ double red[2][64][SUMC];
+  const int col = threadIdx.x & (SUMC - 1), grp = threadIdx.x / SUMC;
+  const int c = blockIdx.x * SUMC + col;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int k = grp; k < nslab; k += 16) {
+  if (c < C) {
+#pragma unroll 4
+    for (int k = grp; k < nslab; k += 64) {
       a += slabs[(size_t)k * 2 * C + c];
       b += slabs[(size_t)k * 2 * C + C + c];
     }
+  }
   red[0][grp][col] = a;
   red[1][grp][col] = b;
   __syncthreads();
-  s0 = s1 = 0.0;
-  if (grp == 0)
-    for (int g = 0; g < 16; ++g) {
-      s0 += red[0][g][col];
-      s1 += red[1][g][col];
+  for (int off = 32; off >= 1; off >>= 1) {  // tree over the 64 groups
+    if (grp < off) {
+      red[0][grp][col] += red[0][grp + off][col];
+      red[1][grp][col] += red[1][grp + off][col];
     }
+    __syncthreads();
+  }
+  s0 = red[0][0][col];
+  s1 = red[1][0][col];
 }
 
 // bn_fold: batch statistics (fp64 sums) -> vec[4][C] = [scale | shift | rstd | -mean*rstd], running-stat update.
@@ -1028,8 +1035,8 @@ __global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, cons
                                int training, float *__restrict__ vec) {
   double s = 0.0, q = 0.0;
   if (training) slab_sum16(stats, nslab, C, s, q);
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  if (threadIdx.x >= 16 || c >= C) return;
+  const int c = blockIdx.x * SUMC + (threadIdx.x & (SUMC - 1));
+  if (threadIdx.x >= SUMC || c >= C) return;
   double mean, var;
   if (training) {
     mean = s / R;
@@ -1057,8 +1064,8 @@ __global__ void bn5_kernel(const float *__restrict__ vec, const float *__restric
                            float *__restrict__ bn5, float *__restrict__ dgamma, float *__restrict__ dbeta) {
   double t[2];
   slab_sum16(tslabs, nslab, C, t[0], t[1]);
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  if (threadIdx.x >= 16 || c >= C) return;
+  const int c = blockIdx.x * SUMC + (threadIdx.x & (SUMC - 1));
+  if (threadIdx.x >= SUMC || c >= C) return;
   const float rstd = vec[2 * C + c];
   bn5[c] = rstd;
   bn5[C + c] = vec[3 * C + c];
@@ -1372,7 +1379,7 @@ extern "C" int vlp3d_sa_bn_fold(const double *stats, int nslab, const float *gam
                                 int training, float *vec, void *stream) {
   if (nslab < 1 || !gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
     return VLP3D_EINVAL;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, nslab, gamma, beta,
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + SUMC - 1) / SUMC), dim3(256), 0, (hipStream_t)stream, stats, nslab, gamma, beta,
                      running_mean, running_var, C, (double)R, eps, momentum, training, vec);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
@@ -1383,7 +1390,7 @@ extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, cons
                                       long long R, int training, float *bn5, float *dgamma, float *dbeta,
                                       void *stream) {
   if (nslab < 1 || !vec || !gamma || !t || !bn5 || !dgamma || !dbeta || C < 1 || R < 1) return VLP3D_EINVAL;
-  hipLaunchKernelGGL(bn5_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, vec, gamma, t, nslab, C, (double)R,
+  hipLaunchKernelGGL(bn5_kernel, dim3((C + SUMC - 1) / SUMC), dim3(256), 0, (hipStream_t)stream, vec, gamma, t, nslab, C, (double)R,
                      training, bn5, dgamma, dbeta);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
