@@ -250,10 +250,18 @@ __global__ __launch_bounds__(128) void contrast_bwd_cols_kernel(Args a, const fl
     for (int l = 0; l < a.L; ++l) acc += ds[(long long)l * a.K] * a.text[((long long)b * a.L + l) * a.D + d];
     dbox[((long long)b * a.K + j) * a.D + d] = acc;
     float acc2 = 0.f;
-    for (int k = 0; k < a.K; ++k) {
-      const float v = ds[(long long)(a.L + k) * a.K];
-      if (v != 0.f) acc2 += v * a.boxi[((long long)b * a.K + k) * a.D + d];  // uniform branch: dS is mostly zero
+    int k = 0;
+    for (; k + 8 <= a.K; k += 8) {  // eight rows in flight (one row per iteration is a chain of load latencies)
+      float v[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = ds[(long long)(a.L + k + u) * a.K];
+        x[u] = a.boxi[((long long)b * a.K + k + u) * a.D + d];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc2 += v[u] * x[u];
     }
+    for (; k < a.K; ++k) acc2 += ds[(long long)(a.L + k) * a.K] * a.boxi[((long long)b * a.K + k) * a.D + d];
     dboxi[((long long)b * a.K + j) * a.D + d] += acc2;
   }
 }

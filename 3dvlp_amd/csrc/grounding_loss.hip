@@ -7,7 +7,9 @@
 //   reference loss   CE of cluster_ref rows against the proposal nearest to the referred GT centre (mean over rows)
 //   total = vote + w_obj*obj + centre + w_ref*ref
 // Sections of the grid: thread per seed | thread per proposal | workgroup per (scene, sentence) row.
-// The seven global sums go through fp64 atomics (one per workgroup and quantity); `sums` is kept for backward.
+// Every workgroup writes its share of the seven global sums to its own row of a partial buffer; the finalize kernel
+// adds the rows (a few hundred workgroups adding atomically into seven addresses serialise at L2).  `sums` is kept
+// for backward.
 #include "common.h"
 
 namespace {
@@ -83,9 +85,10 @@ __device__ __forceinline__ float nearest_gt(const LossArgs &a, int b, int k, int
   return best;
 }
 
-__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double *__restrict__ sums, int nb_vote, int nb_prop) {
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double *__restrict__ part, int nb_vote, int nb_prop) {
   __shared__ float red[8];
   const int blk = blockIdx.x;
+  double *sums = part + (long long)blk * NSUMS;  // this workgroup's row, fully written below
   if (blk < nb_vote) {  // ---- vote loss: thread per seed
     const long long t = (long long)blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
@@ -99,8 +102,9 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double *__res
     num = bsum(num, red);
     den = bsum(den, red);
     if (threadIdx.x == 0) {
-      atomicAdd(sums + VOTE_NUM, (double)num);
-      atomicAdd(sums + VOTE_DEN, (double)den);
+      for (int q = 0; q < NSUMS; ++q) sums[q] = 0.0;  // the whole row: no memset of the partial buffer needed
+      sums[VOTE_NUM] = (double)num;
+      sums[VOTE_DEN] = (double)den;
     }
   } else if (blk < nb_vote + nb_prop) {  // ---- objectness + centre: thread per proposal
     const long long t = (long long)(blk - nb_vote) * 256 + threadIdx.x;
@@ -132,10 +136,11 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double *__res
     }
     on = bsum(on, red); od = bsum(od, red); cn = bsum(cn, red); cd = bsum(cd, red);
     if (threadIdx.x == 0) {
-      atomicAdd(sums + OBJ_NUM, (double)on);
-      atomicAdd(sums + OBJ_DEN, (double)od);
-      atomicAdd(sums + CTR_NUM, (double)cn);
-      atomicAdd(sums + CTR_DEN, (double)cd);
+      for (int q = 0; q < NSUMS; ++q) sums[q] = 0.0;
+      sums[OBJ_NUM] = (double)on;
+      sums[OBJ_DEN] = (double)od;
+      sums[CTR_NUM] = (double)cn;
+      sums[CTR_DEN] = (double)cd;
     }
   } else {  // ---- reference loss: workgroup per (scene, sentence)
     const int row = blk - nb_vote - nb_prop, b = row / a.L;
@@ -171,14 +176,35 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double *__res
     float e = 0.f;
     for (int k = threadIdx.x; k < a.K; k += 256) e += expf(logit[k] - mx);
     e = bsum(e, red);
-    if (threadIdx.x == 0) atomicAdd(sums + REF_SUM, (double)(mx + logf(e) - logit[target]));
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < NSUMS; ++q) sums[q] = 0.0;
+      sums[REF_SUM] = (double)(mx + logf(e) - logit[target]);
+    }
   }
 }
 
-// out = [vote, objectness, centre, reference, total]
-__global__ void loss_finalize_kernel(const double *__restrict__ sums, float w_obj, float w_ref, int rows,
-                                     float *__restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// sums[q] = sum over the workgroup rows of part[.][q];  out = [vote, objectness, centre, reference, total]
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double *__restrict__ part, int nblocks, double *__restrict__ sums,
+                                                            float w_obj, float w_ref, int rows, float *__restrict__ out) {
+  __shared__ double red[NSUMS][256];
+  double acc[NSUMS];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) acc[q] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int q = 0; q < NSUMS; ++q) acc[q] += part[(long long)b * NSUMS + q];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) red[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int q = 0; q < NSUMS; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) sums[q] = red[q][0];
   const float vote = (float)sums[VOTE_NUM] / ((float)sums[VOTE_DEN] + 1e-6f);
   const float obj = (float)sums[OBJ_NUM] / ((float)sums[OBJ_DEN] + 1e-6f);
   const float ctr = (float)sums[CTR_NUM] / ((float)sums[CTR_DEN] + 1e-6f);
@@ -271,6 +297,13 @@ bool bad(const LossArgs &a) {
 
 }  // namespace
 
+// doubles the caller must provide as `sums`: 7 totals + 7 per workgroup of the forward kernel
+extern "C" long long vlp3d_grounding_loss_sums(int B, int S, int K, int L) {
+  if (B < 1 || S < 1 || K < 1 || L < 1) return 0;
+  const long long nblocks = ((long long)B * S + 255) / 256 + ((long long)B * K + 255) / 256 + (long long)B * L;
+  return NSUMS * (1 + nblocks);
+}
+
 extern "C" int vlp3d_grounding_loss_fwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds,
                                         const float *vote_label, const float *vote_mask, const float *agg_xyz,
                                         const float *center_label, const float *obj_scores, const float *pred_center,
@@ -282,11 +315,11 @@ extern "C" int vlp3d_grounding_loss_fwd(const float *vote_xyz, const float *seed
                 cluster_ref, ref_center, B, S, N, K, G, L, near_thr, far_thr, w0, w1, huber_delta, w_obj, w_ref};
   if (bad(a) || !sums || !out5) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, NSUMS * sizeof(double), s);
-  if (e != hipSuccess) return (int)e;
   const int nbv = (int)(((long long)B * S + 255) / 256), nbp = (int)(((long long)B * K + 255) / 256);
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nbv + nbp + B * L), dim3(256), 0, s, a, sums, nbv, nbp);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums, w_obj, w_ref, B * L, out5);
+  const int nblocks = nbv + nbp + B * L;
+  double *part = sums + NSUMS;  // sums: [7 totals | nblocks x 7 workgroup rows]
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nblocks), dim3(256), 0, s, a, part, nbv, nbp);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblocks, sums, w_obj, w_ref, B * L, out5);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

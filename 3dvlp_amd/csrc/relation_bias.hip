@@ -20,6 +20,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HID = 32;
 constexpr int NPARAM = 4 * HID + HID + HID + HID + HID * HID + HID + HID + HID + 4 * HID + 4;  // 1476
+static_assert(NPARAM % 4 == 0, "slab_sum_kernel reads the slabs as float4");
 // offsets inside one parameter(-gradient) block
 constexpr int O_W1 = 0, O_B1 = 128, O_G1 = 160, O_E1 = 192, O_W2 = 224, O_B2 = 1248, O_G2 = 1280, O_E2 = 1312,
               O_W3 = 1344, O_B3 = 1472;
@@ -364,18 +365,32 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
     G[i] = (lds[i] + lds[NPARAM + i]) + (lds[2 * NPARAM + i] + lds[3 * NPARAM + i]);
 }
 
-// out[i] = sum_k slabs[k][i]: 256 threads = 4 slab-groups x 64 consecutive elements
+// out[i] = sum_k slabs[k][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups, then folds
+// the groups through LDS (n % 4 == 0).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ slabs, int nslab, int n,
                                                        float *__restrict__ out) {
-  __shared__ float red[4][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (i < n)
-    for (int k = grp; k < nslab; k += 4) s += slabs[(long long)k * n + i];
-  red[grp][col] = s;
+  __shared__ float4 red[16][16];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 64 + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+#pragma unroll 4
+    for (int k = grp; k < nslab; k += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(slabs + (long long)k * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[grp][q] = s;
   __syncthreads();
-  if (grp == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (grp == 0 && i < n) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {
+      const float4 v = red[g][q];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + i) = t;
+  }
 }
 
 }  // namespace

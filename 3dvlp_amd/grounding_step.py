@@ -113,7 +113,8 @@ class _LossCore(torch.autograd.Function):
         seed_inds = seed_inds.contiguous().int()
         B, S = seed_inds.shape
         N, K, G, L = vote_mask.shape[1], agg_xyz.shape[1], center_label.shape[1], ref_center.shape[1]
-        sums = torch.empty((7,), dtype=torch.float64, device=vote_xyz.device)
+        nsum = int(_ext.load().vlp3d_grounding_loss_sums(B, S, K, L))
+        sums = torch.empty((nsum,), dtype=torch.float64, device=vote_xyz.device)
         out = torch.empty((5,), dtype=torch.float32, device=vote_xyz.device)
         args = (vote_xyz, seed_xyz, seed_inds, vote_label, vote_mask, agg_xyz, center_label, obj_scores, pred_center,
                 cluster_ref, ref_center, B, S, N, K, G, L, *_LossCore.CONSTS)

@@ -201,9 +201,11 @@ int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int 
  * vote_xyz, seed_xyz (B,S,3); seed_inds (B,S) i32 into the N input points; vote_label (B,N,9), vote_mask (B,N) f32;
  * agg_xyz (B,K,3); center_label (B,G,3); obj_scores (B,K,2); pred_center (B,K,3).
  * fwd -> out5 = [vote, objectness, centre, reference, vote + w_obj*objectness + centre + w_ref*reference];
- *        sums: 7 doubles (numerators / denominators), kept for backward.
+ *        sums: vlp3d_grounding_loss_sums(B,S,K,L) doubles of scratch; the first 7 (numerators / denominators) are
+ *        kept for backward.
  * bwd: gout = device scalar d/d(out5[4]) (NULL = 1) -> d_vote (B,S,3), d_obj (B,K,2), d_center (B,K,3),
  *      d_ref (B*L,K), all fully written. */
+long long vlp3d_grounding_loss_sums(int B, int S, int K, int L);
 int vlp3d_grounding_loss_fwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds, const float *vote_label,
                              const float *vote_mask, const float *agg_xyz, const float *center_label,
                              const float *obj_scores, const float *pred_center, const float *cluster_ref,
