@@ -91,7 +91,8 @@ struct RowGemmArgs {
   const float *pool_g;   // (BM x ldin): dP where out > 0, else 0 (written by pool_tstats)
   const unsigned char *pool_sel;
   int pool_S, pool_shift;  // pool_shift = log2(pool_S) when it is a power of two, else -1
-  int S_shift;             // GATHER in wgrad: log2(S) when S is a power of two, else -1
+  int S_shift;             // GATHER: log2(S) when S is a power of two, else -1
+  int tile_scene;          // GATHER in row_gemm_lds: 1 when M*S % 32 == 0 (a 32-row tile never straddles two scenes)
   int ldw;                 // BIAS_WT: the weight is given K-major, (K x ldw) row-major (dX = dY W without a transpose)
 };
 
@@ -472,9 +473,67 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
   constexpr bool HOIST = (LOADER == BNRELU || LOADER == BNBWD) && !(LOADER == BNRELU && COUT >= 256);
   float ca[8], cb[8], cc[8];
   hoist_consts<HOIST ? LOADER : GATHER>(a, (lane % kc) * 8, ca, cb, cc);
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+  // GATHER fast path (tile_scene): the chunk -> (row, column) map of a lane does not depend on the tile, the scene index
+  // is a per-tile scalar and the ball-query indices of the NEXT tile are fetched while this one is computed.  The
+  // generic path below spends three integer divisions per chunk (27 per lane and tile at SA1 — more VALU work than
+  // the tile's matrix products) and waits for idx before it can ask for a feature row.
+  constexpr int MAXCH = 10;  // chunks per lane: 32 * (K/8) / 64, K <= 160
+  const bool fastg = LOADER == GATHER && a.tile_scene && nch <= 64 * MAXCH;
+  int crow[MAXCH], ccol[MAXCH], pidx[MAXCH];
+  const long long tile_step = (long long)gridDim.x * 4;
+  if (fastg) {
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+      const int c = min(64 * u + lane, nch - 1);
+      crow[u] = c / kc;
+      ccol[u] = (c - crow[u] * kc) * 8;
+    }
+    const long long t0 = (long long)blockIdx.x * 4 + wave;
+    if (t0 < ntiles) {
+#pragma unroll
+      for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t0 * 32 + crow[u]];
+    }
+  }
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
     const int row0 = (int)(tile * 32);
-    for (int c0 = 0; c0 < nch; c0 += 256) {
+    if (fastg) {
+      const int scene = row0 / (a.M * a.S);  // wave-uniform (R < 2^31)
+      const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
+      const float *xbase = a.xyz + (long long)scene * a.N * 3;
+      const long long tnext = tile + tile_step < ntiles ? tile + tile_step : tile;
+      for (int u0 = 0; u0 < MAXCH; u0 += 5) {
+        float4 v0[5], v1[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {  // five chunk pairs in flight, addresses need no further loads
+          const int uu = u0 + u;
+          const float *fr = fbase + (long long)pidx[uu] * a.C;
+          const int col = ccol[uu];
+          v0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          v1[u] = v0[u];
+          if (64 * uu < nch) {  // uniform
+            if (col < a.C) v0[u] = ld4(fr + col);
+            if (col + 4 < a.C) v1[u] = ld4(fr + col + 4);
+            if (col == a.C || col + 4 == a.C) {  // the [dx, dy, dz, 0] chunk
+              const float *q = xbase + (long long)pidx[uu] * 3;
+              const int rr = row0 + crow[uu];
+              const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+              const float *cc3 = a.new_xyz + (long long)bm * 3;
+              const float4 g = make_float4((q[0] - cc3[0]) / a.radius, (q[1] - cc3[1]) / a.radius,
+                                           (q[2] - cc3[2]) / a.radius, 0.f);
+              if (col == a.C) v0[u] = g; else v1[u] = g;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int uu = u0 + u;
+          if (64 * uu + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[uu] * ldw + ccol[uu]) = pack8(v0[u], v1[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[tnext * 32 + crow[u]];  // in flight during the MFMAs / epilogue
+    }
+    for (int c0 = 0; !fastg && c0 < nch; c0 += 256) {
       if (HOIST) {
         Raw8 raw[4];
 #pragma unroll
@@ -1248,6 +1307,8 @@ extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const
   a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feat_pm = feat_pm;
   a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
   a.W = W; a.K = K; a.R = (long long)B * M * S; a.Yout = Y; a.ldout = cout; a.stats = stats;
+  a.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
+  a.tile_scene = (((long long)M * S) & 31) == 0;
   return bf16_io ? launch_row_gemm<bf16>(GATHER, STORE, cout, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(GATHER, STORE, cout, a, (hipStream_t)stream);
 }
