@@ -290,21 +290,29 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
           st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, acc[ct][i] + bv);
       }
     } else {  // SCATTER: columns [0,C) -> d(features), [C,C+3) -> d(xyz), the rest is padding
+      // 32-bit index math, the scene index once per tile when a tile cannot straddle scenes: the 64-bit divisions per
+      // accumulator row were 32 multi-instruction sequences per lane and tile
+      const int trow0 = (int)(tile * 32);
+      const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
+      int pr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[i] = a.idx[trow0 + acc_row(i, half)];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const long long rr = tile * 32 + acc_row(i, half);
-        const long long bm = rr / a.S, b = bm / a.M;
-        const long long p = a.idx[rr];
+        const int rr = trow0 + acc_row(i, half);
+        const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+        const int b = tscene >= 0 ? tscene : bm / a.M;
+        const long long pn = (long long)b * a.N + pr[i];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const int col = 32 * ct + r;
           const float v = acc[ct][i];
           if (col < a.C) {
-            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + (b * a.N + p) * a.C + col, v);
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
           } else if (col < a.C + 3) {
             const float gv = v / a.radius;
-            if (a.dxyz) atomicAdd(a.dxyz + (b * a.N + p) * 3 + (col - a.C), gv);
-            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + bm * 3 + (col - a.C), -gv);
+            if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
+            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
           }
         }
       }
@@ -635,21 +643,29 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
         *reinterpret_cast<uint4 *>(G + (long long)row * a.ldout + ch * 8) = *reinterpret_cast<const uint4 *>(sA + row * lde + ch * 8);
       }
     } else {
+      // 32-bit index math, the scene index once per tile when a tile cannot straddle scenes: the 64-bit divisions per
+      // accumulator row were 32 multi-instruction sequences per lane and tile
+      const int trow0 = (int)(tile * 32);
+      const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
+      int pr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[i] = a.idx[trow0 + acc_row(i, half)];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const long long rr = tile * 32 + acc_row(i, half);
-        const long long bm = rr / a.S, b = bm / a.M;
-        const long long p = a.idx[rr];
+        const int rr = trow0 + acc_row(i, half);
+        const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+        const int b = tscene >= 0 ? tscene : bm / a.M;
+        const long long pn = (long long)b * a.N + pr[i];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const int col = 32 * ct + r;
           const float v = acc[ct][i];
           if (col < a.C) {
-            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + (b * a.N + p) * a.C + col, v);
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
           } else if (col < a.C + 3) {
             const float gv = v / a.radius;
-            if (a.dxyz) atomicAdd(a.dxyz + (b * a.N + p) * 3 + (col - a.C), gv);
-            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + bm * 3 + (col - a.C), -gv);
+            if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
+            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
           }
         }
       }
@@ -1400,6 +1416,8 @@ extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const f
   a.rstd = bn5; a.nmean_rstd = bn5 + ld; a.k1 = bn5 + 2 * ld; a.k2 = bn5 + 3 * ld; a.k3 = bn5 + 4 * ld;
   a.W = WT; a.K = ld; a.R = (long long)B * M * S;
   a.idx = idx; a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
+  a.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
+  a.tile_scene = (((long long)M * S) & 31) == 0;
   a.dfeat_pm = dfeat_pm; a.dxyz = dxyz; a.dnew_xyz = dnew_xyz;
   return bf16_io ? launch_row_gemm<bf16>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream);
