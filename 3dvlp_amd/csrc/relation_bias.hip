@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void relation_bias_fwd_kernel(const float *__r
   const float *P = sp;
   const long long total = (long long)B * K * K;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int j = (int)(t % K);
-    const int i = (int)((t / K) % K);
-    const int b = (int)(t / ((long long)K * K));
+    const unsigned tu = (unsigned)t;  // B*K*K < 2^32 (host-checked): 32-bit divisions
+    const int j = (int)(tu % (unsigned)K);
+    const int i = (int)((tu / (unsigned)K) % (unsigned)K);
+    const int b = (int)(tu / ((unsigned)K * (unsigned)K));
     Fwd f;
     pair_input(centre, b, i, j, K, f.x);
     mlp_forward<true>(P, f);
@@ -199,9 +200,10 @@ __global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__r
     const long long t = tile * 32 + r;
     const bool ok = t < total;
     const long long tc = ok ? t : total - 1;
-    const int j = (int)(tc % K);
-    const int i = (int)((tc / K) % K);
-    const int b = (int)(tc / ((long long)K * K));
+    const unsigned tu = (unsigned)tc;  // B*K*K < 2^32 (host-checked): 32-bit divisions
+    const int j = (int)(tu % (unsigned)K);
+    const int i = (int)((tu / (unsigned)K) % (unsigned)K);
+    const int b = (int)(tu / ((unsigned)K * (unsigned)K));
     float x[4];
     pair_input(centre, b, i, j, K, x);
     // ---- forward, layer 1 (K = 4: vector unit) + LN1
@@ -401,7 +403,7 @@ extern "C" int vlp3d_relation_bias_nparam(void) { return NPARAM; }
 // centre (B,K,3) -> out (B,4,K,K)
 extern "C" int vlp3d_relation_bias_fwd(const float *centre, const float *params, int B, int K, float *out,
                                        void *stream) {
-  if (!centre || !params || !out || B < 1 || K < 1) return VLP3D_EINVAL;
+  if (!centre || !params || !out || B < 1 || K < 1 || (long long)B * K * K >= (1ll << 32)) return VLP3D_EINVAL;
   const long long total = (long long)B * K * K;
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -414,7 +416,9 @@ extern "C" int vlp3d_relation_bias_fwd(const float *centre, const float *params,
 // dout (B,4,K,K) -> dparams (NPARAM); slabs: scratch of at least nblocks*NPARAM floats (nblocks >= 1).
 extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
                                        float *dparams, float *slabs, int nblocks, void *stream) {
-  if (!centre || !params || !dout || !dparams || !slabs || B < 1 || K < 1 || nblocks < 1) return VLP3D_EINVAL;
+  if (!centre || !params || !dout || !dparams || !slabs || B < 1 || K < 1 || nblocks < 1 ||
+      (long long)B * K * K >= (1ll << 32))
+    return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long long ntiles = ((long long)B * K * K + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
