@@ -544,17 +544,18 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
     for (int c0 = 0; !fastg && c0 < nch; c0 += 256) {
       if (HOIST) {
         Raw8 raw[4];
+        const int kshift = __builtin_ctz(kc);  // kc | 64: a power of two (shifts instead of eight divisions per batch)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
           const int c = min(c0 + 64 * u + lane, nch - 1);
-          const int row = c / kc, ch = c - row * kc;
+          const int row = c >> kshift, ch = c & (kc - 1);
           raw_load8<LOADER>(a, row0 + row, ch * 8, raw[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int c = c0 + 64 * u + lane;
           if (c < nch) {
-            const int row = c / kc, ch = c - row * kc;
+            const int row = c >> kshift, ch = c & (kc - 1);
             *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish8<LOADER>(a, row0 + row, raw[u], ca, cb, cc);
           }
         }
