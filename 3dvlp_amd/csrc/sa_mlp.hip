@@ -877,6 +877,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   constexpr int MAXE_A = 9;                              // 32 * KP / 4 / 256 with KP <= 288
   const int KF = (LOADER == GATHER) ? w.src.C : K;       // columns read as plain 16-byte row slices
   const int kf4 = KF / 4, nef = 32 * kf4;
+  // row of staging element e: K/4 is a power of two for the BN+ReLU / plain operands (host-checked: 256 % (K/4) == 0)
+  const int kfs = (LOADER == GATHER) ? 0 : __builtin_ctz(kf4);
+  auto row_of = [&](int e) -> int { return LOADER == GATHER ? e / kf4 : e >> kfs; };
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[NE_DY], va[MAXE_A], vt;
 
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
-      pidx[j] = w.src.idx[row0 + e / kf4];
+      pidx[j] = w.src.idx[row0 + row_of(e)];
     }
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
     tp = w.src.idx[row0 + te / max(tc, 1)];
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
-      const int row = e / kf4, k0 = (e - row * kf4) * 4;
+      const int row = row_of(e), k0 = (e - row * kf4) * 4;
       const int rr = row0 + row;
       if (LOADER == GATHER) {
         va[j] = ld4(w.src.feat_pm + (pbase + pidx[j]) * w.src.C + k0);
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       for (int j = 0; j < MAXE_A; ++j) {
         const int e = threadIdx.x + 256 * j;
         if (e < nef) {
-          const int row = e / kf4;
+          const int row = row_of(e);
           *reinterpret_cast<uint2 *>(ldb_a + row * RSA + (e - row * kf4) * 4) = pack4(va[j]);
         }
       }
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       for (int j = 0; j < MAXE_A; ++j) {
         const int e = threadIdx.x + 256 * j;
         if (e < nef) {
-          const int row = e / kf4;
+          const int row = row_of(e);
           *reinterpret_cast<float4 *>(lds_a + row * KP + (e - row * kf4) * 4) = va[j];
         }
       }
@@ -1440,7 +1443,7 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
     w.src.N = N; w.src.M = M; w.src.S = S; w.src.C = C; w.src.radius = radius;
     w.src.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   } else {
-    if (!Yprev || !scale || !shift || (256 % (K / 4))) return VLP3D_EINVAL;  // fixed staging columns per thread
+    if (!Yprev || !scale || !shift || (256 % (K / 4)) || ((K / 4) & (K / 4 - 1))) return VLP3D_EINVAL;  // fixed staging columns per thread, shift-indexed rows
     w.src.Yin = Yprev; w.src.ldin = K; w.src.scale = scale; w.src.shift = shift;
   }
   w.dy.Gin = G; w.dy.Yin = Y; w.dy.ldin = cout;
@@ -1603,7 +1606,7 @@ extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, 
 extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                                   int max_blocks, int with_bias, void *stream) {
   if (!dY || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
-      (N & 31))
+      ((K / 4) & (K / 4 - 1)) || (N & 31))  // K/4 a power of two: the staging row index is a shift
     return VLP3D_EINVAL;
   WgradArgs w = {};
   w.colsum = with_bias != 0;

@@ -16,13 +16,14 @@ _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumula
 WGRAD_BLOCKS = 256     # at most this many workgroups (= partial [dW | db] slabs)
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256)
+_WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
 
 
 def supported(x, weight):
     R = x.numel() // x.shape[-1]
     N, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
-            and K % 8 == 0 and N in _WGRAD_N and K in _FWD_N and 32 * (N + ((K + 31) // 32) * 32) * 4 <= 65536)
+            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K and 32 * (N + ((K + 31) // 32) * 32) * 4 <= 65536)
 
 
 class _Linear(Function):
