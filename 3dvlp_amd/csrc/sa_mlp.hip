@@ -874,7 +874,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   // predicated — hipcc otherwise branches around each load and waits vmcnt(0) per element, serialising them.
   static_assert((32 * COUT / 4) % 256 == 0, "dY tile must split evenly over 256 threads");
   constexpr int NE_DY = 32 * COUT / 4 / 256;
-  constexpr int MAXE_A = 9;                              // 32 * KP / 4 / 256 with KP <= 288
+  // staging elements of the A tile per thread = 32*KP/4/256 = KP/32 = NKT <= 4*MAXT/NCT (MAXT >= NCT*NKT/4): sized by
+  // the instantiation instead of the worst case 9 (five float4 of dead loads and registers at K = 128)
+  constexpr int MAXE_A = (4 * MAXT / NCT) < 1 ? 1 : ((4 * MAXT / NCT) < 9 ? (4 * MAXT / NCT) : 9);
   const int KF = (LOADER == GATHER) ? w.src.C : K;       // columns read as plain 16-byte row slices
   const int kf4 = KF / 4, nef = 32 * kf4;
   // row of staging element e: K/4 is a power of two for the BN+ReLU / plain operands (host-checked: 256 % (K/4) == 0)
@@ -883,8 +885,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[NE_DY], va[MAXE_A], vt;
 
+  // column-block mode (gridDim.y > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
+  // runs as two 128-wide halves (64 instead of 144 accumulator registers: three waves per SIMD instead of one)
+  const int coff = blockIdx.y * COUT;
   DyConsts<T> dyk;
-  if (DYL == BNBWD) dyk.load(w.dy, (threadIdx.x % (COUT / 4)) * 4);
+  if (DYL == BNBWD) dyk.load(w.dy, coff + (threadIdx.x % (COUT / 4)) * 4);
   float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;
   if (LOADER == BNRELU) {
     const int k0 = (threadIdx.x % kf4) * 4;
@@ -924,7 +929,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < NE_DY; ++j) {
       const int e = threadIdx.x + 256 * j;
-      vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), (e % (COUT / 4)) * 4, dyk);
+      vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), coff + (e % (COUT / 4)) * 4, dyk);
     }
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
@@ -1032,7 +1037,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   }
   // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
   // thousands of workgroups atomically adding into the same 36 KB matrix run an order of magnitude slower
-  float *slab = w.partials + (long long)blockIdx.x * (COUT * K + (w.colsum ? COUT : 0));
+  float *slab = w.partials + (long long)blockIdx.x * ((long long)COUT * gridDim.y * K + (w.colsum ? COUT : 0)) +
+                (long long)coff * K;
   if (!BF && w.colsum && (int)threadIdx.x < COUT) slab[COUT * K + threadIdx.x] = csum;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
@@ -1304,6 +1310,10 @@ int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
   const dim3 grid((unsigned)nblk);
   const size_t lds = sizeof(T) == 2 ? (size_t)32 * (cout + w.KP + 8) * 2 : (size_t)32 * (cout + w.KP) * sizeof(float);
   if (lds > 64 * 1024) return VLP3D_EINVAL;
+  if (sizeof(T) == 2 && cout == 256) {  // two 128-column halves (see the kernel: coff)
+    const size_t lds_half = (size_t)32 * (128 + w.KP + 8) * 2;
+    return launch_wgrad_c<T, LOADER, 128>(w, s, dim3(grid.x, 2), lds_half);
+  }
   switch (cout) {
     case 64: return launch_wgrad_c<T, LOADER, 64>(w, s, grid, lds);
     case 128: return launch_wgrad_c<T, LOADER, 128>(w, s, grid, lds);
