@@ -448,8 +448,10 @@ __device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Ra
   return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
 }
 
+// second launch bound: at least two waves per SIMD for outputs up to 160 columns (the register allocator otherwise
+// settles just above 256 registers for <128, BNBWD, MASK>: one wave per SIMD on a latency-bound kernel)
 template <int COUT, int LOADER, int EPI>
-__global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
+__global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kernel(RowGemmArgs a) {
   typedef bf16 T;
   constexpr int NCT = COUT / 32;
   constexpr int CC = COUT / 8;  // 16-byte chunks per output row
@@ -541,18 +543,21 @@ __global__ __launch_bounds__(256) void row_gemm_lds_kernel(RowGemmArgs a) {
 #pragma unroll
       for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[tnext * 32 + crow[u]];  // in flight during the MFMAs / epilogue
     }
-    for (int c0 = 0; !fastg && c0 < nch; c0 += 256) {
+    // chunks in flight per lane: four, two for the wide BN-backward kernels (their raw operands — y, g or the pooled
+    // triple — at four in flight pushed the kernel over 256 registers: one wave per SIMD)
+    constexpr int UB = (LOADER == BNBWD && COUT >= 128) ? 2 : 4;
+    for (int c0 = 0; !fastg && c0 < nch; c0 += (HOIST ? 64 * UB : 256)) {
       if (HOIST) {
-        Raw8 raw[4];
+        Raw8 raw[UB];
         const int kshift = __builtin_ctz(kc);  // kc | 64: a power of two (shifts instead of eight divisions per batch)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
+        for (int u = 0; u < UB; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
           const int c = min(c0 + 64 * u + lane, nch - 1);
           const int row = c >> kshift, ch = c & (kc - 1);
           raw_load8<LOADER>(a, row0 + row, ch * 8, raw[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UB; ++u) {
           const int c = c0 + 64 * u + lane;
           if (c < nch) {
             const int row = c >> kshift, ch = c & (kc - 1);
