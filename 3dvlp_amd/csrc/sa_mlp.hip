@@ -1042,9 +1042,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   }
   // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
   // thousands of workgroups atomically adding into the same 36 KB matrix run an order of magnitude slower
-  float *slab = w.partials + (long long)blockIdx.x * ((long long)COUT * gridDim.y * K + (w.colsum ? COUT : 0)) +
-                (long long)coff * K;
-  if (!BF && w.colsum && (int)threadIdx.x < COUT) slab[COUT * K + threadIdx.x] = csum;
+  // slab of this row chunk: [Ntot x K | Ntot bias sums (colsum)] with Ntot = COUT * gridDim.y; this workgroup fills
+  // rows coff .. coff + COUT of the matrix and its part of the bias segment
+  const long long ntot = (long long)COUT * gridDim.y;
+  float *slab0 = w.partials + (long long)blockIdx.x * (ntot * K + (w.colsum ? ntot : 0));
+  float *slab = slab0 + (long long)coff * K;
+  if (!BF && w.colsum && (int)threadIdx.x < COUT) slab0[ntot * K + coff + threadIdx.x] = csum;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = wave + 4 * i;
@@ -1636,14 +1639,20 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   const int nblk = (int)((ntiles + tpb - 1) / tpb);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nblk);
-  const size_t lds = (size_t)32 * (N + w.KP) * sizeof(float);
-  if (lds > 64 * 1024) return VLP3D_EINVAL;
   int st;
-  switch (N) {
-    case 64: st = launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds); break;
-    case 128: st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, grid, lds); break;
-    case 256: st = launch_wgrad_c<float, PLAIN, 256, PLAIN>(w, s, grid, lds); break;
-    default: return VLP3D_EINVAL;
+  if (N > 256 && N % 128 == 0 && N <= 1024) {  // wide (merged q/k/v) layers: 128-column workgroup blocks
+    const size_t lds128 = (size_t)32 * (128 + w.KP) * sizeof(float);
+    if (lds128 > 64 * 1024) return VLP3D_EINVAL;
+    st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, dim3((unsigned)nblk, N / 128), lds128);
+  } else {
+    const size_t lds = (size_t)32 * (N + w.KP) * sizeof(float);
+    if (lds > 64 * 1024) return VLP3D_EINVAL;
+    switch (N) {
+      case 64: st = launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds); break;
+      case 128: st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, grid, lds); break;
+      case 256: st = launch_wgrad_c<float, PLAIN, 256, PLAIN>(w, s, grid, lds); break;
+      default: return VLP3D_EINVAL;
+    }
   }
   if (st != VLP3D_OK) return st;
   const int n = N * K + (with_bias ? N : 0);

@@ -15,7 +15,7 @@ _ext.load()
 _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
 WGRAD_BLOCKS = 256     # at most this many workgroups (= partial [dW | db] slabs)
 _FWD_N = (32, 64, 128, 160, 256, 288)
-_WGRAD_N = (64, 128, 256)
+_WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
 
 
@@ -23,7 +23,7 @@ def supported(x, weight):
     R = x.numel() // x.shape[-1]
     N, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
-            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K and 32 * (N + ((K + 31) // 32) * 32) * 4 <= 65536)
+            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K and 32 * (min(N, 128 if N > 256 else N) + ((K + 31) // 32) * 32) * 4 <= 65536)
 
 
 class _Linear(Function):

@@ -324,7 +324,7 @@ def test_geometry_pipeline_and_graph_equal_inline_step():
     assert losses["inline"][2] < losses["inline"][0]
 
 
-@pytest.mark.parametrize("R,K,N", [(16384, 128, 128), (3136, 128, 128), (2048, 128, 256), (2048, 256, 128), (64, 64, 64)])
+@pytest.mark.parametrize("R,K,N", [(16384, 128, 128), (3136, 128, 128), (2048, 128, 256), (2048, 256, 128), (64, 64, 64), (16384, 128, 384), (2048, 128, 512)])
 def test_mfma_linear_equals_f_linear(R, K, N):
     ml = importlib.import_module("3dvlp_amd.mfma_linear")
     torch.manual_seed(R + K)
