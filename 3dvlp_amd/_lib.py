@@ -63,9 +63,9 @@ SIGNATURES = {
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],
     "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
-    "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                       _i, _vp],
+                       _i, _i, _i, _i, _vp],
 }
 
 _lib = None
@@ -278,10 +278,32 @@ def _opt(t):
     return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _row_stride(t, name):
+    """Row stride (floats) of a (B, n, C) float32 CUDA tensor whose rows are contiguous and evenly spaced — a contiguous
+    tensor or a column block of one (e.g. q / k / v slices of a merged projection)."""
+    if not t.is_cuda:
+        raise RuntimeError("CPU not supported")
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) \
+            or t.stride(1) % 4 or t.data_ptr() % 16:
+        raise RuntimeError(name + " must be a float tensor with contiguous, evenly spaced, 16-byte aligned rows")
+    return t.stride(1)
+
+
+def _row_stride_ok(t):
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1
+            and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0)
+
+
+def _adjacent(a, b):
+    """b is the column block right after a in the same row-strided buffer."""
+    return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.stride() == b.stride()
+            and a.shape[:2] == b.shape[:2] and b.storage_offset() == a.storage_offset() + a.shape[2])
+
+
 def sdpa_fwd(q, k, v, H, bias, bias_mode, mask, bf16_mma=False):
-    """q (B,nq,H*32), k/v (B,nk,H*32) -> (out (B,nq,H*32), lse (B,H,nq))."""
-    for name, t in (("q", q), ("k", k), ("v", v)):
-        _chk_float(t, name)
+    """q (B,nq,H*32), k/v (B,nk,H*32), each contiguous or a column block of a wider buffer
+    -> (out (B,nq,H*32) contiguous, lse (B,H,nq))."""
+    ldq, ldk, ldv = _row_stride(q, "q"), _row_stride(k, "k"), _row_stride(v, "v")
     _chk_dev(q, ("k", k), ("v", v))
     B, nq, HD = q.shape
     nk = k.shape[1]
@@ -291,25 +313,46 @@ def sdpa_fwd(q, k, v, H, bias, bias_mode, mask, bf16_mma=False):
             raise RuntimeError("attention_weights must be (b_s, h, nq, nk)")
     if mask is not None:
         _chk_float(mask, "attention_mask")
-    out = torch.empty_like(q)
+    out = torch.empty((B, nq, HD), dtype=torch.float32, device=q.device)
     lse = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         _check(load().vlp3d_sdpa_fwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), B, H, nq, nk,
-                                     HD // H, _p(out), _p(lse), int(bool(bf16_mma)), _stream()), "sdpa_fwd")
+                                     HD // H, _p(out), _p(lse), int(bool(bf16_mma)), ldq, ldk, ldv, _stream()),
+               "sdpa_fwd")
     return out, lse
 
 
 def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias, bf16_mma=False):
+    """Gradients with the layout of their inputs: when q, k, v (or k, v) are adjacent column blocks of one buffer, dq, dk,
+    dv (dk, dv) are column blocks of ONE gradient buffer, i.e. already the dY of the merged projection."""
+    ldq, ldk, ldv = _row_stride(q, "q"), _row_stride(k, "k"), _row_stride(v, "v")
     B, nq, HD = q.shape
     nk = k.shape[1]
     _chk_float(dout, "dout")
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    new = lambda n, c: torch.empty((B, n, c), dtype=torch.float32, device=q.device)
+    if _adjacent(q, k) and _adjacent(k, v) and ldq == 3 * HD:
+        g = new(nq, 3 * HD)
+        dq, dk, dv = g[..., :HD], g[..., HD:2 * HD], g[..., 2 * HD:]
+    elif _adjacent(k, v) and ldk == 2 * HD:
+        g = new(nk, 2 * HD)
+        dq, dk, dv = new(nq, HD), g[..., :HD], g[..., HD:]
+        ldq = HD
+    else:
+        dq, dk, dv = new(nq, HD), new(nk, HD), new(nk, HD)
+        ldq = ldk = ldv = HD
+    # forward operands keep their own strides; the gradient strides follow the buffers allocated above
+    gq, gk, gv = dq.stride(1), dk.stride(1), dv.stride(1)
+    if (gq, gk, gv) != (_row_stride(q, "q"), _row_stride(k, "k"), _row_stride(v, "v")):
+        # the kernels use one stride per operand for input and gradient: fall back to contiguous copies of the inputs
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        dq, dk, dv = new(nq, HD), new(nk, HD), new(nk, HD)
+        gq = gk = gv = HD
     dbias = torch.empty((B, H, nq, nk), dtype=torch.float32, device=q.device) if need_dbias else None
     delta = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         _check(load().vlp3d_sdpa_bwd(_p(q), _p(k), _p(v), _opt(bias), int(bias_mode), _opt(mask), _p(out), _p(lse),
                                      _p(dout), B, H, nq, nk, HD // H, _p(dq), _p(dk), _p(dv), _opt(dbias),
-                                     _p(delta), int(bool(bf16_mma)), _stream()), "sdpa_bwd")
+                                     _p(delta), int(bool(bf16_mma)), gq, gk, gv, _stream()), "sdpa_bwd")
     return dq, dk, dv, dbias
 
 

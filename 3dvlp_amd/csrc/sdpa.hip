@@ -94,8 +94,8 @@ template <bool BF>
 __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ v, const float *__restrict__ bias,
                                                       int bias_mode, const float *__restrict__ mask, int H, int nq,
-                                                      int nk, float scale, float *__restrict__ out,
-                                                      float *__restrict__ lse) {
+                                                      int nk, int ldq, int ldk, int ldv, float scale,
+                                                      float *__restrict__ out, float *__restrict__ lse) {
   const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int HD = H * D;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   const long long qrow = (long long)b * nq + qi;
 
   float qreg[16];
-  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(q, qrow, ldq, h, half, qreg);
 
   f32x16 o = zero16();
   float m = -__builtin_inff(), l = 0.f;
@@ -113,11 +113,11 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   // its key tiles alone; without this every tile exposes two full memory latencies)
   float kreg[16], vcol[16];
   auto load_tile = [&](int k0, float (&kr)[16], float (&vc)[16]) {
-    load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), HD, h, half, kr);
+    load_half_row(k, (long long)b * nk + min(k0 + r, nk - 1), ldk, h, half, kr);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = min(k0 + acc_row(i, half), nk - 1);  // p == 0 beyond nk
-      vc[i] = v[((long long)b * nk + key) * HD + h * D + r];
+      vc[i] = v[((long long)b * nk + key) * ldv + h * D + r];
     }
   };
   load_tile(0, kreg, vcol);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                            const float *__restrict__ v, const float *__restrict__ bias,
                                                            int bias_mode, const float *__restrict__ mask, int H, int nq,
-                                                           int nk, int nkp, float scale, float *__restrict__ out,
-                                                           float *__restrict__ lse) {
+                                                           int nk, int nkp, int ldq, int ldk, int ldv, float scale,
+                                                           float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) short sm_kv[];
   constexpr int KS = D + 8;        // K row stride (shorts): 80 B -> conflict-free b128 phases
   const int VS = nkp + 4;          // V^T row stride (shorts): (nkp/2 + 2) dwords -> conflict-free b64 phases
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
     const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (key < nk) {
-      const long long off = ((long long)b * nk + key) * HD + h * D + d4;
-      kv = *reinterpret_cast<const float4 *>(k + off);
-      vv = *reinterpret_cast<const float4 *>(v + off);
+      const long long krow = (long long)b * nk + key;
+      kv = *reinterpret_cast<const float4 *>(k + krow * ldk + h * D + d4);
+      vv = *reinterpret_cast<const float4 *>(v + krow * ldv + h * D + d4);
     }
     short4 kb;
     kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
   const int qi = min(q0 + r, nq - 1);
   const long long qrow = (long long)b * nq + qi;
   float qreg[16];
-  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(q, qrow, ldq, h, half, qreg);
   bf16x8 qa[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -296,8 +296,8 @@ template <bool BF>
 __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
-    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, float scale,
-    float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
+    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, int ldq, int ldk, int ldv,
+    float scale, float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
   const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int HD = H * D;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
   const bool q_ok = q0 + r < nq;
 
   float qreg[16], doreg[16], oreg[16];
-  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(q, qrow, ldq, h, half, qreg);
   load_half_row(dout, qrow, HD, h, half, doreg);
   load_half_row(out, qrow, HD, h, half, oreg);
   float dl = 0.f;
@@ -322,12 +322,12 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
   float kreg[16], vreg[16], kcol[16];
   auto load_tile = [&](int k0, float (&kr)[16], float (&vr)[16], float (&kc)[16]) {
     const long long krow = (long long)b * nk + min(k0 + r, nk - 1);
-    load_half_row(k, krow, HD, h, half, kr);
-    load_half_row(v, krow, HD, h, half, vr);
+    load_half_row(k, krow, ldk, h, half, kr);
+    load_half_row(v, krow, ldv, h, half, vr);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = min(k0 + acc_row(i, half), nk - 1);
-      kc[i] = k[((long long)b * nk + key) * HD + h * D + r];
+      kc[i] = k[((long long)b * nk + key) * ldk + h * D + r];
     }
   };
   load_tile(0, kreg, vreg, kcol);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
     }
   }
   if (q_ok) {
-    float *__restrict__ row = dq + qrow * HD + h * D;
+    float *__restrict__ row = dq + qrow * ldq + h * D;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 w;
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
-    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, int nkp, float scale,
-    float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
+    const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, int nkp, int ldq, int ldk,
+    int ldv, float scale, float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) short sm_kv[];
   constexpr int KS = D + 8;
   const int TS = nkp + 4;
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
     const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (key < nk) {
-      const long long off = ((long long)b * nk + key) * HD + h * D + d4;
-      kv = *reinterpret_cast<const float4 *>(k + off);
-      vv = *reinterpret_cast<const float4 *>(v + off);
+      const long long krow = (long long)b * nk + key;
+      kv = *reinterpret_cast<const float4 *>(k + krow * ldk + h * D + d4);
+      vv = *reinterpret_cast<const float4 *>(v + krow * ldv + h * D + d4);
     }
     short4 kb, vb;
     kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   const long long qrow = (long long)b * nq + qi;
   const bool q_ok = q0 + r < nq;
   float qreg[16], doreg[16], oreg[16];
-  load_half_row(q, qrow, HD, h, half, qreg);
+  load_half_row(q, qrow, ldq, h, half, qreg);
   load_half_row(dout, qrow, HD, h, half, doreg);
   load_half_row(out, qrow, HD, h, half, oreg);
   float dl = 0.f;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
     }
   }
   if (q_ok) {
-    float *__restrict__ row = dq + qrow * HD + h * D;
+    float *__restrict__ row = dq + qrow * ldq + h * D;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 w;
@@ -494,8 +494,8 @@ template <bool BF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sdpa_bwd_dkv_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
-    const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nk, float scale,
-    float *__restrict__ dk, float *__restrict__ dv) {
+    const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nk, int ldq, int ldk, int ldv,
+    float scale, float *__restrict__ dk, float *__restrict__ dv) {
   const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
   const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int HD = H * D;
@@ -505,8 +505,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
   const bool masked = mask != nullptr && mask[(long long)b * nk + ki] == 0.f;
 
   float kreg[16], vreg[16];
-  load_half_row(k, krow, HD, h, half, kreg);
-  load_half_row(v, krow, HD, h, half, vreg);
+  load_half_row(k, krow, ldk, h, half, kreg);
+  load_half_row(v, krow, ldv, h, half, vreg);
 
   f32x16 dka = zero16(), dva = zero16();
   // Rows of the next query tile are prefetched one tile ahead; the column-layout copies and the per-query
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
   float qreg[16], doreg[16];
   auto load_rows = [&](int q0, float (&qr)[16], float (&dr)[16]) {
     const long long qrow = (long long)b * nq + min(q0 + r, nq - 1);
-    load_half_row(q, qrow, HD, h, half, qr);
+    load_half_row(q, qrow, ldq, h, half, qr);
     load_half_row(dout, qrow, HD, h, half, dr);
   };
   load_rows(0, qreg, doreg);
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int qq = min(q0 + acc_row(i, half), nq - 1);
-      const long long row = ((long long)b * nq + qq) * HD + h * D + r;
-      docol[i] = dout[row];
-      qcol[i] = q[row];
+      const long long qr_ = (long long)b * nq + qq;
+      docol[i] = dout[qr_ * HD + h * D + r];
+      qcol[i] = q[qr_ * ldq + h * D + r];
       const long long stat = ((long long)b * H + h) * nq + qq;
       lse_t[i] = lse[stat];
       delta_t[i] = delta[stat];
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
     }
   }
   if (k_ok) {
-    float *__restrict__ rk = dk + krow * HD + h * D;
-    float *__restrict__ rv = dv + krow * HD + h * D;
+    float *__restrict__ rk = dk + krow * ldk + h * D;
+    float *__restrict__ rv = dv + krow * ldv + h * D;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 a, c;
@@ -575,6 +575,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
   }
 }
 
+// row strides (floats) of q / k / v (and of dq / dk / dv): >= H*D and a multiple of 4 (16-byte row slices)
+bool bad_ld(int ldq, int ldk, int ldv, int H) {
+  return ldq < H * D || ldk < H * D || ldv < H * D || ((ldq | ldk | ldv) & 3);
+}
+
 bool bad(int B, int H, int nq, int nk, int Dh, int bias_mode) {
   return B < 1 || B > 65535 || H < 1 || H > 65535 || nq < 1 || nk < 1 || Dh != D || bias_mode < 0 || bias_mode > 2;
 }
@@ -583,22 +588,23 @@ bool bad(int B, int H, int nq, int nk, int Dh, int bias_mode) {
 
 extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                               const float *mask, int B, int H, int nq, int nk, int Dh, float *out, float *lse,
-                              int bf16_mma, void *stream) {
+                              int bf16_mma, int ldq, int ldk, int ldv, void *stream) {
   if (!q || !k || !v || !out || !lse || bad(B, H, nq, nk, Dh, bias_mode) || (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
+  if (bad_ld(ldq, ldk, ldv, H)) return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   const dim3 grid(vlp3d_cdiv(nq, 32), H, B);
   if (bf16_mma && nk <= 384) {  // K/V of a head shared by 4 waves through LDS (<= 55 KB)
     const int nkp = (nk + 31) & ~31;
     const size_t lds = ((size_t)nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
     hipLaunchKernelGGL(sdpa_fwd_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, (hipStream_t)stream, q, k, v,
-                       bias, bias_mode, mask, H, nq, nk, nkp, scale, out, lse);
+                       bias, bias_mode, mask, H, nq, nk, nkp, ldq, ldk, ldv, scale, out, lse);
   } else if (bf16_mma)
     hipLaunchKernelGGL(sdpa_fwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask, H,
-                       nq, nk, scale, out, lse);
+                       nq, nk, ldq, ldk, ldv, scale, out, lse);
   else
     hipLaunchKernelGGL(sdpa_fwd_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask,
-                       H, nq, nk, scale, out, lse);
+                       H, nq, nk, ldq, ldk, ldv, scale, out, lse);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
@@ -606,10 +612,11 @@ extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, co
 extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                               const float *mask, const float *out, const float *lse, const float *dout, int B, int H,
                               int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
-                              int bf16_mma, void *stream) {
+                              int bf16_mma, int ldq, int ldk, int ldv, void *stream) {
   if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta || bad(B, H, nq, nk, Dh, bias_mode) ||
       (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
+  if (bad_ld(ldq, ldk, ldv, H)) return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(vlp3d_cdiv(nq, 32), H, B), gk(vlp3d_cdiv(nk, 32), H, B);
@@ -619,17 +626,17 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
       const int nkp = (nk + 31) & ~31;
       const size_t lds = ((size_t)2 * nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
       hipLaunchKernelGGL(sdpa_bwd_dq_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, s, q, k, v, bias,
-                         bias_mode, mask, out, lse, dout, H, nq, nk, nkp, scale, dq, dbias, delta);
+                         bias_mode, mask, out, lse, dout, H, nq, nk, nkp, ldq, ldk, ldv, scale, dq, dbias, delta);
     } else
       hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
-                         nq, nk, scale, dq, dbias, delta);
+                         nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
     hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
-                       H, nq, nk, scale, dk, dv);
+                       H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
   } else {
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel<false>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
-                       nq, nk, scale, dq, dbias, delta);
+                       nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
     hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<false>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
-                       H, nq, nk, scale, dk, dv);
+                       H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
   }
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

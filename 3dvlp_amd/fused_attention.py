@@ -41,7 +41,8 @@ def supported(d_k, d_v, attention_mask, nk):
 class _SDPA(Function):
     @staticmethod
     def forward(ctx, q, k, v, bias, H, bias_mode, mask, bf16_mma):
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        # q / k / v may be column blocks of one merged projection output (row-strided views): no copies
+        q, k, v = (t if _ext._row_stride_ok(t) else t.contiguous() for t in (q, k, v))
         bias = bias.contiguous() if bias is not None else None
         out, lse = _ext.sdpa_fwd(q, k, v, H, bias, bias_mode, mask, bf16_mma)
         ctx.save_for_backward(q, k, v, bias, mask, out, lse)
@@ -55,6 +56,57 @@ class _SDPA(Function):
         dq, dk, dv, dbias = _ext.sdpa_bwd(q, k, v, ctx.H, bias, ctx.bias_mode, mask, out, lse, dout.contiguous(),
                                           need_dbias, ctx.bf16_mma)
         return dq, dk, dv, dbias, None, None, None, None
+
+
+class _SDPAMerged(Function):
+    """Same core on MERGED projections: `a` is (b, n, 3*h*32) = [q | k | v] (self-attention, `b_` None) or `a` = q
+    (b, nq, h*32) and `b_` = [k | v] (b, nk, 2*h*32).  The column blocks go to the kernels as row-strided views and the
+    backward returns ONE gradient tensor per merged input — directly the dY of the merged linear layer (no split /
+    cat copies on either side)."""
+
+    @staticmethod
+    def forward(ctx, a, b_, bias, H, bias_mode, mask, bf16_mma):
+        HD = H * 32
+        a = a.contiguous()
+        if b_ is None:
+            q, k, v = a[..., :HD], a[..., HD:2 * HD], a[..., 2 * HD:]
+        else:
+            b_ = b_.contiguous()
+            q, k, v = a, b_[..., :HD], b_[..., HD:]
+        bias = bias.contiguous() if bias is not None else None
+        out, lse = _ext.sdpa_fwd(q, k, v, H, bias, bias_mode, mask, bf16_mma)
+        ctx.save_for_backward(a, b_, bias, mask, out, lse)
+        ctx.H, ctx.bias_mode, ctx.bf16_mma = H, bias_mode, bf16_mma
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b_, bias, mask, out, lse = ctx.saved_tensors
+        HD = ctx.H * 32
+        if b_ is None:
+            q, k, v = a[..., :HD], a[..., HD:2 * HD], a[..., 2 * HD:]
+        else:
+            q, k, v = a, b_[..., :HD], b_[..., HD:]
+        need_dbias = bias is not None and ctx.needs_input_grad[2]
+        dq, dk, dv, dbias = _ext.sdpa_bwd(q, k, v, ctx.H, bias, ctx.bias_mode, mask, out, lse, dout.contiguous(),
+                                          need_dbias, ctx.bf16_mma)
+        if b_ is None:
+            da, db = dq._base if dq._base is not None else torch.cat([dq, dk, dv], -1), None
+        else:
+            da, db = dq, (dk._base if dk._base is not None else torch.cat([dk, dv], -1))
+        return da, db, dbias, None, None, None, None
+
+
+def sdpa_merged(a, b_, h, attention_weights=None, way="add", attention_mask=None, bf16_mma=None):
+    """a = [q | k | v] merged (b_ None) or a = q, b_ = [k | v] merged; see _SDPAMerged."""
+    nk = a.shape[1] if b_ is None else b_.shape[1]
+    mask = _key_mask(attention_mask, a.shape[0], nk)
+    if mask is False:
+        raise RuntimeError("fused sdpa: unsupported attention_mask shape")
+    if mask is not None:
+        mask = mask.to(torch.float32).contiguous()
+    bias_mode = 0 if attention_weights is None else (1 if way == "add" else 2)
+    return _SDPAMerged.apply(a, b_, attention_weights, h, bias_mode, mask, BF16_MMA if bf16_mma is None else bool(bf16_mma))
 
 
 def sdpa(q, k, v, h, attention_weights=None, way="add", attention_mask=None, bf16_mma=None):

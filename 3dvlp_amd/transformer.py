@@ -29,6 +29,7 @@ class ScaledDotProductAttention(nn.Module):
         self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
         self.impl = impl
         self.bf16_mma = False  # True: bf16 MFMA operands in the fused core (timing configuration of the step driver)
+        self.merge_qkv = True  # one projection launch for inputs shared by q/k/v (self) or k/v (cross attention)
         for fc in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
             nn.init.xavier_uniform_(fc.weight)
             nn.init.constant_(fc.bias, 0)
@@ -40,13 +41,29 @@ class ScaledDotProductAttention(nn.Module):
         Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran)."""
         b_s, nq = queries.shape[:2]
         nk = keys.shape[1]
-        q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
-        k = _linear(keys, self.fc_k.weight, self.fc_k.bias)
-        v = _linear(values, self.fc_v.weight, self.fc_v.bias)
         if way not in ("add", "mul"):
             raise NotImplementedError(way)
         impl = self.impl or DEFAULT_IMPL
-        if impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk):
+        fused = impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk)
+        if fused and self.merge_qkv and keys is values and queries.is_cuda and queries.dtype == torch.float32:
+            # projections that read the same input run as ONE linear layer over concatenated weights (the parameters
+            # keep the reference's names): q|k|v for self-attention, k|v for cross-attention; the attention kernels
+            # take the column blocks as row-strided views and return one merged gradient
+            aw = None if attention_weights is None else attention_weights.float()
+            if queries is keys:
+                qkv = _linear(queries, torch.cat([self.fc_q.weight, self.fc_k.weight, self.fc_v.weight], 0),
+                              torch.cat([self.fc_q.bias, self.fc_k.bias, self.fc_v.bias], 0))
+                out = fused_attention.sdpa_merged(qkv, None, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
+            else:
+                q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
+                kv = _linear(keys, torch.cat([self.fc_k.weight, self.fc_v.weight], 0),
+                             torch.cat([self.fc_k.bias, self.fc_v.bias], 0))
+                out = fused_attention.sdpa_merged(q, kv, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
+            return _linear(out, self.fc_o.weight, self.fc_o.bias), None
+        q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
+        k = _linear(keys, self.fc_k.weight, self.fc_k.bias)
+        v = _linear(values, self.fc_v.weight, self.fc_v.bias)
+        if fused:
             out = fused_attention.sdpa(q.float(), k.float(), v.float(), self.h,
                                        None if attention_weights is None else attention_weights.float(), way,
                                        attention_mask, bf16_mma=self.bf16_mma)

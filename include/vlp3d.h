@@ -288,14 +288,16 @@ int vlp3d_relation_bias_bwd(const float *centre, const float *params, const floa
  *           1 = operands rounded to bf16 in registers, fp32 accumulation and softmax (timing configuration). */
 int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                    const float *mask, int B, int H, int nq, int nk, int D, float *out, float *lse, int bf16_mma,
-                   void *stream);
+                   int ldq, int ldk, int ldv, void *stream);
 
-/* backward of vlp3d_sdpa_fwd: dout (B,nq,H*D) -> dq, dk, dv (shapes of q,k,v; fully written),
- * dbias (B,H,nq,nk) or NULL.  delta (B,H,nq) f32 scratch. */
+/* backward of vlp3d_sdpa_fwd: dout (B,nq,H*D) -> dq, dk, dv (shapes and ROW STRIDES of q,k,v; fully written),
+ * dbias (B,H,nq,nk) or NULL.  delta (B,H,nq) f32 scratch.
+ * ldq / ldk / ldv: row strides in floats of q / k / v (>= H*D, multiple of 4; H*D = contiguous) — the three may be
+ * column blocks of one merged projection output, and dq / dk / dv column blocks of one merged gradient. */
 int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
                    const float *mask, const float *out, const float *lse, const float *dout, int B, int H, int nq,
                    int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, int bf16_mma,
-                   void *stream);
+                   int ldq, int ldk, int ldv, void *stream);
 
 #ifdef __cplusplus
 }

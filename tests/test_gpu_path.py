@@ -87,6 +87,36 @@ def test_fused_sdpa_bf16_mma_close_to_fp32(nq, nk, mode):
     assert not torch.equal(res[0][0], res[1][0])
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("layout", ["qkv", "kv"])
+def test_fused_sdpa_row_strided_views_equal_contiguous(layout, bf):
+    """q / k / v as column blocks of ONE merged projection output (no copies in, ONE merged gradient buffer out) give
+    the same result and gradients as contiguous tensors."""
+    fa = importlib.import_module("3dvlp_amd.fused_attention")
+    torch.manual_seed(11)
+    B, n, H, HD = 4, 256, 4, 128
+    nk = n if layout == "qkv" else 49
+    merged = torch.randn(B, nk, (3 if layout == "qkv" else 2) * HD, device="cuda", requires_grad=True)
+    qsep = torch.randn(B, n, HD, device="cuda", requires_grad=True)
+    go = torch.randn(B, n, HD, device="cuda")
+    if layout == "qkv":
+        q, k, v = merged.split(HD, dim=-1)
+    else:
+        q = qsep
+        k, v = merged.split(HD, dim=-1)
+    out = fa.sdpa(q, k, v, H, bf16_mma=bf)
+    out.backward(go)
+    g_merged, g_q = merged.grad.clone(), (None if layout == "qkv" else qsep.grad.clone())
+    qc, kc, vc = (t.detach().contiguous().requires_grad_(True) for t in (q, k, v))
+    ref = fa.sdpa(qc, kc, vc, H, bf16_mma=bf)
+    ref.backward(go)
+    torch.testing.assert_close(out, ref, rtol=0, atol=0)
+    exp = torch.cat([qc.grad, kc.grad, vc.grad], -1) if layout == "qkv" else torch.cat([kc.grad, vc.grad], -1)
+    torch.testing.assert_close(g_merged, exp, rtol=0, atol=0)
+    if g_q is not None:
+        torch.testing.assert_close(g_q, qc.grad, rtol=0, atol=0)
+
+
 def test_fused_sdpa_matches_oracle_numpy():
     fa = importlib.import_module("3dvlp_amd.fused_attention")
     rng = np.random.default_rng(0)
