@@ -1640,7 +1640,8 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nblk);
   int st;
-  if (N > 256 && N % 128 == 0 && N <= 1024) {  // wide (merged q/k/v) layers: 128-column workgroup blocks
+  if ((N > 256 || (N / 32) * (w.KP / 32) > 36) && N % 128 == 0 && N <= 1024) {
+    // wide layers (merged q/k/v) or more than 9 output tiles per wave: 128-column workgroup blocks
     const size_t lds128 = (size_t)32 * (128 + w.KP) * sizeof(float);
     if (lds128 > 64 * 1024) return VLP3D_EINVAL;
     st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, dim3((unsigned)nblk, N / 128), lds128);

@@ -22,8 +22,13 @@ _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging
 def supported(x, weight):
     R = x.numel() // x.shape[-1]
     N, K = weight.shape
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
-            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K and 32 * (min(N, 128 if N > 256 else N) + ((K + 31) // 32) * 32) * 4 <= 65536)
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
+            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K):
+        return False
+    kt = (K + 31) // 32
+    blocked = N > 256 or (N // 32) * kt > 36  # the weight gradient then runs as 128-column workgroup blocks
+    nb = 128 if blocked else N
+    return (not blocked or N % 128 == 0) and (nb // 32) * kt <= 36 and 32 * (nb + kt * 32) * 4 <= 65536
 
 
 class _Linear(Function):
