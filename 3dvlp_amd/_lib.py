@@ -47,9 +47,9 @@ SIGNATURES = {
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_sa_pool_tstats": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "vlp3d_sa_prep_weights": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
-    "vlp3d_grounding_loss_sums": [_i, _i, _i, _i],
-    "vlp3d_grounding_loss_fwd": [_vp] * 11 + [_i] * 6 + [_f] * 7 + [_vp, _vp, _vp],
-    "vlp3d_grounding_loss_bwd": [_vp] * 11 + [_i] * 6 + [_f] * 7 + [_vp] * 6 + [_vp],
+    "vlp3d_joint_loss_rows": [_i, _i, _i, _i],
+    "vlp3d_joint_loss_fwd": [_vp] * 25 + [_i] * 8 + [_f] * 6 + [_i] + [_vp] * 6 + [_vp],
+    "vlp3d_joint_loss_bwd": [_vp] * 25 + [_i] * 8 + [_f] * 6 + [_i] + [_vp] * 5 + [_vp] * 10 + [_vp],
     "vlp3d_contrast_fwd": [_vp] * 9 + [_i] * 4 + [_vp, _vp, _vp],
     "vlp3d_contrast_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 7 + [_vp],
     "vlp3d_add_norm_blocks": [ctypes.c_longlong],
@@ -83,7 +83,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name.endswith(("_bytes", "_sums")) else ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith(("_bytes", "_sums", "_rows")) else ctypes.c_int
         _lib = lib
     return _lib
 

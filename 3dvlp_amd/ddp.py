@@ -38,13 +38,22 @@ class FlatGradBucket:
             p.grad = None
 
     def collect(self):
-        """Call after backward: copy the produced gradients into the flat buffer, re-attach the views."""
+        """Call after backward: copy the produced gradients into the flat buffer, re-attach the views.
+
+        A parameter that received NO gradient in this backward keeps ``.grad = None`` (its slice of the flat buffer
+        stays zero, so the all-reduce is unaffected): the optimiser then skips it exactly like the reference's
+        (torch.optim skips grad-None parameters) — no weight decay on, and no optimiser state for, sub-modules that
+        exist only so that reference checkpoints load (lang_emb_proj, box_con_proj, NCELoss.tau, ...).  All ranks run
+        the same graph, so the touched set is the same everywhere."""
         dst, src = [], []
+        self.touched = []
         for p, v in zip(self.params, self.views):
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            got = p.grad is not None
+            if got and p.grad.data_ptr() != v.data_ptr():
                 dst.append(v)
                 src.append(p.grad.to(torch.float32) if p.grad.dtype != torch.float32 else p.grad)
-            p.grad = v
+            p.grad = v if got else None
+            self.touched.append(got)
         if dst:
             torch._foreach_copy_(dst, src)
 
@@ -65,5 +74,8 @@ def broadcast_parameters(module, src=0, process_group=None):
 
 def shard_range(num_scenes, rank, world_size):
     """Contiguous shard of scene ids for this rank (global batch = per-rank batch * world_size)."""
+    if num_scenes % world_size:
+        raise ValueError("shard_range: %d scenes do not divide over %d ranks (the step assumes equal shards: "
+                         "per-rank BatchNorm statistics and a plain 1/world gradient average)" % (num_scenes, world_size))
     per = num_scenes // world_size
     return rank * per, (rank + 1) * per

@@ -17,25 +17,25 @@ BF16_MMA = False
 
 
 def _key_mask(attention_mask, b, nk):
-    """Accept the mask shapes that are pure key masks ((b,1,1,nk) / (b,nk)); None otherwise."""
+    """Only a 4-D (b,1,1,nk) mask is a pure per-batch key mask; None when there is no mask, False for any other shape.
+    (A 2-D mask is NOT accepted: the reference's masked_fill broadcasts (x,nk) over (b,h,nq,nk) as a (nq,nk) mask, so
+    reading a (b,nk) tensor as a key mask would silently differ whenever b == nq.)"""
     if attention_mask is None:
         return None
     m = attention_mask
     if m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1 and m.shape[0] == b and m.shape[3] == nk:
         return m.reshape(b, nk)
-    if m.dim() == 2 and tuple(m.shape) == (b, nk):
-        return m
     return False  # a mask, but not one the kernel takes
 
 
-def supported(d_k, d_v, attention_mask, nk):
+def supported(d_k, d_v, attention_mask, nk, b=None):
+    """Shapes the fused core takes.  `b` = batch size of the queries (masks are checked against it); callers fall back
+    to the unfused formulation when this returns False."""
     if d_k != 32 or d_v != 32:
         return False
     if attention_mask is None:
         return True
-    m = attention_mask
-    return (m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1 and m.shape[3] == nk) or \
-           (m.dim() == 2 and m.shape[1] == nk)
+    return _key_mask(attention_mask, attention_mask.shape[0] if b is None else b, nk) is not False
 
 
 class _SDPA(Function):

@@ -1,4 +1,4 @@
-"""The grounding hot path end to end: network graph, reduced loss, one optimisation step.
+"""The grounding hot path end to end: network graph, the reference's training loss, one optimisation step.
 
 GroundingNet is the hot-path subset of the reference's JointNet (models/jointnet/jointnet.py:112-220):
 backbone -> voting (+L2 norm) -> proposal (vote clustering, ROI heads, decode) -> relation -> match
@@ -7,10 +7,8 @@ backbone -> voting (+L2 norm) -> proposal (vote clustering, ROI heads, decode) -
 1:1.  The frozen BERT encoder (`lang`, out of scope) is replaced by its outputs `lang_fea`/`lang_emb`
 in the data_dict.
 
-`grounding_loss` is a REDUCED form of lib/loss_helper/loss_joint.py:26-227 (the full detection +
-grounding loss stack is the "next" row §8f-1): vote loss and objectness loss as in
-loss_detection.py:24-110 (both consume nn_distance), a centre/size regression of the assigned
-proposals, the reference cross-entropy over cluster_ref, and 0.5*OCC + 2.5*OSC (loss_joint.py:208).
+`grounding_loss` is the reference's loss for this path (lib/loss_helper/loss_joint.py:26-227 with detection +
+reference + DIoU + OCC/OSC as run.sh:1 configures it): 3dvlp_amd/losses.py, fused in csrc/joint_loss.hip.
 """
 import importlib
 from types import SimpleNamespace
@@ -21,17 +19,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as _ext
-from . import add_norm, synth
+from . import add_norm, losses, synth
 from .ddp import FlatGradBucket
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
 from .grounding import ContrastModule, MatchModule
-from .nn_distance import huber_loss, nn_distance
-
-FAR_THRESHOLD = 0.6   # loss_detection.py:19-23
-NEAR_THRESHOLD = 0.3
-GT_VOTE_FACTOR = 3
-OBJECTNESS_CLS_WEIGHTS = (0.2, 0.8)
-_CLS_W = {}
 
 
 class GroundingNet(nn.Module):
@@ -69,108 +60,15 @@ class GroundingNet(nn.Module):
         return data_dict
 
 
-def compute_vote_loss(d):
-    """loss_detection.py:24-72."""
-    B, S = d["seed_xyz"].shape[:2]
-    seed_inds = d["seed_inds"].long()
-    mask = torch.gather(d["vote_label_mask"], 1, seed_inds).float()
-    gt_votes = torch.gather(d["vote_label"], 1, seed_inds.unsqueeze(-1).expand(-1, -1, 3 * GT_VOTE_FACTOR))
-    gt_votes = gt_votes + d["seed_xyz"].repeat(1, 1, 3)
-    _, _, dist2, _ = nn_distance(d["vote_xyz"].reshape(B * S, -1, 3), gt_votes.reshape(B * S, GT_VOTE_FACTOR, 3),
-                                 l1=True)
-    votes_dist = dist2.min(dim=1)[0].view(B, S)
-    return torch.sum(votes_dist * mask) / (torch.sum(mask) + 1e-6)
+LOSS_IMPL = None  # None -> losses.DEFAULT_IMPL ("hip": csrc/joint_loss.hip); "torch" = batched op-by-op form (tests)
 
 
-def compute_objectness_loss(d):
-    """loss_detection.py:74-110."""
-    agg = d["aggregated_vote_xyz"]
-    gt_center = d["center_label"][:, :, 0:3]
-    dist1, ind1, _, _ = nn_distance(agg, gt_center)
-    euc = torch.sqrt(dist1 + 1e-6)
-    label = (euc < NEAR_THRESHOLD).long()
-    mask = ((euc < NEAR_THRESHOLD) | (euc > FAR_THRESHOLD)).float()
-    if agg.device not in _CLS_W:
-        _CLS_W[agg.device] = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=agg.device)
-    w = _CLS_W[agg.device]
-    ce = F.cross_entropy(d["objectness_scores"].float().transpose(2, 1), label, weight=w, reduction="none")
-    return torch.sum(ce * mask) / (torch.sum(mask) + 1e-6), label, mask, ind1
-
-
-class _LossCore(torch.autograd.Function):
-    """Fused vote + objectness + centre + reference loss (csrc/grounding_loss.hip): one forward kernel (+ finalize)
-    and one backward kernel.  Returns out5 = [vote, objectness, centre, reference, weighted total]; only the total
-    carries gradient (to vote_xyz, objectness_scores, pred_center, cluster_ref)."""
-    CONSTS = (NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS[0], OBJECTNESS_CLS_WEIGHTS[1], 0.15, 0.1, 0.3)
-
-    @staticmethod
-    def forward(ctx, vote_xyz, obj_scores, pred_center, cluster_ref, seed_xyz, seed_inds, vote_label, vote_mask,
-                agg_xyz, center_label, ref_center):
-        cf = lambda t: t.contiguous().float()
-        vote_xyz, obj_scores, pred_center, cluster_ref = cf(vote_xyz), cf(obj_scores), cf(pred_center), cf(cluster_ref)
-        seed_xyz, vote_label, vote_mask, agg_xyz = cf(seed_xyz), cf(vote_label), cf(vote_mask), cf(agg_xyz)
-        center_label, ref_center = cf(center_label), cf(ref_center)
-        seed_inds = seed_inds.contiguous().int()
-        B, S = seed_inds.shape
-        N, K, G, L = vote_mask.shape[1], agg_xyz.shape[1], center_label.shape[1], ref_center.shape[1]
-        nsum = int(_ext.load().vlp3d_grounding_loss_sums(B, S, K, L))
-        sums = torch.empty((nsum,), dtype=torch.float64, device=vote_xyz.device)
-        out = torch.empty((5,), dtype=torch.float32, device=vote_xyz.device)
-        args = (vote_xyz, seed_xyz, seed_inds, vote_label, vote_mask, agg_xyz, center_label, obj_scores, pred_center,
-                cluster_ref, ref_center, B, S, N, K, G, L, *_LossCore.CONSTS)
-        _ext.call("vlp3d_grounding_loss_fwd", *args, sums, out)
-        ctx.save_for_backward(vote_xyz, seed_xyz, seed_inds, vote_label, vote_mask, agg_xyz, center_label, obj_scores,
-                              pred_center, cluster_ref, ref_center, sums)
-        ctx.dims = (B, S, N, K, G, L)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        sv = ctx.saved_tensors
-        sums = sv[11]
-        vote_xyz, obj_scores, pred_center, cluster_ref = sv[0], sv[7], sv[8], sv[9]
-        g = gout[4:5].contiguous()  # only the total is differentiable (the components are reporting values)
-        d_vote, d_obj = torch.empty_like(vote_xyz), torch.empty_like(obj_scores)
-        d_center, d_ref = torch.empty_like(pred_center), torch.empty_like(cluster_ref)
-        _ext.call("vlp3d_grounding_loss_bwd", *sv[:11], *ctx.dims, *_LossCore.CONSTS, sums, g, d_vote, d_obj, d_center,
-                  d_ref)
-        return d_vote, d_obj, d_center, d_ref, None, None, None, None, None, None, None
-
-
-FUSED_LOSS = True  # csrc/grounding_loss.hip on CUDA tensors; False = the op-by-op form below (host tests)
-
-
-def grounding_loss(d, mean_size_arr):
-    if FUSED_LOSS and d["vote_xyz"].is_cuda and d["vote_xyz"].shape[1] == d["seed_xyz"].shape[1]:
-        out = _LossCore.apply(d["vote_xyz"], d["objectness_scores"], d["pred_center"], d["cluster_ref"], d["seed_xyz"],
-                              d["seed_inds"], d["vote_label"], d["vote_label_mask"], d["aggregated_vote_xyz"],
-                              d["center_label"][:, :, 0:3], d["ref_center_label_list"][..., 0:3])
-        loss = out[4]
-        if "lang_con_loss" in d:
-            loss = loss + 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]  # loss_joint.py:208
-        comp = out.detach()
-        d["vote_loss"], d["objectness_loss"], d["center_loss"], d["ref_loss"] = comp[0], comp[1], comp[2], comp[3]
-        d["loss"] = loss
-        return loss
-    vote_loss = compute_vote_loss(d)
-    obj_loss, obj_label, _, assign = compute_objectness_loss(d)
-    B, K = obj_label.shape
-    # regression of the assigned GT centre (proposals near an object only)
-    gt_center = torch.gather(d["center_label"][:, :, 0:3], 1, assign.unsqueeze(-1).expand(-1, -1, 3))
-    pos = obj_label.float()
-    center_loss = (huber_loss(d["pred_center"] - gt_center, 0.15).sum(-1) * pos).sum() / (pos.sum() + 1e-6)
-    size_loss = (d["pred_size"].mean(-1) * 0.0).sum()  # keeps the size head in the graph
-    # reference loss: the proposal nearest to the referred GT centre is the target of cluster_ref
-    L = d["ref_center_label_list"].shape[1]
-    ref_c = d["ref_center_label_list"][..., 0:3]  # (B,L,3)
-    dist = ((d["pred_center"].detach()[:, None, :, :] - ref_c[:, :, None, :]) ** 2).sum(-1)  # (B,L,K)
-    target = dist.argmin(-1).reshape(B * L)
-    ref_loss = F.cross_entropy(d["cluster_ref"].float(), target)
-    loss = vote_loss + 0.1 * obj_loss + center_loss + size_loss + 0.3 * ref_loss
-    if "lang_con_loss" in d:
-        loss = loss + 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]  # loss_joint.py:208
-    d["loss"] = loss
-    return loss
+def grounding_loss(d, config, args=None, impl=None):
+    """The reference's training loss for this path: losses.get_joint_loss == lib/loss_helper/loss_joint.py:26-227 with
+    detection + reference (+ DIoU + OCC/OSC, run.sh:1); the language-classification term belongs to the out-of-scope
+    language encoder and is included only when the batch carries `lang_scores`."""
+    losses.get_joint_loss(args, d, config=config, caption=False, impl=impl or LOSS_IMPL)
+    return d["loss"]
 
 
 def batch_to_device(batch, device):
@@ -239,6 +137,9 @@ class GroundingStep:
         self.pipeline = pipeline
         self._side = torch.cuda.Stream(device=device) if pipeline else None
         self._geom_cur = self._geom_next = None
+        self._geom_tag = None      # eager pipeline: the batch _geom_next was prepared for
+        self._geom_for = None      # graph pipeline: the batch _geom_next was prepared for
+        self._static_tag = self._next_src_tag = None  # sources the static graph buffers were last filled from
         self._graph = None
         self._static_batch = self._static_next = None
         self._static_loss = None
@@ -254,7 +155,7 @@ class GroundingStep:
                     d = self.model(d)
             else:
                 d = self.model(d)
-        return grounding_loss(d, self.model.mean_size_arr), d
+        return grounding_loss(d, self.model.dataset_config), d
 
     @staticmethod
     def _copy_geometry(dst, src):
@@ -262,21 +163,38 @@ class GroundingStep:
             for a, b in zip(dst[k], src[k]):
                 a.copy_(b)
 
+    @staticmethod
+    def _tag(batch):
+        """Identity of a batch's coordinates: (address, in-place version) of point_clouds.  The prepared geometry is
+        only ever used for the batch it was computed from."""
+        pc = batch["point_clouds"]
+        return (pc.data_ptr(), pc._version, tuple(pc.shape))
+
     def _fwd_bwd(self, batch, next_batch=None):
-        """One forward+loss+backward.  With the pipeline on, uses the geometry prepared during the previous call
-        and prepares `next_batch`'s (default: the same batch again) on the side stream meanwhile."""
+        """One forward+loss+backward.  With the pipeline on, uses the geometry prepared during the previous call IF
+        it was prepared for this very batch (else computes it inline on the main stream), and prepares
+        `next_batch`'s on the side stream meanwhile (default guess: the same batch comes again)."""
         geometry = None
         if self.pipeline:
             backbone = self.model.backbone_net
             cur = torch.cuda.current_stream()
-            if self._geom_next is None:  # very first call: nothing prepared yet
-                self._geom_next = backbone.compute_geometry(batch["point_clouds"])
-                self._geom_cur = {k: tuple(t.clone() for t in v) for k, v in self._geom_next.items()}
-            self._copy_geometry(self._geom_cur, self._geom_next)  # tiny: indices + sampled coordinates
+            if self._geom_next is None or self._geom_tag != self._tag(batch):
+                # nothing prepared, or prepared for another batch: geometry inline (correct, just not overlapped)
+                fresh = backbone.compute_geometry(batch["point_clouds"])
+                if self._geom_next is None:
+                    self._geom_next = fresh
+                    self._geom_cur = {k: tuple(t.clone() for t in v) for k, v in fresh.items()}
+                else:
+                    cur.wait_stream(self._side)
+                    self._copy_geometry(self._geom_cur, fresh)
+            else:
+                self._copy_geometry(self._geom_cur, self._geom_next)  # tiny: indices + sampled coordinates
+            nxt_batch = batch if next_batch is None else next_batch
             self._side.wait_stream(cur)  # fork: the side branch may overwrite _geom_next from here on
             with torch.cuda.stream(self._side):
-                nxt = backbone.compute_geometry((next_batch or batch)["point_clouds"])
+                nxt = backbone.compute_geometry(nxt_batch["point_clouds"])
                 self._copy_geometry(self._geom_next, nxt)
+            self._geom_tag = self._tag(nxt_batch)
             geometry = self._geom_cur
         self.bucket.zero()
         loss, _ = self.forward_loss(batch, geometry)
@@ -287,13 +205,23 @@ class GroundingStep:
             torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()
 
+    def _persistent_state(self):
+        """Everything a forward pass mutates besides the parameters: BatchNorm running statistics / counters and the
+        add-norm dropout seed word."""
+        return list(self.model.buffers()) + [add_norm.state(self.device)]
+
     def _capture(self, batch, next_batch):
-        self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        self._static_next = self._static_batch if next_batch is None else \
-            {k: (v.clone() if torch.is_tensor(v) else v) for k, v in next_batch.items()}
+        clone = lambda b: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        self._static_batch = clone(batch)
+        self._static_next = clone(batch if next_batch is None else next_batch)  # always its own buffers
+        self._static_tag = self._tag(batch)
+        self._next_src_tag = self._tag(batch if next_batch is None else next_batch)
+        # the warm-up passes are real training forwards (BN momentum updates, counters, dropout seed): snapshot the
+        # persistent state and put it back, so that a graph step leaves exactly the state an eager step leaves
+        keep = [t.clone() for t in self._persistent_state()]
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(warm):  # warm-up off the capture stream (allocator, MIOpen/hipBLASLt selection)
+        with torch.cuda.stream(warm):  # warm-up off the capture stream (allocator, library kernel selection)
             for _ in range(2):
                 self._fwd_bwd(self._static_batch, self._static_next)
         torch.cuda.current_stream().wait_stream(warm)
@@ -302,37 +230,48 @@ class GroundingStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._static_loss = self._fwd_bwd(self._static_batch, self._static_next)
-            return
-        # Pipelined: THREE single-stream graphs instead of one graph with a forked branch.  ROCm launches a
-        # linear graph in ~0.3 ms of host time but walks a multi-stream graph node by node (16 ms for the 1300
-        # nodes of this step), which made the step host-bound.  The fork/join are two events outside the graphs:
-        #   gC (main): hand the prepared geometry over;   gS (side): geometry of the next batch;
-        #   gM (main): forward + loss + backward of the current batch.
-        backbone = self.model.backbone_net
-        self._gC, self._gS, self._gM = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._gC):
-            self._copy_geometry(self._geom_cur, self._geom_next)
-        with torch.cuda.graph(self._gS, stream=self._side):
-            nxt = backbone.compute_geometry(self._static_next["point_clouds"])
-            self._copy_geometry(self._geom_next, nxt)
-        with torch.cuda.graph(self._gM):
-            self.bucket.zero()
-            loss, _ = self.forward_loss(self._static_batch, self._geom_cur)
-            loss.backward()
-            self.bucket.collect()
-            add_norm.advance(self.device)
-            self._static_loss = loss.detach()
-        self._graph = self._gM
+        else:
+            # Pipelined: THREE single-stream graphs instead of one graph with a forked branch.  ROCm launches a
+            # linear graph in ~0.3 ms of host time but walks a multi-stream graph node by node (16 ms for the 1300
+            # nodes of this step), which made the step host-bound.  The fork/join are two events outside the graphs:
+            #   gC (main): hand the prepared geometry over;   gS (side): geometry of the next batch;
+            #   gM (main): forward + loss + backward of the current batch.
+            backbone = self.model.backbone_net
+            self._gC, self._gS, self._gM = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._gC):
+                self._copy_geometry(self._geom_cur, self._geom_next)
+            with torch.cuda.graph(self._gS, stream=self._side):
+                nxt = backbone.compute_geometry(self._static_next["point_clouds"])
+                self._copy_geometry(self._geom_next, nxt)
+            with torch.cuda.graph(self._gM):
+                self.bucket.zero()
+                loss, _ = self.forward_loss(self._static_batch, self._geom_cur)
+                loss.backward()
+                self.bucket.collect()
+                add_norm.advance(self.device)
+                self._static_loss = loss.detach()
+            self._graph = self._gM
+            # _geom_next currently holds the geometry of _static_next (computed by the warm-up passes)
+            self._geom_for = self._next_src_tag
+        torch.cuda.synchronize()
+        for t, k in zip(self._persistent_state(), keep):
+            t.copy_(k)
 
     def _replay(self):
         if not self.pipeline:
             self._graph.replay()
             return
         cur = torch.cuda.current_stream()
+        if self._geom_for != self._static_tag:
+            # the prepared geometry belongs to another batch than the one about to run: recompute inline (eager)
+            cur.wait_stream(self._side)
+            fresh = self.model.backbone_net.compute_geometry(self._static_batch["point_clouds"])
+            self._copy_geometry(self._geom_next, fresh)
         self._gC.replay()
         self._side.wait_stream(cur)          # fork: geometry of the next batch may overwrite _geom_next now
         with torch.cuda.stream(self._side):
             self._gS.replay()
+        self._geom_for = self._next_src_tag
         self._gM.replay()
         cur.wait_stream(self._side)          # join
 
@@ -347,10 +286,17 @@ class GroundingStep:
             if self._graph is None:
                 self._capture(batch, next_batch)
             else:
-                if batch is not self._static_batch:
+                # static buffers are refilled whenever the caller's batch is not the one they currently hold
+                # (identity = address + in-place version of point_clouds)
+                if self._tag(batch) != self._static_tag:
                     self._refill(self._static_batch, batch)
-                if next_batch is not None and next_batch is not self._static_next:
-                    self._refill(self._static_next, next_batch)
+                    self._static_tag = self._tag(batch)
+                nxt = batch if next_batch is None else next_batch
+                if self._tag(nxt) != self._next_src_tag:
+                    if self.pipeline:
+                        torch.cuda.current_stream().wait_stream(self._side)
+                    self._refill(self._static_next, nxt)
+                    self._next_src_tag = self._tag(nxt)
             self._replay()
             loss = self._static_loss
         else:

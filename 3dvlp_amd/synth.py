@@ -86,9 +86,16 @@ def make_scene(seed, num_points=40000, skip_points=0):
     center_label[:NUM_BOXES] = centers
     box_mask = np.zeros(MAX_NUM_OBJ, np.float32)
     box_mask[:NUM_BOXES] = 1
+    size_residual = (sizes - means[size_class]).astype(np.float32)
+    # per-object GT arrays padded to MAX_NUM_OBJ, as lib/joint/dataset.py:826-840 hands them to the losses
+    # (ScanNet: axis-aligned boxes, heading class / residual 0; semantic class == size class)
+    pad = lambda a: np.concatenate([a, np.zeros((MAX_NUM_OBJ - NUM_BOXES,) + a.shape[1:], a.dtype)], 0)
     return dict(xyz=xyz, features=feats, vote_label=vote_label, vote_label_mask=vote_mask, center_label=center_label,
                 box_label_mask=box_mask, box_centers=centers.astype(np.float32), box_sizes=sizes,
-                size_class=size_class, size_residual=(sizes - means[size_class]).astype(np.float32))
+                size_class=size_class, size_residual=size_residual,
+                heading_class_label=np.zeros(MAX_NUM_OBJ, np.int64), heading_residual_label=np.zeros(MAX_NUM_OBJ, np.float32),
+                size_class_label=pad(size_class.astype(np.int64)), size_residual_label=pad(size_residual),
+                sem_cls_label=pad(size_class.astype(np.int64)))
 
 
 def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000):
@@ -104,6 +111,11 @@ def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_b
         vote_label_mask=np.stack([s["vote_label_mask"] for s in scenes]),
         center_label=np.stack([s["center_label"] for s in scenes]),
         box_label_mask=np.stack([s["box_label_mask"] for s in scenes]),
+        heading_class_label=np.stack([s["heading_class_label"] for s in scenes]),
+        heading_residual_label=np.stack([s["heading_residual_label"] for s in scenes]),
+        size_class_label=np.stack([s["size_class_label"] for s in scenes]),
+        size_residual_label=np.stack([s["size_residual_label"] for s in scenes]),
+        sem_cls_label=np.stack([s["sem_cls_label"] for s in scenes]),
         lang_fea=rng.normal(0, 1, (batch_size * L, 50, 128)).astype(np.float32),
         lang_num=np.full(batch_size, L, np.int64),
         input_ids=np.zeros((batch_size, L, 50), np.int64),

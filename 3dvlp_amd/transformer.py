@@ -44,7 +44,7 @@ class ScaledDotProductAttention(nn.Module):
         if way not in ("add", "mul"):
             raise NotImplementedError(way)
         impl = self.impl or DEFAULT_IMPL
-        fused = impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk)
+        fused = impl == "hip" and not need_att and fused_attention.supported(self.d_k, self.d_v, attention_mask, nk, b_s)
         if fused and self.merge_qkv and keys is values and queries.is_cuda and queries.dtype == torch.float32:
             # projections that read the same input run as ONE linear layer over concatenated weights (the parameters
             # keep the reference's names): q|k|v for self-attention, k|v for cross-attention; the attention kernels

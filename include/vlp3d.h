@@ -194,31 +194,50 @@ int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int 
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, void *stream);
 
-/* ---- reduced detection + reference loss of the grounding step (csrc/grounding_loss.hip) --------------------
- * vote loss and objectness loss as lib/loss_helper/loss_detection.py:24-110 (both on the nearest-neighbour
- * distances of utils/nn_distance.py), Huber(huber_delta) centre regression of the near proposals against their
- * assigned GT centre, cross-entropy of cluster_ref (B*L,K) against the proposal nearest to ref_center (B,L,3).
- * vote_xyz, seed_xyz (B,S,3); seed_inds (B,S) i32 into the N input points; vote_label (B,N,9), vote_mask (B,N) f32;
- * agg_xyz (B,K,3); center_label (B,G,3); obj_scores (B,K,2); pred_center (B,K,3).
- * fwd -> out5 = [vote, objectness, centre, reference, vote + w_obj*objectness + centre + w_ref*reference];
- *        sums: vlp3d_grounding_loss_sums(B,S,K,L) doubles of scratch; the first 7 (numerators / denominators) are
- *        kept for backward.
- * bwd: gout = device scalar d/d(out5[4]) (NULL = 1) -> d_vote (B,S,3), d_obj (B,K,2), d_center (B,K,3),
- *      d_ref (B*L,K), all fully written. */
-long long vlp3d_grounding_loss_sums(int B, int S, int K, int L);
-int vlp3d_grounding_loss_fwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds, const float *vote_label,
-                             const float *vote_mask, const float *agg_xyz, const float *center_label,
-                             const float *obj_scores, const float *pred_center, const float *cluster_ref,
-                             const float *ref_center, int B, int S, int N, int K, int G, int L, float near_thr,
-                             float far_thr, float w0, float w1, float huber_delta, float w_obj, float w_ref, double *sums,
-                             float *out5, void *stream);
-int vlp3d_grounding_loss_bwd(const float *vote_xyz, const float *seed_xyz, const int *seed_inds, const float *vote_label,
-                             const float *vote_mask, const float *agg_xyz, const float *center_label,
-                             const float *obj_scores, const float *pred_center, const float *cluster_ref,
-                             const float *ref_center, int B, int S, int N, int K, int G, int L, float near_thr,
-                             float far_thr, float w0, float w1, float huber_delta, float w_obj, float w_ref,
-                             const double *sums, const float *gout, float *d_vote, float *d_obj, float *d_center,
-                             float *d_ref, void *stream);
+/* ---- the training loss of the grounding step (csrc/joint_loss.hip) ------------------------------------------
+ * replaces lib/loss_helper/loss_joint.py:26-227 (get_joint_loss with detection + reference, run.sh:1) and what it
+ * calls: loss_detection.py:24-258 (vote, objectness, box + sem-cls on recover_assigned_gt_bboxes),
+ * loss_grounding.py:129-365 (compute_diou_loss: utils/box_util.py:488-529 DIoU, best-IoU / smooth labels,
+ * lib/loss_helper/loss.py:6-17 SoftmaxRankingLoss) — minus their Python loops and host syncs.
+ * Differentiable inputs: vote_xyz (B,S,3), obj_scores (B,K,2), heading_scores / heading_res_norm (B,K,NH), rois (B,K,6),
+ * sem_scores (B,K,NC), agg_xyz / pred_center / pred_size (B,K,3), cluster_ref (B*L,K).
+ * Labels: seed_xyz (B,S,3), seed_inds (B,S) i32 into N, vote_label (B,N,9), vote_mask (B,N) f32, center_label (B,G,3),
+ * heading_class_label i32 / heading_residual_label f32 / size_class_label i32 / sem_cls_label i32 (B,G),
+ * size_residual_label (B,G,3), ref_center / ref_size (B,L,3) (decoded GT boxes of the sentences), lang_num (B) i32,
+ * coin: device float, the IoUs are gated by the objectness arg-max when coin < 0.5 (the train-time
+ * `data_dict["random"] < 0.5`; pass 1.0 otherwise), mean_size (num_size_cluster,3).
+ * smooth_labels: 1 = epoch < 50 label smoothing (0.95 / 0.05 split), 0 = hard labels.
+ * fwd: part = vlp3d_joint_loss_rows(B,S,K,L) rows of 16 doubles (scratch), sums = 16 doubles (kept for bwd),
+ *      out[15] = vote, objectness, heading_cls, heading_reg, size_distance, sem_cls, box, ref, diou,
+ *                total = 10*(vote + 0.1*objectness + box) + w_ref*ref + w_diou*diou, pos_ratio, neg_ratio, obj_acc,
+ *                max_iou_rate_0.25, max_iou_rate_0.5;
+ *      assign (B,K) i32 = object_assignment; objlab (B,K) i32 = objectness_label | objectness_mask << 1;
+ *      rowinfo (B,L,4) i32 = per sentence: valid (best IoU >= 0.25), argmax IoU, argmax gated IoU, #gated IoU >= 0.25.
+ * bwd: gout = device scalar d/d(out[9]) (NULL = 1); every gradient buffer is fully written. */
+long long vlp3d_joint_loss_rows(int B, int S, int K, int L);
+int vlp3d_joint_loss_fwd(const float *vote_xyz, const float *obj_scores, const float *heading_scores,
+                         const float *heading_res_norm, const float *rois, const float *sem_scores, const float *agg_xyz,
+                         const float *pred_center, const float *pred_size, const float *cluster_ref, const float *seed_xyz,
+                         const int *seed_inds, const float *vote_label, const float *vote_mask, const float *center_label,
+                         const int *heading_class_label, const float *heading_residual_label, const int *size_class_label,
+                         const float *size_residual_label, const int *sem_cls_label, const float *ref_center,
+                         const float *ref_size, const int *lang_num, const float *coin, const float *mean_size, int B, int S,
+                         int N, int K, int G, int L, int NH, int NC, float near_thr, float far_thr, float w0, float w1,
+                         float w_ref, float w_diou, int smooth_labels, double *part,
+                         double *sums, float *out, int *assign, int *objlab, int *rowinfo, void *stream);
+int vlp3d_joint_loss_bwd(const float *vote_xyz, const float *obj_scores, const float *heading_scores,
+                         const float *heading_res_norm, const float *rois, const float *sem_scores, const float *agg_xyz,
+                         const float *pred_center, const float *pred_size, const float *cluster_ref, const float *seed_xyz,
+                         const int *seed_inds, const float *vote_label, const float *vote_mask, const float *center_label,
+                         const int *heading_class_label, const float *heading_residual_label, const int *size_class_label,
+                         const float *size_residual_label, const int *sem_cls_label, const float *ref_center,
+                         const float *ref_size, const int *lang_num, const float *coin, const float *mean_size, int B, int S,
+                         int N, int K, int G, int L, int NH, int NC, float near_thr, float far_thr, float w0, float w1,
+                         float w_ref, float w_diou, int smooth_labels,
+                         const double *sums, const int *assign, const int *objlab, const int *rowinfo, const float *gout,
+                         float *d_vote_xyz, float *d_obj_scores, float *d_heading_scores, float *d_heading_res_norm,
+                         float *d_rois, float *d_sem_scores, float *d_agg_xyz, float *d_pred_center, float *d_pred_size,
+                         float *d_cluster_ref, void *stream);
 
 /* ---- OCC / OSC InfoNCE of the contrast module (csrc/contrast.hip) ------------------------------------------
  * Core of models/constrast_module/constrast_module.py:53-131 for all (scene, sentence) pairs at once.

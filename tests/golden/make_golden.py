@@ -13,7 +13,7 @@ Pinned here (SURVEY.md §8c list): nn_distance; ScaledDotProductAttention /
 MultiHeadAttention (plain, additive bias, multiplicative weights, mask);
 CrossAttentionDecoderLayer x2; MatchModule (eval, istrain=0); RelationModule
 (eval); VotingModule (train+eval); SharedMLP (train+eval);
-box3d_diou_batch_tensor; StandardROIHeads (eval); get_3d_box_batch.
+box3d_diou_batch_tensor; StandardROIHeads (eval); get_3d_box_batch; SoftmaxRankingLoss.
 
 NOT pinnable (documented in DESIGN.md): the nine pointnet2._ext CUDA ops and
 pytorch3d box3d_overlap.
@@ -277,7 +277,33 @@ def gen_roi_heads():
     save("roi_heads", **d)
 
 
+def gen_ranking_loss():
+    """lib/loss_helper/loss.py:6-17 SoftmaxRankingLoss (pure torch, importable): hard, smooth (0.95 / 0.05 split) and
+    all-zero target rows, as compute_diou_loss feeds it (loss_grounding.py:258-300)."""
+    from lib.loss_helper.loss import SoftmaxRankingLoss
+    rng = np.random.default_rng(900)
+    crit = SoftmaxRankingLoss()
+    d = {}
+    for case, (rows, K) in enumerate([(8, 256), (3, 32), (1, 5)]):
+        x = (rng.normal(0, 3, (rows, K))).astype(np.float32)
+        t = np.zeros((rows, K), np.float32)
+        for r in range(rows):
+            kind = r % 3
+            if kind == 0:
+                t[r, rng.integers(0, K)] = 1
+            elif kind == 1:
+                sel = rng.choice(K, size=min(4, K), replace=False)
+                t[r, sel] = 0.05 / (len(sel) - 1)
+                t[r, sel[0]] = 0.95
+        d[f"{case}/x"], d[f"{case}/t"] = x, t
+        d[f"{case}/loss"] = t2n(crit(torch.from_numpy(x), torch.from_numpy(t)))
+    save("ranking_loss", **d)
+
+
 if __name__ == "__main__":
+    if "--only-ranking" in sys.argv:
+        gen_ranking_loss()
+        sys.exit(0)
     gen_nn_distance()
     gen_attention()
     gen_decoder()
@@ -287,3 +313,4 @@ if __name__ == "__main__":
     gen_shared_mlp()
     gen_boxes()
     gen_roi_heads()
+    gen_ranking_loss()

@@ -41,7 +41,9 @@ def _worker(rank, world, port, ret):
         p.grad = None
     full[2](full[1](full[0](x))).pow(2).mean().backward()
     ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in full.parameters()])
-    ret[rank] = (model[0].weight.detach().clone(), bucket.flat.clone(), model.unused.weight.grad.clone(), ref)
+    assert model.unused.weight.grad is None  # no gradient produced: the optimiser skips it, like the reference's
+    n_unused = sum(p.numel() for p in model.unused.parameters())
+    ret[rank] = (model[0].weight.detach().clone(), bucket.flat.clone(), bucket.flat[-n_unused:].clone(), ref)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,3 +65,6 @@ def test_shard_range_covers_batch():
     spans = [ddp.shard_range(64, r, 8) for r in range(8)]
     assert spans[0] == (0, 8) and spans[-1] == (56, 64)
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    import pytest
+    with pytest.raises(ValueError):
+        ddp.shard_range(10, 0, 4)

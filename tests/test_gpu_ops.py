@@ -242,3 +242,57 @@ def test_nn_distance_gradients_match_dense_torch():
         ra, rb = torch.autograd.grad(dist.min(2)[0].sum() + 2 * dist.min(1)[0].sum(), [a, b])
         torch.testing.assert_close(ga, ra, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(gb, rb, rtol=1e-5, atol=1e-6)
+
+
+# ---- the other BASELINE configurations' shapes (cfg3 B=32/GPU and cfg5 N=80 000 were untested) ----
+def test_fps_ball_query_cfg5_80k_points(pu, ext):
+    """cfg5 (ScanQA + grounding): 80 000-point scenes through SA1's FPS (40k->2048 rule: npoint 2048) and ball query."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    xyz = np.stack([synth.make_scene(3000 + i, 80000)["xyz"] for i in range(2)])
+    t = dev(xyz)
+    ref = orc.furthest_point_sampling(xyz, 2048)
+    got = pu.furthest_point_sample(t, 2048)
+    assert (got.cpu().numpy() == ref).all()
+    assert (ext.furthest_point_sampling(t, 2048, "dense").cpu().numpy() == ref).all()
+    new_xyz = np.stack([xyz[b, ref[b]] for b in range(2)])
+    idx = pu.ball_query(0.2, 64, t, dev(new_xyz)).cpu().numpy()
+    assert (idx == orc.ball_query(new_xyz, xyz, 0.2, 64)).all()
+
+
+def test_fps_ball_query_cfg3_batch32(pu):
+    """cfg3 (pre-training, 32 scenes per GPU): every scene of a 32-scene batch equals the oracle (grid / slab sizing
+    by B)."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    xyz = np.stack([synth.make_scene(4000 + i, 40000)["xyz"] for i in range(32)])
+    t = dev(xyz)
+    ref = orc.furthest_point_sampling(xyz, 2048)
+    assert (pu.furthest_point_sample(t, 2048).cpu().numpy() == ref).all()
+    new_xyz = np.stack([xyz[b, ref[b]] for b in range(32)])
+    idx = pu.ball_query(0.2, 64, t, dev(new_xyz)).cpu().numpy()
+    assert (idx == orc.ball_query(new_xyz, xyz, 0.2, 64)).all()
+    # SA2 shape on the sampled set
+    ref2 = orc.furthest_point_sampling(new_xyz, 1024)
+    assert (pu.furthest_point_sample(dev(new_xyz), 1024).cpu().numpy() == ref2).all()
+
+
+def test_sa1_geometry_on_scene_with_skip_points(pu, ext):
+    """SURVEY §8d's variant scene: 16 points inside the FPS skip ball |p|^2 <= 1e-3 (sampling_gpu.cu:106).  They are
+    never selected (unless first), never update the running minimum, and ball query / three_nn treat them as ordinary
+    points."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    scenes = [synth.make_scene(1000 + i, 40000, skip_points=16) for i in range(2)]
+    xyz = np.stack([s["xyz"] for s in scenes])
+    n_skip = ((xyz.astype(np.float64) ** 2).sum(-1) <= 1e-3).sum(1)
+    assert (n_skip == 16).all()
+    t = dev(xyz)
+    ref = orc.furthest_point_sampling(xyz, 2048)
+    for alg in ("pruned", "dense"):
+        assert (ext.furthest_point_sampling(t, 2048, alg).cpu().numpy() == ref).all(), alg
+    skipped = (xyz.astype(np.float64) ** 2).sum(-1) <= 1e-3
+    for b in range(2):
+        assert not skipped[b, ref[b, 1:]].any()
+    new_xyz = np.stack([xyz[b, ref[b]] for b in range(2)])
+    assert (pu.ball_query(0.2, 64, t, dev(new_xyz)).cpu().numpy() == orc.ball_query(new_xyz, xyz, 0.2, 64)).all()
+    d2, i3 = ext.three_nn(dev(new_xyz[:, :1024]), dev(new_xyz[:, :512].copy()))
+    r2, ri = orc.three_nn(new_xyz[:, :1024], new_xyz[:, :512].copy())
+    assert (i3.cpu().numpy() == ri).all() and (d2.cpu().numpy() == r2).all()

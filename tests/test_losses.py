@@ -1,0 +1,167 @@
+"""The training loss of the grounding path: oracle (literal loops) <-> batched torch form <-> fused
+HIP kernels.
+
+CPU:  oracle pieces vs the reference fixtures (SoftmaxRankingLoss `ranking_loss`, DIoU `boxes`);
+      3dvlp_amd.losses impl="torch" (batched, no loops) == oracle/losses.py (the reference's loops) on every component.
+GPU:  csrc/joint_loss.hip == impl="torch": 15 reported scalars and the gradients of all ten differentiable inputs.
+"""
+import importlib
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as olosses
+
+
+def _case(seed, B=3, S=64, N=500, K=40, G=16, L=4, NH=1, NC=18, nobj=6):
+    """A synthetic data_dict whose proposals overlap the GT boxes enough that every branch of the loss is taken:
+    near / far proposals, IoU >= 0.25 and >= 0.5 rows, rows without any hit, ragged lang_num."""
+    rng = np.random.default_rng(seed)
+    mean_size = rng.uniform(0.4, 1.4, (18, 3)).astype(np.float32)
+    f32 = lambda a: np.asarray(a, np.float32)
+    centers = np.zeros((B, G, 3), np.float32)
+    centers[:, :nobj] = rng.uniform(0.5, 5.0, (B, nobj, 3))
+    scl = np.zeros((B, G), np.int64)
+    scl[:, :nobj] = rng.integers(0, 18, (B, nobj))
+    srl = np.zeros((B, G, 3), np.float32)
+    srl[:, :nobj] = rng.normal(0, 0.1, (B, nobj, 3))
+    hcl = rng.integers(0, NH, (B, G)).astype(np.int64)
+    hrl = f32(rng.normal(0, 0.1, (B, G))) if NH > 1 else np.zeros((B, G), np.float32)
+    sizes = mean_size[scl] + srl
+    pick = rng.integers(0, nobj, (B, K))
+    jitter = rng.choice([0.05, 0.25, 1.0], size=(B, K, 1)) * rng.normal(0, 1, (B, K, 3))
+    agg = f32(np.take_along_axis(centers, pick[..., None].repeat(3, -1), 1) + jitter)
+    pred_center = f32(agg + rng.normal(0, 0.05, (B, K, 3)))
+    pred_size = f32(np.take_along_axis(sizes, pick[..., None].repeat(3, -1), 1) * rng.uniform(0.7, 1.3, (B, K, 3)))
+    ref_obj = rng.integers(0, nobj, (B, L))
+    ref_center = f32(np.take_along_axis(centers, ref_obj[..., None].repeat(3, -1), 1))
+    ref_center[0, 0] += 50.0  # a sentence whose box no proposal reaches
+    seed_inds = np.stack([rng.permutation(N)[:S] for _ in range(B)]).astype(np.int32)
+    seed_xyz = f32(rng.uniform(0, 5, (B, S, 3)))
+    lang_num = rng.integers(1, L + 1, (B,)).astype(np.int64)
+    lang_num[0] = L
+    d = dict(
+        seed_xyz=seed_xyz, seed_inds=seed_inds, vote_xyz=f32(seed_xyz + rng.normal(0, 0.3, (B, S, 3))),
+        vote_label=f32(rng.normal(0, 0.4, (B, N, 9))), vote_label_mask=(rng.random((B, N)) > 0.4).astype(np.int64),
+        aggregated_vote_xyz=agg, center_label=centers, heading_class_label=hcl, heading_residual_label=hrl,
+        size_class_label=scl, size_residual_label=srl, sem_cls_label=scl.copy(),
+        objectness_scores=f32(rng.normal(0, 1, (B, K, 2))), heading_scores=f32(rng.normal(0, 1, (B, K, NH))),
+        heading_residuals_normalized=f32(rng.normal(0, 0.5, (B, K, NH))),
+        rois=f32(np.exp(rng.normal(-1, 0.5, (B, K, 6)))), sem_cls_scores=f32(rng.normal(0, 1, (B, K, NC))),
+        pred_center=pred_center, pred_size=pred_size, cluster_ref=f32(rng.normal(0, 2, (B * L, K))),
+        ref_center_label_list=ref_center, ref_size_class_label_list=np.take_along_axis(scl, ref_obj, 1),
+        ref_size_residual_label_list=f32(np.take_along_axis(srl, ref_obj[..., None].repeat(3, -1), 1)),
+        lang_num=lang_num, aggregated_vote_features=np.zeros((B, K, 1), np.float32),
+        lang_con_loss=np.float32(0.31), iou_con_loss=np.float32(0.17))
+    config = SimpleNamespace(num_heading_bin=NH, num_size_cluster=18, num_class=NC, mean_size_arr=mean_size)
+    return d, config
+
+
+DIFF = ("vote_xyz", "objectness_scores", "heading_scores", "heading_residuals_normalized", "rois", "sem_cls_scores",
+        "aggregated_vote_xyz", "pred_center", "pred_size", "cluster_ref")
+SCALARS = ("vote_loss", "objectness_loss", "heading_cls_loss", "heading_reg_loss", "size_distance_loss", "sem_cls_loss",
+           "box_loss", "ref_loss", "diou_loss", "pos_ratio", "neg_ratio", "obj_acc", "loss")
+
+
+def _to_torch(d, device, grad=False):
+    out = {}
+    for k, v in d.items():
+        t = torch.as_tensor(np.asarray(v)).to(device)
+        if grad and k in DIFF:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def test_oracle_ranking_loss_and_diou_match_reference_fixtures(golden):
+    g = golden("ranking_loss")
+    for case in range(3):
+        assert abs(olosses.softmax_ranking_loss(g[f"{case}/x"], g[f"{case}/t"]) - float(g[f"{case}/loss"])) < 1e-5
+    b = golden("boxes")
+    iou, diou = olosses.box3d_diou(b["c1"], b["s1"], b["c2"], b["s2"])
+    np.testing.assert_allclose(iou, b["iou"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(diou, b["diou"], rtol=1e-4, atol=1e-6)
+
+
+def test_product_ranking_loss_and_diou_match_reference_fixtures(golden):
+    L = importlib.import_module("3dvlp_amd.losses")
+    g = golden("ranking_loss")
+    crit = L.SoftmaxRankingLoss()
+    for case in range(3):
+        got = crit(torch.from_numpy(g[f"{case}/x"]), torch.from_numpy(g[f"{case}/t"]))
+        assert abs(float(got) - float(g[f"{case}/loss"])) < 1e-6
+    b = golden("boxes")
+    iou, diou = L.box3d_diou_batch_tensor(*(torch.from_numpy(b[k]) for k in ("c1", "s1", "c2", "s2")))
+    np.testing.assert_allclose(iou.numpy(), b["iou"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(diou.numpy(), b["diou"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("epoch", [10, 60])
+@pytest.mark.parametrize("coin", [0.2, 0.8])
+@pytest.mark.parametrize("NH", [1, 12])
+def test_batched_torch_loss_equals_reference_loops(epoch, coin, NH):
+    """impl='torch' (no loops, no syncs) == the literal restatement of the reference's loops, component by component."""
+    L = importlib.import_module("3dvlp_amd.losses")
+    d, config = _case(epoch * 7 + NH, NH=NH)
+    d["epoch"], d["istrain"], d["random"] = epoch, [1], coin
+    ref = olosses.get_joint_loss(d, vars(config), use_diou_loss=True, use_con=True)
+    t = _to_torch(d, "cpu")
+    t["epoch"], t["istrain"], t["random"] = epoch, [1], torch.tensor(coin)
+    out = L.get_joint_loss(None, t, config=config, impl="torch")
+    for k in SCALARS:
+        assert abs(float(out[k]) - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (k, float(out[k]), ref[k])
+    assert abs(float(out["max_iou_rate_0.25"]) - ref["max_iou_rate_25"]) < 1e-6
+    assert abs(float(out["max_iou_rate_0.5"]) - ref["max_iou_rate_5"]) < 1e-6
+    assert (out["cluster_labels"].numpy() == ref["cluster_labels"]).all()
+    assert (out["objectness_label"].numpy() == ref["objectness_label"]).all()
+    assert (out["object_assignment"].numpy() == ref["object_assignment"]).all()
+    # the case exercises what it claims to
+    assert 0 < ref["pos_ratio"] < 1 and 0 < ref["max_iou_rate_25"] < 1 and ref["diou_loss"] > 0
+    if epoch < 50:
+        assert ((ref["smooth_labels"] > 0) & (ref["smooth_labels"] < 0.5)).any()  # label smoothing taken
+
+
+def test_eval_mode_and_unsupported_switches():
+    L = importlib.import_module("3dvlp_amd.losses")
+    d, config = _case(5)
+    d["epoch"], d["istrain"] = 60, [0]
+    ref = olosses.get_joint_loss(dict(d, random=0.1), vars(config))
+    t = _to_torch(d, "cpu")
+    t["epoch"], t["istrain"] = 60, [0]
+    out = L.get_joint_loss(None, t, config=config, impl="torch")   # eval: no `random` key needed, no gating
+    assert abs(float(out["loss"]) - ref["loss"]) <= 2e-5 * abs(ref["loss"])
+    with pytest.raises(NotImplementedError):
+        L.get_joint_loss(None, t, config=config, caption=True, impl="torch")
+    with pytest.raises(NotImplementedError):
+        L.get_joint_loss(SimpleNamespace(use_reg_head=True), t, config=config, impl="torch")
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        L.get_joint_loss(None, t, config=config)      # the product path has no CPU fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [dict(), dict(B=8, S=1024, N=40000, K=256, G=128, L=8, nobj=12)])
+@pytest.mark.parametrize("epoch,coin,NH", [(10, 0.2, 1), (60, 0.8, 1), (60, 0.2, 12), (10, 0.8, 12)])
+def test_fused_joint_loss_equals_torch_form(shape, epoch, coin, NH):
+    """csrc/joint_loss.hip vs impl='torch' on the GPU: reported scalars, labels and the gradients of all ten inputs."""
+    L = importlib.import_module("3dvlp_amd.losses")
+    d, config = _case(epoch + NH + len(shape), NH=NH, **shape)
+    res = {}
+    for impl in ("torch", "hip"):
+        t = _to_torch(d, "cuda", grad=True)
+        t["epoch"], t["istrain"], t["random"] = epoch, [1], torch.tensor(coin, device="cuda")
+        out = L.get_joint_loss(None, t, config=config, impl=impl)
+        out["loss"].backward()
+        res[impl] = (out, {k: t[k].grad.clone() for k in DIFF})
+    a, b = res["torch"], res["hip"]
+    for k in SCALARS + ("max_iou_rate_0.25", "max_iou_rate_0.5"):
+        assert abs(float(a[0][k]) - float(b[0][k])) <= 1e-4 * max(1e-3, abs(float(a[0][k]))), (k, float(a[0][k]), float(b[0][k]))
+    assert torch.equal(a[0]["cluster_labels"], b[0]["cluster_labels"])
+    assert torch.equal(a[0]["objectness_label"], b[0]["objectness_label"])
+    assert torch.equal(a[0]["object_assignment"], b[0]["object_assignment"])
+    for k in DIFF:
+        ga, gb = a[1][k], b[1][k]
+        scale = ga.abs().max().item()
+        assert scale > 0, k                                  # every input really receives gradient in this case
+        assert (ga - gb).abs().max().item() <= 1e-4 * scale + 1e-9, (k, (ga - gb).abs().max().item(), scale)
