@@ -63,6 +63,9 @@ SIGNATURES = {
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],
     "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "vlp3d_probe_read": [_vp, ctypes.c_longlong, _i, _vp, _vp],
+    "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
+    "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _i, _i, _i, _i, _vp],

@@ -1,0 +1,80 @@
+// Hardware-denominator probes: what this very box delivers for the three rooflines the kernels
+// are priced against.  Called by bench.py / tools/hw_denominators.py; not part of the data path.
+//   vlp3d_probe_read      streaming read of `bytes` (16-byte loads, grid-stride)            -> HBM read GB/s
+//   vlp3d_probe_mfma_bf16 `iters` x 4 independent v_mfma_f32_32x32x16_bf16 per wave           -> dense bf16 MFMA TFLOP/s
+//   vlp3d_probe_fma_f32   `iters` x 8 independent v_fma_f32 chains per lane                   -> fp32 vector TFLOP/s
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ __launch_bounds__(256) void probe_read_kernel(const float4 *__restrict__ p, long long n, float *__restrict__ sink) {
+  float acc = 0.f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  long long i = (long long)blockIdx.x * 256 * 4 + threadIdx.x;
+  for (; i + 3 * 256 < n; i += stride) {  // four loads in flight per lane
+    const float4 a = p[i], b = p[i + 256], c = p[i + 512], d = p[i + 768];
+    acc += (a.x + b.y) + (c.z + d.w);
+  }
+  if (acc == 123.456f) sink[0] = acc;  // keeps the loads alive, never true for real data
+}
+
+__global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float *__restrict__ sink) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (__bf16)(0.001f * (float)(threadIdx.x + j));
+    b[j] = (__bf16)(0.002f * (float)(threadIdx.x - j));
+  }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+  }
+  const float s = (c0[0] + c1[1]) + (c2[2] + c3[3]);
+  if (s == 123.456f) sink[0] = s;
+}
+
+__global__ __launch_bounds__(256) void probe_fma_kernel(int iters, float *__restrict__ sink) {
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = 0.001f * (float)(threadIdx.x + j);
+  const float m = 0.999f, k = 0.0001f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = __builtin_fmaf(x[j], m, k);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += x[j];
+  if (s == 123.456f) sink[0] = s;
+}
+
+}  // namespace
+
+extern "C" int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, void *stream) {
+  if (!buf || !sink || bytes < 16 * 1024 || blocks < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(probe_read_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)buf, bytes / 16, sink);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// flops of one launch = blocks * 4 waves * iters * 4 * (2*32*32*16)
+extern "C" int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream) {
+  if (!sink || iters < 1 || blocks < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// flops of one launch = blocks * 256 lanes * iters * 8 * 2
+extern "C" int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream) {
+  if (!sink || iters < 1 || blocks < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(probe_fma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

@@ -314,8 +314,8 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
         for i, name in enumerate(OUT_NAMES):
             if name != "loss":
                 d[name] = comp[i]
-        d["object_assignment"], d["objectness_label"] = assign.long(), objlab.long()
-        d["objectness_mask"] = torch.ones_like(objlab, dtype=torch.float32) if NEAR_THRESHOLD == FAR_THRESHOLD else None
+        d["object_assignment"] = assign.long()
+        d["objectness_label"], d["objectness_mask"] = (objlab & 1).long(), (objlab >> 1).float()
         B, L = rowinfo.shape[:2]
         K = d["cluster_ref"].shape[-1]
         # cluster_labels (hard one-hot of the best-IoU proposal, zero rows where no proposal reaches 0.25)

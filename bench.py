@@ -1,14 +1,22 @@
-"""bench.py — scenes/sec of the 3DVLP grounding step (fwd + bwd + all-reduce + AdamW) on N MI355X.
+"""bench.py — scenes/sec of the 3DVLP grounding step (fwd + reference loss + bwd + all-reduce + AdamW) on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python bench.py [--gpus N --steps K --warmup W]            (N=1, K=100, W=20)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: ScanRefer grounding, 40 000 points, 256 proposals, batch 8 per
-GPU (weak scaling: scenes shard across ranks, one flat gradient all-reduce per step), synthetic scenes
-(3dvlp_amd/synth.py) resident in HBM before the timed region, random-init weights.
-One JSON line on rank 0.  `roofline` is measured live with events on the launch stream around the
-hand-written kernels (right after the timed steps, same process and inputs); `cpu_baseline` times the CPU oracle (forward only) on one scene.
+Workload = BASELINE.json configs[1]: ScanRefer grounding, 40 000 points, 256 proposals, batch 8 per GPU (weak
+scaling: scenes shard across ranks, one flat gradient all-reduce per step), synthetic scenes (3dvlp_amd/synth.py)
+resident in HBM before the timed region, random-init weights.  ONE JSON line on rank 0:
+
+  value / ms_per_step   K steps between two barrier + synchronize brackets (max over ranks) — the contract's number
+  step_ms               per-step durations from events on the launch stream: median, p10, p90
+  roofline              the dominant critical-path hand-written kernel (grouped-MLP gather GEMM of SA1), measured live
+                        with events on the launch stream; `traffic` = PMC HBM bytes of the same launch
+                        (profiles/r02_pmc_traffic.json, produced by tools/pmc_traffic.py; null when absent)
+  roofline_kernels      FPS (algorithmic and executed-update numerators), ball query, attention cores (self + cross)
+  roofline_step         whole step: algorithmic flops and bytes per step / ms_per_step against the chip's peaks
+  hw                    this box's measured denominators (HBM read, bf16 MFMA, fp32 FMA) beside the guide's figures
+  cpu_baseline          the same training step (fwd + loss + bwd + AdamW) on the host CPU (oracle/baseline.py)
 """
 import argparse
 import importlib
@@ -26,23 +34,13 @@ sys.path.insert(0, ROOT)
 B_PER_GPU = 8
 NUM_POINTS = 40000
 LANG_NUM = 8
+NUM_TOKENS = 49
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 NUM_CUS = 256
-
-
-def cpu_baseline(batch_np):
-    from oracle import baseline
-    import numpy as np
-    pc = batch_np["point_clouds"][:1]
-    xyz = np.ascontiguousarray(pc[..., :3])
-    feats = np.ascontiguousarray(pc[..., 3:].transpose(0, 2, 1))
-    sec, parts = baseline.scene_forward(xyz, feats, LANG_NUM)
-    return {"value": round(1.0 / sec, 4), "unit": "scenes/s", "cores": baseline.threads_used(), "kind": "port",
-            "sample": "1 scene (40k pts, 256 proposals, 8 sentences), FORWARD ONLY (the oracle has no backward): "
-                      "C/OpenMP geometry + numpy dense; seconds per part: " +
-                      ", ".join(f"{k} {v:.2f}" for k, v in parts.items())}
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def time_kernel(fn, reps, inner=8):
@@ -63,41 +61,90 @@ def time_kernel(fn, reps, inner=8):
     return total / (reps * inner)
 
 
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-PMC_KEYS = ("fps_pruned_kernel", "ball_query_kernel<8>", "row_gemm_%s64, 0, 0>", "sdpa_fwd_%s")
+def measure_hw(ext, device):
+    """the denominators re-measured on this box (csrc/hwprobe.hip)."""
+    sink = torch.zeros(1, device=device)
+    buf = torch.empty(1 << 30, dtype=torch.uint8, device=device)  # 1 GiB
+    buf.zero_()
+    dst = torch.empty_like(buf)
+    blocks = NUM_CUS * 8
+    rd = time_kernel(lambda: ext.call("vlp3d_probe_read", buf, buf.numel(), blocks, sink), 3, inner=4)
+    cp = time_kernel(lambda: dst.copy_(buf), 3, inner=4)
+    it = 2048
+    mf = time_kernel(lambda: ext.call("vlp3d_probe_mfma_bf16", it, blocks, sink), 3, inner=2)
+    fm = time_kernel(lambda: ext.call("vlp3d_probe_fma_f32", 4 * it, blocks, sink), 3, inner=2)
+    return {"hbm_read_GBs": round(buf.numel() / (rd * 1e-3) / 1e9, 1),
+            "hbm_copy_GBs_read_plus_write": round(2 * buf.numel() / (cp * 1e-3) / 1e9, 1),
+            "bf16_mfma_TFLOPs": round(blocks * 4 * it * 4 * 2 * 32 * 32 * 16 / (mf * 1e-3) / 1e12, 1),
+            "fp32_fma_TFLOPs": round(blocks * 256 * 4 * it * 16 / (fm * 1e-3) / 1e12, 1),
+            "guide": {"hbm_GBs": PEAK_HBM_GBS, "bf16_mfma_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
+                      "fp32_vector_TFLOPs": PEAK_FP32_VECTOR_TFLOPS},
+            "note": "1 GiB streaming read / device copy; 4 independent v_mfma_f32_32x32x16_bf16 chains per wave, 8 waves "
+                    "per SIMD-group; 8 independent v_fma_f32 chains per lane.  Fractions below use the guide's peaks."}
 
 
-def attach_pmc_traffic(kernels, bf):
-    """`traffic` = HBM bytes per launch from rocprofv3 PMC passes of the same kernels on the same inputs
-    (tools/roofline_kernels.py; FETCH_SIZE and WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself, so it attaches the
-    committed measurement (profiles/r01_pmc_*.csv); null when that file is absent."""
-    if not os.path.exists(PMC_TRAFFIC):
-        return
-    table = json.load(open(PMC_TRAFFIC))
-    for entry, key in zip(kernels, PMC_KEYS):
-        if "row_gemm" in key:
-            key = key % ("lds_kernel<" if bf else "kernel<float, ")
-        elif "sdpa" in key:
-            key = key % ("lds_kernel" if bf else "kernel<false>")
-        for name, v in table.items():
-            if key in name:
-                entry["traffic"] = v["hbm_bytes_corrected"]
-                entry["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE bytes/launch, profiles/r01_pmc_traffic.json"
-                break
+def step_work(B, esz):
+    """Algorithmic work of ONE step on B scenes: dense flops (forward; fwd+bwd = 3x) and the HBM bytes
+    a fused implementation with stored pre-activations has to move (every stored tensor written once and read once
+    forward, read once more and its gradient written + read once backward)."""
+    L, K, T = LANG_NUM, 256, NUM_TOKENS
+    sa = [(B * 2048 * 64, [135, 64, 64, 128], 40000, 132), (B * 1024 * 32, [131, 128, 128, 256], 2048, 128),
+          (B * 512 * 16, [259, 128, 128, 256], 1024, 256), (B * 256 * 16, [259, 128, 128, 256], 512, 256),
+          (B * 256 * 16, [259, 128, 128, 128], 1024, 256)]
+    flops = 0.0
+    byts = 0.0
+    for R, dims, n_in, c_in in sa:
+        flops += 2.0 * R * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        y = R * sum(dims[1:]) * esz
+        fwd = B * n_in * c_in * 4 + R * 4 + 2 * y          # features once + ball-query idx + Y written, read
+        byts += fwd + (2 * y + B * n_in * c_in * 4)        # backward: Y read again, G written+read folded in 2y, dfeat
+    rows = lambda r, dims: 2.0 * r * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    flops += rows(B * 512, [512, 256, 256]) + rows(B * 1024, [512, 256, 256])      # FP1, FP2
+    flops += rows(B * 1024, [256, 256, 256, 259])                                    # voting
+    flops += rows(B * K, [128, 128, 128, 28])                                        # ROI heads
+    flops += rows(B * K, [128, 128, 128])                                            # relation features_concat
+    for _ in range(2):                                                               # relation layers
+        flops += rows(B * K, [128, 128]) + rows(B * K, [27, 128]) + 4 * rows(B * K, [128, 128])
+        flops += 2 * 2.0 * B * K * K * 128 + rows(B * K * K, [4, 32, 32, 4])
+    for _ in range(2):                                                               # match decoder layers
+        r = B * L * K
+        flops += 4 * rows(r, [128, 128]) + 2 * 2.0 * B * L * K * K * 128            # self attention
+        flops += 2 * rows(r, [128, 128]) + 2 * rows(B * L * T, [128, 128]) + 2 * 2.0 * B * L * K * T * 128
+        flops += rows(r, [128, 256, 128])
+        byts += 4 * r * 128 * 4 * 2 + (2 * r + 2 * B * L * T) * 128 * 4 * 2        # SDPA q,k,v,o once each way
+    flops += rows(B * L * K, [128, 128, 128, 1])                                     # match MLP
+    flops += rows(B * L + 2 * B * K, [128, 128])                                     # contrast projections
+    return 3.0 * flops, byts
 
 
-def report(args, world, elapsed, loss, batch, ext):
-    """The JSON line.  Per-kernel roofline entries are measured right after the timed steps, in the same process
-    and on the same resident inputs (the steps themselves are hipGraph replays, which cannot be bracketed)."""
+def pmc_traffic():
+    return json.load(open(PMC_TRAFFIC)) if os.path.exists(PMC_TRAFFIC) else {}
+
+
+def kernel_rooflines(args, batch, ext):
+    """Per-kernel entries, measured right after the timed steps in the same process on the same resident inputs (the
+    steps themselves are hipGraph replays, which cannot be bracketed kernel by kernel)."""
     pu = importlib.import_module("3dvlp_amd.pointnet2_utils")
     fa = importlib.import_module("3dvlp_amd.fused_attention")
     B, n, m = B_PER_GPU, NUM_POINTS, 2048
     bf = args.dtype == "bf16"
-    reps = max(3, args.steps)
+    reps = 5
     pc = batch["point_clouds"]
     xyz = pc[..., :3].contiguous()
     feat_pm = pc[..., 3:].contiguous()
+    table = pmc_traffic()
+
+    def entry(kernel, key, bound, work, peak, unit, ms, **extra):
+        ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+        d = {"kernel": kernel, "bound": bound, "achieved": round(ach, 4), "peak": round(peak, 4), "unit": unit,
+             "frac": round(ach / peak, 4), "traffic": None, "ms": round(ms, 4)}
+        for name, v in table.items():
+            if key and key in name:
+                d["traffic"] = v["hbm_bytes_corrected"]
+                d["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE bytes/launch, profiles/r02_pmc_traffic.json"
+                break
+        d.update(extra)
+        return d
 
     fps_ms = time_kernel(lambda: pu.furthest_point_sample(xyz, m), reps, inner=1)
     inds = pu.furthest_point_sample(xyz, m)
@@ -105,7 +152,7 @@ def report(args, world, elapsed, loss, batch, ext):
     bq_ms = time_kernel(lambda: pu.ball_query(0.2, 64, xyz, new_xyz), reps)
     idx = pu.ball_query(0.2, 64, xyz, new_xyz)
 
-    # SA1 layer 1: gather + GEMM (135 -> 64) + BN statistics, the largest grouped-MLP product
+    # SA1 layer 1: gather + GEMM (135 -> 64) + BN statistics — the largest forward kernel of the critical path
     dt = torch.bfloat16 if bf else torch.float32
     C, cout, R = feat_pm.shape[2], 64, B * m * 64
     K1 = (C + 4 + (15 if bf else 7)) // (16 if bf else 8) * (16 if bf else 8)
@@ -115,72 +162,53 @@ def report(args, world, elapsed, loss, batch, ext):
     g_ms = time_kernel(lambda: ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1,
                                         cout, Y, stats, int(bf)), reps)
 
-    # match-module self-attention core: (B*L = 64, 256 queries, 256 keys, 4 heads x 32)
-    q = torch.randn(B * LANG_NUM, 256, 128, device=xyz.device)
+    # match-module attention cores: (B*L = 64, 256 queries, 4 heads x 32): self 256 keys, cross 49 keys
+    BL = B * LANG_NUM
+    q = torch.randn(BL, 256, 128, device=xyz.device)
+    kc = torch.randn(BL, NUM_TOKENS, 128, device=xyz.device)
     att_ms = time_kernel(lambda: fa.sdpa(q, q, q, 4, bf16_mma=bf), reps)
+    xat_ms = time_kernel(lambda: fa.sdpa(q, kc, kc, 4, bf16_mma=bf), reps)
 
     esz = 2 if bf else 4
-    fps_flops = B * (m - 1) * n * 11.0  # 11 flop per distance-update-compare
+    fps_flops = B * (m - 1) * n * 11.0  # 11 flop per distance-update-compare of the DENSE algorithm
     fps_peak = PEAK_FP32_VECTOR_TFLOPS * B / NUM_CUS  # one workgroup (CU) per scene
     bq_bytes = B * (12 * n + 12 * m + 4 * m * 64)
     g_bytes = B * n * C * 4 + B * m * 64 * 4 + R * cout * esz + B * n * 12  # features once + idx + Y + xyz
     g_flops = 2.0 * R * (C + 3) * cout
     att_bytes = 4 * q.numel() * 4
-
-    def entry(kernel, bound, work, peak, unit, ms, **extra):
-        ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
-        d = {"kernel": kernel, "bound": bound, "achieved": round(ach, 4), "peak": round(peak, 4), "unit": unit,
-             "frac": round(ach / peak, 4), "traffic": None, "ms": round(ms, 4)}
-        d.update(extra)
-        return d
-
-    kernels = [
-        entry("fps_pruned_kernel SA1 40000->2048 (bit-exact bounding-box pruned FPS; work = the dense algorithm's "
-              "B*(m-1)*n distance-update-compares)", "valu", fps_flops, fps_peak, "TFLOP/s", fps_ms, cus_used=B,
+    xat_bytes = (2 * q.numel() + 2 * kc.numel()) * 4
+    gname = ("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>")
+    head = entry(gname + " SA1 layer 1 (gather + 135->64 GEMM + BN sums): dominant critical-path kernel",
+                 "row_gemm_lds_kernel<64, 0, 0>" if bf else "row_gemm_kernel<float, 64, 0, 0>", "hbm", g_bytes,
+                 PEAK_HBM_GBS, "GB/s", g_ms, mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2),
+                 algorithmic_bytes=g_bytes)
+    others = [
+        entry("fps_pruned_kernel SA1 40000->2048 (side stream; bit-exact bounding-box pruned FPS)", "fps_pruned_kernel",
+              "valu", fps_flops, fps_peak, "TFLOP/s", fps_ms, cus_used=B,
+              numerator="ALGORITHMIC: the dense algorithm's B*(m-1)*n distance-update-compares x 11 flop; the kernel "
+                        "executes only the updates its bounding-box test cannot rule out (DESIGN.md §4.1)",
               hbm_algorithmic_GBs=round(B * (12 * n + 4 * m) / (fps_ms * 1e-3) / 1e9, 3),
               streaming_equiv_GBs=round(B * m * n * 20.0 / (fps_ms * 1e-3) / 1e9, 1)),
-        entry("ball_query_kernel<8> SA1 r=0.2 ns=64", "hbm", bq_bytes, PEAK_HBM_GBS, "GB/s", bq_ms,
-              tests_per_s=round(B * m * n / (bq_ms * 1e-3) / 1e12, 3)),
-        entry(("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>") +
-              " SA1 layer 1 (gather + 135->64 GEMM + BN sums)", "hbm", g_bytes, PEAK_HBM_GBS,
-              "GB/s", g_ms, mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2)),
-        entry(("sdpa_fwd_lds_kernel (bf16 MFMA, K/V shared through LDS)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
-              " match self-attention 64x(256x256) h4 d32",
-              "hbm", att_bytes, PEAK_HBM_GBS, "GB/s", att_ms, mfma_TFLOPs=round(4.0 * q.shape[0] * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
+        entry("ball_query_kernel SA1 r=0.2 ns=64", "ball_query", "hbm", bq_bytes, PEAK_HBM_GBS, "GB/s", bq_ms,
+              tests_per_s_T=round(B * m * n / (bq_ms * 1e-3) / 1e12, 3)),
+        entry(("sdpa_fwd_lds_kernel (bf16 MFMA)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
+              " match self-attention 64x(256x256) h4 d32", "sdpa_fwd", "hbm", att_bytes, PEAK_HBM_GBS, "GB/s", att_ms,
+              mfma_TFLOPs=round(4.0 * BL * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
+        entry(("sdpa_fwd_lds_kernel (bf16 MFMA)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
+              " match cross-attention 64x(256x49) h4 d32", None, "hbm", xat_bytes, PEAK_HBM_GBS, "GB/s", xat_ms,
+              mfma_TFLOPs=round(4.0 * BL * 256 * NUM_TOKENS * 128 / (xat_ms * 1e-3) / 1e12, 2)),
     ]
-    attach_pmc_traffic(kernels, bf)
-    out = {
-        "metric": "scenes/sec fwd+bwd, 40k-pt/256-proposal grounding",
-        "value": round(B_PER_GPU * world * args.steps / elapsed, 3),
-        "unit": "scenes/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg2: ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
-                   "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
-                   "step": "fwd + reduced loss + bwd + flat grad all-reduce + AdamW",
-                   "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs, bf16 MFMA "
-                                 "operands (fp32 I/O, softmax, accumulate) in the attention cores, fp32 elsewhere"
-                                 if bf else "fp32 everywhere (exact-fp32 MFMA)"),
-                   "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
-                   "geometry": "inline" if args.no_pipeline else
-                   "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)",
-                   "loss": float(loss.detach())},
-        # dominant hand-written kernel by time (3.6 ms, one workgroup per scene; off the critical path when pipelined)
-        "roofline": kernels[0],
-        "roofline_kernels": kernels[1:],
-    }
-    return out
+    return head, others
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline section (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute the backbone geometry (FPS / ball query) inline instead of one batch ahead")
@@ -223,20 +251,63 @@ def main():
     for _ in range(args.warmup):
         step.run(batch)
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         loss = step.run(batch)
+    marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda p: round(per_step[min(len(per_step) - 1, int(p * len(per_step)))], 3)
 
     if rank == 0:
-        out = report(args, world, elapsed, loss, batch, ext)
+        bf = args.dtype == "bf16"
+        ms = 1e3 * elapsed / args.steps
+        flops, byts = step_work(B_PER_GPU, 2 if bf else 4)
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_BF16_MFMA_TFLOPS / 16  # exact-fp32 MFMA: 1/16 of the bf16 rate
+        out = {
+            "metric": "scenes/sec fwd+bwd, 40k-pt/256-proposal grounding",
+            "value": round(B_PER_GPU * world * args.steps / elapsed, 3),
+            "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cfg2: ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
+                       "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
+                       "step": "fwd + the reference's loss (loss_joint.py: vote, objectness, box + sem-cls, DIoU + "
+                               "SoftmaxRankingLoss reference, OCC/OSC; epoch 50) + bwd + flat grad all-reduce + AdamW",
+                       "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs, bf16 MFMA "
+                                     "operands (fp32 I/O, softmax, accumulate) in the attention cores, fp32 elsewhere"
+                                     if bf else "fp32 everywhere (exact-fp32 MFMA)"),
+                       "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
+                       "geometry": "inline" if args.no_pipeline else
+                       "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)",
+                       "loss": float(loss.detach())},
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
+                        "how": "events on the launch stream between consecutive steps (this rank)"},
+            "roofline_step": {"flops_per_step": flops, "bytes_per_step": byts,
+                              "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2), "peak_TFLOPs": peak_tf,
+                              "frac_mfma": round(flops / (ms * 1e-3) / 1e12 / peak_tf, 4),
+                              "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1), "peak_GBs": PEAK_HBM_GBS,
+                              "frac_hbm": round(byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                              "note": "algorithmic dense flops (fwd x3) and stored-activation bytes of one step on this "
+                                      "rank's scenes; the step is latency / launch bound, both fractions are small"},
+        }
+        if not args.no_kernels:
+            out["roofline"], out["roofline_kernels"] = kernel_rooflines(args, batch, ext)
+            out["hw"] = measure_hw(ext, device)
+        else:
+            out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch_np)
+            from oracle import baseline
+            out["cpu_baseline"] = baseline.cpu_baseline(batch_np, scenes=1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

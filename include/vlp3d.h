@@ -318,6 +318,15 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
                    int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, int bf16_mma,
                    int ldq, int ldk, int ldv, void *stream);
 
+/* ---- hardware-denominator probes (csrc/hwprobe.hip; measurement only) --------------------
+ * vlp3d_probe_read: streaming 16-byte-load read of `bytes` (multiple of 16, >= 16 KiB) with `blocks` workgroups;
+ * vlp3d_probe_mfma_bf16: blocks*4 waves each issue iters*4 independent v_mfma_f32_32x32x16_bf16
+ *   (flops = blocks*4*iters*4*2*32*32*16);  vlp3d_probe_fma_f32: blocks*256 lanes x iters x 8 independent FMAs
+ *   (flops = blocks*256*iters*16).  `sink`: one float, never written for real data. */
+int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, void *stream);
+int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
+int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

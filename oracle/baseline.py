@@ -1,76 +1,157 @@
-"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU baseline for bench.py's `cpu_baseline` leg.
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU baseline for bench.py's `cpu_baseline` leg (kind "port").
 
-Times the oracle's FORWARD pass of the grounding path on ONE synthetic scene of the bench workload
-(40 000 points, 256 proposals, 8 sentences): geometry (FPS / ball query / group / three_nn /
-interpolate) in the OpenMP C restatement, dense layers (SharedMLP, attention) in numpy.  The oracle
-has no backward, so the figure is forward-only and says so; it is a reported baseline, not a target.
+One full TRAINING step (forward + the reference's loss + backward + AdamW) of the grounding path on the host CPU:
+  * geometry (FPS, ball query, three_nn) by the C/OpenMP restatement of the reference's kernels (pointnet2_oracle.c);
+  * grouping / interpolation as torch index ops, every dense layer (SharedMLP 1x1 convs + BatchNorm, voting, ROI heads,
+    relation / match attention, contrast heads) and the loss (3dvlp_amd.losses, impl="torch") through PyTorch-CPU
+    autograd — the same nn.Modules and parameters as the GPU path, on their explicit pure-torch branches.
+The reference's own ops have no CPU implementation at all (sampling.cpp:39 "CPU not supported"), so this port is what
+"the reference's CPU path" can mean on this box.  It is a reported baseline, not a target.
 """
+import importlib
 import os
 import time
 
 import numpy as np
+import torch
+import torch.nn.functional as F
 
 from . import oracle as orc
 
 
-def _layers(rng, dims):
-    return [dict(w=rng.normal(0, 0.1, (dims[i + 1], dims[i])).astype(np.float32), gamma=np.ones(dims[i + 1]),
-                 beta=np.zeros(dims[i + 1]), mean=np.zeros(dims[i + 1]), var=np.ones(dims[i + 1]))
-            for i in range(len(dims) - 1)]
-
-
-def _mha_weights(rng, prefix=""):
-    W = {}
-    for n in ("q", "k", "v", "o"):
-        W[f"{prefix}attention.fc_{n}.weight"] = rng.normal(0, 0.08, (128, 128))
-        W[f"{prefix}attention.fc_{n}.bias"] = np.zeros(128)
-    W[f"{prefix}layer_norm.weight"], W[f"{prefix}layer_norm.bias"] = np.ones(128), np.zeros(128)
-    return W
-
-
-def scene_forward(xyz, feats, lang_num=8, seed=0):
-    """xyz (1,N,3), feats (1,C,N). Returns (seconds, breakdown dict)."""
-    rng = np.random.default_rng(seed)
-    t = {}
-    t0 = time.perf_counter()
-    cfg = [(2048, 0.2, 64, [feats.shape[1] + 3, 64, 64, 128]), (1024, 0.4, 32, [131, 128, 128, 256]),
-           (512, 0.8, 16, [259, 128, 128, 256]), (256, 1.2, 16, [259, 128, 128, 256])]
-    cur_xyz, cur_f = xyz, feats
-    levels = []
-    for i, (m, r, ns, dims) in enumerate(cfg):
-        s = time.perf_counter()
-        cur_xyz, cur_f, _ = orc.sa_module_votes(cur_xyz, cur_f, _layers(rng, dims), m, r, ns, training=True)
-        levels.append((cur_xyz, cur_f))
-        t[f"sa{i + 1}"] = time.perf_counter() - s
-    s = time.perf_counter()
-    f = orc.fp_module(levels[2][0], levels[3][0], levels[2][1], levels[3][1], _layers(rng, [512, 256, 256]), True)
-    f = orc.fp_module(levels[1][0], levels[2][0], levels[1][1], f, _layers(rng, [512, 256, 256]), True)
-    t["fp"] = time.perf_counter() - s
-    s = time.perf_counter()
-    vote_xyz = levels[1][0] + rng.normal(0, 0.05, levels[1][0].shape).astype(np.float32)
-    agg_xyz, agg_f, _ = orc.sa_module_votes(vote_xyz, f, _layers(rng, [259, 128, 128, 128]), 256, 0.3, 16, True)
-    t["vote_agg"] = time.perf_counter() - s
-    s = time.perf_counter()
-    x = agg_f.transpose(0, 2, 1).astype(np.float64)
-    for _ in range(2):  # relation self-attention
-        x, _ = orc.multi_head_attention(_mha_weights(rng), x, x, x, 4)
-    xq = np.repeat(x, lang_num, axis=0)
-    lang = rng.normal(size=(lang_num, 49, 128))
-    for _ in range(2):  # match decoder layers
-        W = {}
-        W.update(_mha_weights(rng, "self_attention."))
-        W.update(_mha_weights(rng, "enc_dec_attention."))
-        W.update({"ffn.linear1.weight": rng.normal(0, 0.08, (256, 128)), "ffn.linear1.bias": np.zeros(256),
-                  "ffn.linear2.weight": rng.normal(0, 0.08, (128, 256)), "ffn.linear2.bias": np.zeros(128),
-                  "norm.weight": np.ones(128), "norm.bias": np.zeros(128)})
-        xq = orc.cross_attention_decoder_layer(W, xq, lang, lang)
-    t["attention"] = time.perf_counter() - s
-    s = time.perf_counter()
-    orc.nn_distance(agg_xyz, agg_xyz)
-    t["nn_distance"] = time.perf_counter() - s
-    return time.perf_counter() - t0, t
-
-
 def threads_used():
-    """Threads the C/OpenMP part actually runs on (numpy's BLAS may use its own pool for the dense part)."""
+    """Threads the C/OpenMP part runs on."""
     return int(orc.lib().orc_num_threads())
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def _sa_cpu(sa, xyz, features):
+    """PointnetSAModuleVotes.forward (pointnet2_modules.py:210-272) on CPU tensors: oracle geometry + torch dense."""
+    B, N, _ = xyz.shape
+    x = np.ascontiguousarray(_np(xyz), np.float32)
+    inds = orc.furthest_point_sampling(x, sa.npoint)
+    new_x = np.stack([x[b, inds[b]] for b in range(B)])
+    idx = torch.from_numpy(orc.ball_query(new_x, x, sa.radius, sa.nsample).astype(np.int64))  # (B,M,S)
+    M, S = idx.shape[1:]
+    ii = torch.from_numpy(inds.astype(np.int64))
+    new_xyz = torch.gather(xyz, 1, ii[..., None].expand(-1, -1, 3))                            # autograd to xyz
+    flat = idx.reshape(B, 1, M * S)
+    gx = torch.gather(xyz.transpose(1, 2), 2, flat.expand(-1, 3, -1)).reshape(B, 3, M, S)
+    gx = (gx - new_xyz.transpose(1, 2).unsqueeze(-1)) / sa.radius
+    gf = torch.gather(features, 2, flat.expand(-1, features.shape[1], -1)).reshape(B, -1, M, S)
+    y = sa.mlp_module(torch.cat([gx, gf], 1))
+    return new_xyz, F.max_pool2d(y, kernel_size=[1, S]).squeeze(-1), ii
+
+
+def _fp_cpu(fp, unknown, known, unknow_feats, known_feats):
+    """PointnetFPModule.forward (pointnet2_modules.py:371-416)."""
+    d2, idx = orc.three_nn(_np(unknown), _np(known))
+    dist = torch.from_numpy(np.sqrt(d2))
+    recip = 1.0 / (dist + 1e-8)
+    w = recip / recip.sum(2, keepdim=True)
+    idx = torch.from_numpy(idx.astype(np.int64))
+    B, n, _ = idx.shape
+    C = known_feats.shape[1]
+    g = torch.gather(known_feats, 2, idx.reshape(B, 1, n * 3).expand(-1, C, -1)).reshape(B, C, n, 3)
+    interp = (g * w.unsqueeze(1)).sum(-1)
+    return fp.mlp(torch.cat([interp, unknow_feats], 1).unsqueeze(-1)).squeeze(-1)
+
+
+class CpuStep:
+    """The whole step on the CPU.  `net` is a 3dvlp_amd.grounding_step.GroundingNet built on the CPU."""
+
+    def __init__(self, seed=0, lr=1e-3):
+        self.gs = importlib.import_module("3dvlp_amd.grounding_step")
+        self.losses = importlib.import_module("3dvlp_amd.losses")
+        tr = importlib.import_module("3dvlp_amd.transformer")
+        torch.manual_seed(seed)
+        self.net = self.gs.GroundingNet().train()
+        for m in self.net.modules():
+            if isinstance(m, tr.ScaledDotProductAttention):
+                m.impl = "torch"      # explicit unfused attention: the CPU branch of the module
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=1e-5)
+
+    def forward_loss(self, batch):
+        net = self.net
+        d = dict(batch)
+        d["epoch"] = 50
+        pc = d["point_clouds"]
+        xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+        bb = net.backbone_net
+        lv = []
+        for sa in (bb.sa1, bb.sa2, bb.sa3, bb.sa4):
+            xyz, feats, inds = _sa_cpu(sa, xyz, feats)
+            lv.append((xyz, feats, inds))
+        f = _fp_cpu(bb.fp1, lv[2][0], lv[3][0], lv[2][1], lv[3][1])
+        f = _fp_cpu(bb.fp2, lv[1][0], lv[2][0], lv[1][1], f)
+        d["seed_inds"], d["seed_xyz"], d["seed_features"] = lv[0][2][:, :lv[1][0].shape[1]].int(), lv[1][0], f
+        vx, vf = net.vgen(lv[1][0], f)
+        vf = vf.div(torch.norm(vf, p=2, dim=1).unsqueeze(1))
+        d["vote_xyz"], d["vote_features"] = vx, vf
+        prop = net.proposal
+        ax, af, ai = _sa_cpu(prop.vote_aggregation, vx, vf)
+        d["aggregated_vote_xyz"], d["aggregated_vote_inds"] = ax, ai.int()
+        d["aggregated_vote_features"] = af.permute(0, 2, 1).contiguous()
+        d = prop.decode_scores(prop.proposal(af, d))
+        d = net.match(net.relation(d))
+        d = net.constrast(d)
+        self.losses.get_joint_loss(None, d, config=net.dataset_config, impl="torch")
+        return d["loss"]
+
+    def step(self, batch):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.forward_loss(batch)
+        loss.backward()
+        self.opt.step()
+        return float(loss.detach())
+
+
+def to_torch(batch_np, scenes):
+    L = batch_np["lang_fea"].shape[0] // batch_np["point_clouds"].shape[0]
+    out = {}
+    for k, v in batch_np.items():
+        per_sentence = k in ("lang_fea", "lang_emb")
+        out[k] = torch.from_numpy(np.ascontiguousarray(v[:scenes * L] if per_sentence else v[:scenes]))
+    out["istrain"] = [1]
+    out["random"] = torch.tensor(0.75)
+    return out
+
+
+def timed_step(batch_np, scenes, threads, reps=1):
+    """Seconds per full step (fwd + loss + bwd + AdamW) on `scenes` scenes with `threads` host threads."""
+    torch.set_num_threads(threads)
+    orc.lib().orc_set_num_threads(int(threads))
+    step = CpuStep()
+    batch = to_torch(batch_np, scenes)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step.step(batch)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def cpu_baseline(batch_np, scenes=1):
+    """-> the `cpu_baseline` object of bench.py's JSON line: all host cores, plus a single-thread figure."""
+    cores = os.cpu_count() or 1
+    t_all = timed_step(batch_np, scenes, cores, reps=2)  # best of two: the first call pays one-time thread-pool start-up
+    t_one = timed_step(batch_np, scenes, 1)
+    torch.set_num_threads(cores)
+    orc.lib().orc_set_num_threads(cores)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(scenes / t_all, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(scenes / t_one, 4), "cpu_model": model,
+            "sample": f"{scenes} scene(s) of the same workload (40k pts, 256 proposals, 8 sentences), ONE full training "
+                      f"step each (fwd + reference loss + bwd + AdamW): C/OpenMP geometry + PyTorch-CPU autograd; "
+                      f"{t_all:.2f} s on {cores} threads, {t_one:.2f} s on 1 thread"}

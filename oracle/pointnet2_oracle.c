@@ -45,6 +45,15 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* Limit the OpenMP team (the CPU baseline reports an all-cores and a single-thread figure). */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 static inline float sumsq3(float a, float b, float c, int contract) {
   if (contract == 1) return fmaf(c, c, fmaf(a, a, b * b));
   if (contract == 2) return fmaf(c, c, fmaf(b, b, a * a));

@@ -159,6 +159,7 @@ def test_fused_joint_loss_equals_torch_form(shape, epoch, coin, NH):
         assert abs(float(a[0][k]) - float(b[0][k])) <= 1e-4 * max(1e-3, abs(float(a[0][k]))), (k, float(a[0][k]), float(b[0][k]))
     assert torch.equal(a[0]["cluster_labels"], b[0]["cluster_labels"])
     assert torch.equal(a[0]["objectness_label"], b[0]["objectness_label"])
+    assert torch.equal(a[0]["objectness_mask"], b[0]["objectness_mask"])
     assert torch.equal(a[0]["object_assignment"], b[0]["object_assignment"])
     for k in DIFF:
         ga, gb = a[1][k], b[1][k]
