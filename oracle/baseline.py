@@ -137,7 +137,14 @@ def timed_step(batch_np, scenes, threads, reps=1):
 
 def cpu_baseline(batch_np, scenes=1):
     """-> the `cpu_baseline` object of bench.py's JSON line: all host cores, plus a single-thread figure."""
-    cores = os.cpu_count() or 1
+    # the threads this process may really use: its affinity mask, capped at the GPU box's per-GPU CPU share (16) —
+    # os.cpu_count() reports every core of the host (256 on the MI355X boxes) and oversubscribing them made the
+    # all-cores run 100x SLOWER than one thread
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("VLP3D_CPU_BASELINE_THREADS", 16))))
     t_all = timed_step(batch_np, scenes, cores, reps=2)  # best of two: the first call pays one-time thread-pool start-up
     t_one = timed_step(batch_np, scenes, 1)
     torch.set_num_threads(cores)

@@ -164,5 +164,6 @@ def test_fused_joint_loss_equals_torch_form(shape, epoch, coin, NH):
     for k in DIFF:
         ga, gb = a[1][k], b[1][k]
         scale = ga.abs().max().item()
-        assert scale > 0, k                                  # every input really receives gradient in this case
+        if not (k == "heading_scores" and NH == 1):          # a one-bin softmax has zero gradient by construction
+            assert scale > 0, k                              # every other input really receives gradient in this case
         assert (ga - gb).abs().max().item() <= 1e-4 * scale + 1e-9, (k, (ga - gb).abs().max().item(), scale)
