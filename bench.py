@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline section (profiling runs)")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="after the timed steps, gather a checksum of every rank's parameters into the JSON line")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute the backbone geometry (FPS / ball query) inline instead of one batch ahead")
@@ -266,6 +268,18 @@ def main():
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda p: round(per_step[min(len(per_step) - 1, int(p * len(per_step)))], 3)
 
+    checks = None
+    if args.check_replicas:
+        flat = torch.cat([p.detach().reshape(-1).double() for p in step.model.parameters()])
+        mine = torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(1, flat.numel() + 1, device=device)
+                                                           .double().remainder(97.0)).sum()])
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(gathered, mine)
+        else:
+            gathered = [mine]
+        checks = [[float(v) for v in g.cpu()] for g in gathered]
+
     if rank == 0:
         bf = args.dtype == "bf16"
         ms = 1e3 * elapsed / args.steps
@@ -305,6 +319,8 @@ def main():
             out["hw"] = measure_hw(ext, device)
         else:
             out["roofline"] = None
+        if checks is not None:
+            out["replica_param_checksums"] = checks
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline
             out["cpu_baseline"] = baseline.cpu_baseline(batch_np, scenes=1)

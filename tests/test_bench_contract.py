@@ -37,3 +37,29 @@ def test_bench_json_line_contract():
     assert "fps" in names and "ball_query" in names and "cross-attention" in names
     hw = d["hw"]
     assert 2000 < hw["hbm_read_GBs"] < 9000 and 500 < hw["bf16_mfma_TFLOPs"] < 3000 and 50 < hw["fp32_fma_TFLOPs"] < 200
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """The data-parallel path end to end on the hardware we do have: two fresh ranks (torch.distributed.run children,
+    started before they touch the GPU) share cuda:0, gradients go through the flat-bucket all-reduce (gloo stands in for
+    RCCL on a one-GPU box), and after the steps both replicas hold identical parameters."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VLP3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-kernels", "--check-replicas"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    a, b = d["replica_param_checksums"]
+    assert a == b, (a, b)                      # identical replicas after averaged-gradient steps
+    assert d["config"]["loss"] == d["config"]["loss"] and d["config"]["loss"] > 0   # finite
