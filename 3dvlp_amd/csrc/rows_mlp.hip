@@ -1,0 +1,384 @@
+// Exact-fp32 dense stacks on FEW rows (R <= 64K): the 1x1 Conv(+bias) -> BatchNorm -> ReLU chains of the feature-
+// propagation modules (lib/pointnet2/pointnet2_modules.py:403-416), the voting module (voting_module.py:33-60) and the ROI
+// heads (roi_heads.py:15-147) as matrix-core products on ROW-MAJOR (point-major) matrices — no NCHW convolutions, layout
+// transposes, library BatchNorm or separate ReLU kernels.  Same arithmetic as the grouped per-ball MLP (csrc/sa_mlp.hip):
+// train-mode BatchNorm = column statistics of the pre-activation Y, folded into per-channel scale/shift that the NEXT
+// product applies while loading its A operand; backward folds BatchNorm/ReLU backward into loaders and epilogues.
+//
+// One wave owns a 32 x 32 output tile (few rows: a wave per tile gives 4-8x more waves than a wave per 32 x N) and walks
+// the whole K with v_mfma_f32_32x32x2_f32 (exact fp32: these layers are part of the 1e-4 parity gate).
+//   LOADER  PLAIN   a = X[r][k]
+//           BNRELU  a = relu(X[r][k] * scale[k] + shift[k])                (X = previous pre-activation)
+//           BNBWD   a = k1[k] * (G[r][k] - k2[k] - (X[r][k]*rstd[k] + nmr[k]) * k3[k])   (BatchNorm backward of (G, Y = X))
+//   EPI     STORE   Y = acc, per-column sum / sum of squares -> this workgroup's slab (fp64, no atomics)
+//           BIAS    Y = acc + bias (bias may be NULL)
+//           MASK    G = relu'(Yprev*p_scale + p_shift) * acc, column sums of G and G * yhat_prev -> slab
+// The weight is (N x K) row-major, or K-major (wt = 1: (K x ldw), i.e. the SAME buffer read as the transposed operand of
+// the input-gradient product — no transposed copies).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+enum Loader { PLAIN = 0, BNRELU = 1, BNBWD = 2 };
+enum Epilogue { STORE = 0, BIAS = 1, MASK = 2 };
+
+struct RowsArgs {
+  const float *X, *G;  // A operand source(s), row stride ldx
+  int ldx;
+  const float *a_scale, *a_shift;  // BNRELU
+  const float *bn5;                // BNBWD: [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)], each of length K
+  const float *W;
+  int ldw, wt;
+  int K, N;
+  long long R;
+  float *Y;
+  int ldy;
+  const float *bias;
+  double *stats;  // STORE / MASK: slabs [gridDim.x][2][N]
+  const float *Yprev;
+  int ldprev;
+  const float *p_vec;  // MASK: [scale | shift | rstd | -mean*rstd] of the previous BatchNorm, each of length N
+};
+
+__device__ __forceinline__ int acc_row(int i, int half) { return (i & 3) + 8 * (i >> 2) + 4 * half; }
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Raw operands of one 32-wide K chunk for a lane: 4 steps x (A float4 [+ G float4], W float4), all requested before
+// anything is consumed.  The loader's per-column constants (L1-resident vectors) are fetched when the chunk is consumed —
+// behind the previous chunk's queued MFMAs — instead of riding along in the double buffer (160 more registers).
+template <int LOADER>
+struct Chunk {
+  float4 x[4], g[4], w[4];
+};
+
+template <int LOADER>
+__device__ __forceinline__ void chunk_load(const RowsArgs &a, long long row, int col, int kbase, int half, Chunk<LOADER> &c) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k0 = kbase + 8 * s + 4 * half;  // lane half h covers columns 8s + 4h .. +3 of the chunk
+    c.x[s] = ld4(a.X + row * a.ldx + k0);
+    if (LOADER == BNBWD) c.g[s] = ld4(a.G + row * a.ldx + k0);
+    if (a.wt) {  // K-major weight: four dword loads, each coalesced over the lanes' 32 output columns
+      const float *wp = a.W + (long long)k0 * a.ldw + col;
+      c.w[s] = make_float4(wp[0], wp[a.ldw], wp[2 * a.ldw], wp[3 * a.ldw]);
+    } else {
+      c.w[s] = ld4(a.W + (long long)col * a.ldw + k0);
+    }
+  }
+}
+
+template <int LOADER>
+__device__ __forceinline__ void chunk_mma(const RowsArgs &a, int kbase, int half, const Chunk<LOADER> &c, f32x16 &acc) {
+  float4 k_a[4], k_b[4], k_c[4], k_d[4], k_e[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k0 = kbase + 8 * s + 4 * half;
+    if (LOADER == BNRELU) {
+      k_a[s] = ld4(a.a_scale + k0);
+      k_b[s] = ld4(a.a_shift + k0);
+    } else if (LOADER == BNBWD) {
+      k_a[s] = ld4(a.bn5 + k0);
+      k_b[s] = ld4(a.bn5 + a.K + k0);
+      k_c[s] = ld4(a.bn5 + 2 * a.K + k0);
+      k_d[s] = ld4(a.bn5 + 3 * a.K + k0);
+      k_e[s] = ld4(a.bn5 + 4 * a.K + k0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float4 av = c.x[s];
+    if (LOADER == BNRELU) {
+      const float4 sc = k_a[s], sh = k_b[s];
+      av = make_float4(fmaxf(0.f, av.x * sc.x + sh.x), fmaxf(0.f, av.y * sc.y + sh.y), fmaxf(0.f, av.z * sc.z + sh.z),
+                       fmaxf(0.f, av.w * sc.w + sh.w));
+    } else if (LOADER == BNBWD) {
+      const float4 x = c.x[s], g = c.g[s], rs = k_a[s], nm = k_b[s], k1 = k_c[s], k2 = k_d[s], k3 = k_e[s];
+      av = make_float4(k1.x * (g.x - k2.x - (x.x * rs.x + nm.x) * k3.x), k1.y * (g.y - k2.y - (x.y * rs.y + nm.y) * k3.y),
+                       k1.z * (g.z - k2.z - (x.z * rs.z + nm.z) * k3.z), k1.w * (g.w - k2.w - (x.w * rs.w + nm.w) * k3.w));
+    }
+    const float4 bv = c.w[s];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+}
+
+template <int LOADER, int EPI>
+__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {  // <= 256 registers: two waves per SIMD
+  __shared__ double red[4][2][32];
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = blockIdx.y * 32, col = c0 + r;  // this block's 32 output columns
+  const long long ntiles = a.R / 32;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const long long row = tile * 32 + r;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // K in chunks of 32, software-pipelined by hand: chunk c+1's 8..32 loads are in flight while chunk c is on the matrix
+    // cores (a wave walks its tile alone; the one-step loop exposed a full memory latency per 8 columns: 45 us for
+    // 8192 x 512 x 256, the products themselves are ~7 us per wave)
+    Chunk<LOADER> ca, cb;
+    chunk_load<LOADER>(a, row, col, 0, half, ca);
+    for (int kb = 0; kb < a.K; kb += 64) {
+      if (kb + 32 < a.K) chunk_load<LOADER>(a, row, col, kb + 32, half, cb);
+      chunk_mma<LOADER>(a, kb, half, ca, acc);
+      if (kb + 32 >= a.K) break;
+      if (kb + 64 < a.K) chunk_load<LOADER>(a, row, col, kb + 64, half, ca);
+      chunk_mma<LOADER>(a, kb + 32, half, cb, acc);
+    }
+    // acc[i] = element (row tile*32 + acc_row(i, half), column col)
+    if (EPI == STORE) {
+      float ps = 0.f, pq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = acc[i];
+        a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = v;
+        ps += v;
+        pq += v * v;
+      }
+      s1 += (double)ps;
+      s2 += (double)pq;
+    } else if (EPI == BIAS) {
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = acc[i] + bv;
+    } else {  // MASK
+      const float sc = a.p_vec[col], sh = a.p_vec[a.N + col], rs = a.p_vec[2 * a.N + col], nm = a.p_vec[3 * a.N + col];
+      float ps = 0.f, pq = 0.f;
+      float yv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yv[i] = a.Yprev[(tile * 32 + acc_row(i, half)) * a.ldprev + col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float g = (yv[i] * sc + sh > 0.f) ? acc[i] : 0.f;
+        a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = g;
+        ps += g;
+        pq += g * (yv[i] * rs + nm);
+      }
+      s1 += (double)ps;
+      s2 += (double)pq;
+    }
+  }
+  if (EPI == STORE || EPI == MASK) {  // this workgroup's share of the column reductions -> its slab, columns c0..c0+31
+    const double t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+    if (half == 0) {
+      red[wave][0][r] = t1;
+      red[wave][1][r] = t2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      a.stats[((size_t)blockIdx.x * 2 + which) * a.N + c0 + c] =
+          (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+  }
+}
+
+// out = relu(Y * scale + shift): the activation of the LAST BatchNorm layer of a stack, 4 columns per thread
+__global__ __launch_bounds__(256) void rows_act_kernel(const float *__restrict__ Y, long long n4, int C,
+                                                       const float *__restrict__ vec, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const float4 y = ld4(Y + i * 4), sc = ld4(vec + c), sh = ld4(vec + C + c);
+  *reinterpret_cast<float4 *>(out + i * 4) =
+      make_float4(fmaxf(0.f, y.x * sc.x + sh.x), fmaxf(0.f, y.y * sc.y + sh.y), fmaxf(0.f, y.z * sc.z + sh.z),
+                  fmaxf(0.f, y.w * sc.w + sh.w));
+}
+
+// G = dOut * [Y*scale + shift > 0], per-workgroup column sums of G and G*yhat -> slab [blockIdx.x][2][C]; thread = column
+__global__ __launch_bounds__(256) void rows_act_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ Y,
+                                                           long long R, int C, const float *__restrict__ vec,
+                                                           long long rows_per_block, float *__restrict__ G,
+                                                           double *__restrict__ slabs) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sc = vec[c], sh = vec[C + c], rs = vec[2 * C + c], nm = vec[3 * C + c];
+    double s1 = 0.0, s2 = 0.0;
+    long long r = r0;
+    for (; r + 4 <= r1; r += 4) {  // four rows in flight
+      float y[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        y[u] = Y[(r + u) * C + c];
+        d[u] = dOut[(r + u) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float g = (y[u] * sc + sh > 0.f) ? d[u] : 0.f;
+        G[(r + u) * C + c] = g;
+        s1 += g;
+        s2 += g * (y[u] * rs + nm);
+      }
+    }
+    for (; r < r1; ++r) {
+      const float y = Y[r * C + c];
+      const float g = (y * sc + sh > 0.f) ? dOut[r * C + c] : 0.f;
+      G[r * C + c] = g;
+      s1 += g;
+      s2 += g * (y * rs + nm);
+    }
+    slabs[((size_t)blockIdx.x * 2) * C + c] = s1;
+    slabs[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
+  }
+}
+
+// ---- feature propagation glue on point-major rows (pointnet2_modules.py:393-411) -------------------------------------
+// X[b,n,:] = [ sum_k w[b,n,k] * known[b, idx[b,n,k], :]  |  unknown[b,n,:] ]   (three_interpolate + torch.cat)
+__global__ __launch_bounds__(256) void fp_rows_kernel(const float *__restrict__ known, const float *__restrict__ unknown,
+                                                      const int *__restrict__ idx, const float *__restrict__ w, int B,
+                                                      int n, int m, int C1, int C2, float *__restrict__ X) {
+  const int ld = C1 + C2, q = ld / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * n * q) return;
+  const long long bn = t / q;
+  const int c = (int)(t - bn * q) * 4;
+  float4 v;
+  if (c < C1) {
+    const int b = (int)(bn / n);
+    const int *ip = idx + bn * 3;
+    const float *wp = w + bn * 3;
+    const float4 p1 = ld4(known + ((long long)b * m + ip[0]) * C1 + c), p2 = ld4(known + ((long long)b * m + ip[1]) * C1 + c),
+                 p3 = ld4(known + ((long long)b * m + ip[2]) * C1 + c);
+    const float w1 = wp[0], w2 = wp[1], w3 = wp[2];
+    v = make_float4(vlp3d_blend3(p1.x, w1, p2.x, w2, p3.x, w3), vlp3d_blend3(p1.y, w1, p2.y, w2, p3.y, w3),
+                    vlp3d_blend3(p1.z, w1, p2.z, w2, p3.z, w3), vlp3d_blend3(p1.w, w1, p2.w, w2, p3.w, w3));
+  } else {
+    v = ld4(unknown + bn * C2 + (c - C1));
+  }
+  *reinterpret_cast<float4 *>(X + bn * ld + c) = v;
+}
+
+// adjoint: d_known[b, j, :] += w * dX[b, n, :C1] over the three neighbours (m known points of a scene accumulate in LDS:
+// one workgroup = one scene x a slab of CH channels), d_unknown = dX[:, C1:] is a VIEW taken by the caller.
+template <int CH>
+__global__ __launch_bounds__(256) void fp_rows_grad_kernel(const float *__restrict__ dX, const int *__restrict__ idx,
+                                                           const float *__restrict__ w, int n, int m, int C1, int ld,
+                                                           float *__restrict__ dknown) {
+  extern __shared__ float acc[];  // [m][CH]
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  for (int i = threadIdx.x; i < m * CH; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * CH; e += 256) {
+    const int p = e / CH, c = e - p * CH;
+    const long long bn = (long long)b * n + p;
+    const float g = dX[bn * ld + c0 + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(&acc[idx[bn * 3 + k] * CH + c], g * w[bn * 3 + k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m * CH; i += 256) {
+    const int j = i / CH, c = i - j * CH;
+    dknown[((long long)b * m + j) * C1 + c0 + c] = acc[i];
+  }
+}
+
+template <int LOADER, int EPI>
+int launch(const RowsArgs &a, hipStream_t s) {
+  const long long blocks = (a.R / 32 + 3) / 4;
+  const dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024), a.N / 32);
+  hipLaunchKernelGGL((rows_gemm_kernel<LOADER, EPI>), grid, dim3(256), 0, s, a);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+bool bad_gemm(const float *X, const float *W, const float *Y, long long R, int K, int N, int ldx, int ldw, int ldy) {
+  return !X || !W || !Y || R < 32 || (R & 31) || R > (1ll << 24) || K < 32 || (K & 31) || N < 32 || (N & 31) || ldx < K ||
+         (ldx & 3) || ldw < 1 || ldy < N;
+}
+
+}  // namespace
+
+// workgroups (= statistic slabs of 2*N doubles each) a rows product over R rows is launched with
+extern "C" int vlp3d_rows_slabs(long long R) {
+  const long long blocks = (R / 32 + 3) / 4;
+  return (int)(blocks < 1024 ? blocks : 1024);
+}
+
+// Y (R x N, row stride ldy) = A W^T [+ bias], A = X (a_vec NULL) or relu(X*scale + shift) (a_vec = [scale | shift | ..],
+// each of length K: the `vec` of vlp3d_sa_bn_fold).  stats != NULL: no bias, per-column sums of Y -> slabs
+// [vlp3d_rows_slabs(R)][2][N] for vlp3d_sa_bn_fold.  W (N x K) row-major.  R % 32 == 0, K % 32 == 0, N % 32 == 0.
+extern "C" int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W,
+                              const float *bias, int N, float *Y, int ldy, double *stats, void *stream) {
+  if (bad_gemm(X, W, Y, R, K, N, ldx, K, ldy) || (stats && bias)) return VLP3D_EINVAL;
+  RowsArgs a = {};
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = K; a.K = K; a.N = N; a.R = R; a.Y = Y; a.ldy = ldy; a.bias = bias; a.stats = stats;
+  if (a_vec) { a.a_scale = a_vec; a.a_shift = a_vec + K; }
+  hipStream_t s = (hipStream_t)stream;
+  if (a_vec) return stats ? launch<BNRELU, STORE>(a, s) : launch<BNRELU, BIAS>(a, s);
+  return stats ? launch<PLAIN, STORE>(a, s) : launch<PLAIN, BIAS>(a, s);
+}
+
+// Input gradient of a layer Y = A W^T with W (N x K): dA (R x K) = dY W, dY = G (bn5 NULL) or BatchNorm-backward of
+// (G, Ypre) with the constants bn5 [5][N] of vlp3d_sa_bn_bwd_consts.  p_vec != NULL: A was relu(BN(Yprev)) — the result
+// is masked with relu'(Yprev*scale + shift) (p_vec = that layer's `vec` [4][K]) and the column sums of the masked
+// gradient / gradient * yhat_prev go to tstats slabs [vlp3d_rows_slabs(R)][2][K]; p_vec NULL: plain store (the stack's
+// input gradient).  K % 32 == 0, N % 32 == 0.
+extern "C" int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R,
+                                int N, int K, const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda,
+                                double *tstats, void *stream) {
+  if (bad_gemm(G, W, dA, R, N, K, ldg, K, lda) || (bn5 && !Ypre) || (p_vec && (!Yprev || !tstats || ldprev < K)))
+    return VLP3D_EINVAL;
+  RowsArgs a = {};
+  a.ldx = ldg; a.W = W; a.ldw = K; a.wt = 1; a.K = N; a.N = K; a.R = R; a.Y = dA; a.ldy = lda;
+  if (bn5) { a.X = Ypre; a.G = G; a.bn5 = bn5; } else { a.X = G; }
+  a.Yprev = Yprev; a.ldprev = ldprev; a.p_vec = p_vec; a.stats = tstats;
+  hipStream_t s = (hipStream_t)stream;
+  if (bn5) return p_vec ? launch<BNBWD, MASK>(a, s) : launch<BNBWD, BIAS>(a, s);
+  return p_vec ? launch<PLAIN, MASK>(a, s) : launch<PLAIN, BIAS>(a, s);
+}
+
+// out (R x C) = relu(Y * scale + shift), vec = [scale | shift | ..] of length C each.  C % 4 == 0.
+extern "C" int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream) {
+  if (!Y || !vec || !out || R < 1 || C < 4 || (C & 3)) return VLP3D_EINVAL;
+  const long long n4 = R * C / 4;
+  hipLaunchKernelGGL(rows_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Y, n4, C, vec, out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// G (R x C) = dOut masked by the ReLU of the last BatchNorm layer, tstats slabs [nslab][2][C] (nslab returned by
+// vlp3d_rows_act_slabs) for vlp3d_sa_bn_bwd_consts.  vec = that layer's [scale | shift | rstd | -mean*rstd].
+extern "C" int vlp3d_rows_act_slabs(long long R) {
+  const long long n = (R + 63) / 64;
+  return (int)(n < 256 ? n : 256);
+}
+extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G,
+                                  double *tstats, void *stream) {
+  if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 1) return VLP3D_EINVAL;
+  const int nslab = vlp3d_rows_act_slabs(R);
+  const long long rpb = (R + nslab - 1) / nslab;
+  hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, rpb, G, tstats);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// Feature-propagation rows: X (B*n, C1 + C2) = [three_interpolate(known (B,m,C1) point-major, idx, weight) | unknown
+// (B,n,C2) point-major] — pointnet2_modules.py:393-411 without the (B,C,n) round trips.  C1, C2 % 4 == 0.
+extern "C" int vlp3d_fp_rows(const float *known, const float *unknown, const int *idx, const float *weight, int B, int n,
+                             int m, int C1, int C2, float *X, void *stream) {
+  if (!known || !unknown || !idx || !weight || !X || B < 1 || n < 1 || m < 1 || C1 < 4 || (C1 & 3) || C2 < 4 || (C2 & 3))
+    return VLP3D_EINVAL;
+  const long long total = (long long)B * n * ((C1 + C2) / 4);
+  hipLaunchKernelGGL(fp_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, known,
+                     unknown, idx, weight, B, n, m, C1, C2, X);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// d_known (B,m,C1) = adjoint of the interpolation part of vlp3d_fp_rows applied to dX[:, :C1] (row stride ld), fully
+// written.  m * 16 floats of LDS per workgroup: m <= 1024.  C1 % 16 == 0.
+extern "C" int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *weight, int B, int n, int m, int C1, int ld,
+                                  float *d_known, void *stream) {
+  if (!dX || !idx || !weight || !d_known || B < 1 || n < 1 || m < 1 || m > 1024 || C1 < 16 || (C1 & 15) || ld < C1)
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(fp_rows_grad_kernel<16>, dim3(C1 / 16, B), dim3(256), (size_t)m * 16 * sizeof(float),
+                     (hipStream_t)stream, dX, idx, weight, n, m, C1, ld, d_known);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

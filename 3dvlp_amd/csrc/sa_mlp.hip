@@ -1088,6 +1088,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
+// Same sum, but the (N x K) matrix part goes to dW with row stride ldo (a K-slice of a wider weight gradient) and the
+// optional trailing N bias sums go to dbias.  One thread per output element, 16 slab groups like wgrad_reduce.
+__global__ __launch_bounds__(256) void wgrad_reduce_strided_kernel(const float *__restrict__ partials, int nblk, int N, int K,
+                                                                   int with_bias, float *__restrict__ dW, int ldo,
+                                                                   float *__restrict__ dbias) {
+  __shared__ float red[16][16];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int n = N * K + (with_bias ? N : 0);
+  const int i = blockIdx.x * 16 + q;
+  float s = 0.f;
+  if (i < n) {
+#pragma unroll 4
+    for (int b = grp; b < nblk; b += 16) s += partials[(long long)b * n + i];
+  }
+  red[grp][q] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = red[0][q];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += red[g][q];
+    if (i < N * K) dW[(long long)(i / K) * ldo + (i % K)] = t;
+    else dbias[i - N * K] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-channel bookkeeping of the fused layer (each replaces ~20 tiny framework kernels per BatchNorm):
 // ------------------------------------------------------------------------------------------------
@@ -1658,6 +1683,51 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   if (st != VLP3D_OK) return st;
   const int n = N * K + (with_bias ? N : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// Weight gradient of a layer of a rows stack (csrc/rows_mlp.hip): dW[:, 0:K] (N x K, row stride ldo) = dY^T A over R rows,
+//   dY = G (R x N, row stride ldg)                      when bn5 == NULL   (a plain linear layer; dbias = column sums of G)
+//      = BatchNorm-backward of (G, Ypre) with bn5 [5][N] otherwise       (dbias must be NULL)
+//   A  = X (R x K, row stride lda)                      when a_scale == NULL
+//      = relu(X * a_scale + a_shift)                    otherwise (the previous layer's folded BatchNorm, length K)
+// N % 64 == 0, K % 32 == 0, K <= 288, 256 % (K/4) == 0; wider K: call per K-slice (offset X / a_scale / a_shift / dW).
+// partials: max_blocks * (N*K + N) floats of scratch.
+extern "C" int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
+                                const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo,
+                                float *dbias, float *partials, int max_blocks, void *stream) {
+  if (!G || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 32 || (K & 31) ||
+      K > 288 || (256 % (K / 4)) || ((K / 4) & (K / 4 - 1)) || N < 64 || (N & 63) || ldg < N || lda < K || ldo < K ||
+      (bn5 && (!Ypre || dbias)) || (a_scale && !a_shift))
+    return VLP3D_EINVAL;
+  WgradArgs w = {};
+  w.colsum = dbias != nullptr;
+  w.src.K = K; w.src.R = R; w.src.Yin = X; w.src.ldin = lda; w.src.scale = a_scale; w.src.shift = a_shift;
+  w.dy.ldin = ldg;
+  if (bn5) {
+    w.dy.Gin = G; w.dy.Yin = Ypre;
+    w.dy.rstd = bn5; w.dy.nmean_rstd = bn5 + N; w.dy.k1 = bn5 + 2 * N; w.dy.k2 = bn5 + 3 * N; w.dy.k3 = bn5 + 4 * N;
+  } else {
+    w.dy.Yin = G;
+  }
+  w.KP = K;
+  w.partials = partials;
+  const long long ntiles = R / 32;
+  long long tpb = (ntiles + max_blocks - 1) / max_blocks;
+  if (tpb < 1) tpb = 1;
+  w.tiles_per_block = tpb;
+  const int nblk = (int)((ntiles + tpb - 1) / tpb);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)nblk, N / 64);
+  const size_t lds = (size_t)32 * (64 + K) * sizeof(float);
+  int st;
+  if (bn5) st = a_scale ? launch_wgrad_c<float, BNRELU, 64, BNBWD>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, BNBWD>(w, s, grid, lds);
+  else st = a_scale ? launch_wgrad_c<float, BNRELU, 64, PLAIN>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds);
+  if (st != VLP3D_OK) return st;
+  const int n = N * K + (dbias ? N : 0);
+  hipLaunchKernelGGL(wgrad_reduce_strided_kernel, dim3((n + 15) / 16), dim3(256), 0, s, partials, nblk, N, K, dbias ? 1 : 0, dW,
+                     ldo, dbias);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

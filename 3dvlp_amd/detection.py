@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from . import row_mlp
 from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
@@ -100,10 +101,21 @@ class VotingModule(nn.Module):
         self.conv3 = nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
         self.bn1 = nn.BatchNorm1d(self.in_dim)
         self.bn2 = nn.BatchNorm1d(self.in_dim)
+        self.fused = True  # csrc/rows_mlp.hip on CUDA tensors; False = the reference's Conv1d / BatchNorm1d / ReLU sequence
 
     def forward(self, seed_xyz, seed_features):
         B, num_seed = seed_xyz.shape[:2]
         num_vote = num_seed * self.vote_factor
+        if self.fused and seed_features.is_cuda:
+            seed_pm = seed_features.float().transpose(1, 2).contiguous()  # (B,S,C): free when the producer was point-major
+            X = seed_pm.view(B * num_seed, self.in_dim)
+            layers = [(self.conv1.weight, self.conv1.bias, self.bn1), (self.conv2.weight, self.conv2.bias, self.bn2),
+                      (self.conv3.weight, self.conv3.bias, None)]
+            if row_mlp.supported(X, layers):
+                net = row_mlp.row_stack(X, layers).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
+                vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, num_vote, 3)
+                vote_features = (seed_pm.unsqueeze(2) + net[..., 3:]).reshape(B, num_vote, self.out_dim)
+                return vote_xyz, vote_features.transpose(2, 1)  # (B,C,num_vote) view of point-major data
         net = F.relu(self.bn1(self.conv1(seed_features)))
         net = F.relu(self.bn2(self.conv2(net)))
         net = self.conv3(net).transpose(2, 1).reshape(B, num_seed, self.vote_factor, 3 + self.out_dim)
@@ -121,6 +133,7 @@ class StandardROIHeads(nn.Module):
         self.num_heading_bin = num_heading_bin
         self.num_class = num_class
         self.use_kl_loss = use_kl_loss
+        self.fused = True  # csrc/rows_mlp.hip on CUDA tensors; False = the reference's Conv1d / BatchNorm1d / ReLU sequence
         convs = [nn.Conv1d(128, 128, kernel_size=1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
                  nn.Conv1d(128, 128, kernel_size=1), nn.BatchNorm1d(128), nn.ReLU(inplace=True)]
         self.convs = nn.Sequential(*convs)
@@ -142,17 +155,29 @@ class StandardROIHeads(nn.Module):
             nn.init.constant_(predictor.bias, 0)
 
     def forward(self, ROI_features, data_dict):
+        heads = [self.heading_reg_predictor, self.heading_cls_predictor, self.box_predictor, self.objectness_predictor]
+        if self.num_class:
+            heads.append(self.sem_cls_predictor)
+        if self.fused and ROI_features.is_cuda and not self.use_kl_loss:
+            B, C, K = ROI_features.shape
+            X = ROI_features.float().transpose(1, 2).contiguous().view(B * K, C)  # free for a point-major producer
+            layers = [(self.convs[0].weight, self.convs[0].bias, self.convs[1]),
+                      (self.convs[3].weight, self.convs[3].bias, self.convs[4]),
+                      (torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0), None)]
+            if row_mlp.supported(X, layers):
+                out = row_mlp.row_stack(X, layers).view(B, K, -1)
+                return self._split(out, heads, data_dict)
         x = self.convs(ROI_features)
         if self.use_kl_loss:
             data_dict["alpha"] = self.alpha_activation(self.alpha_predictor(x).permute(0, 2, 1)) * 0.1 - 0.05
         # The five 1x1 predictors read the same features: ONE convolution with the concatenated weights (the
         # parameters stay separate tensors with the reference's names), then column slices — 5x fewer GEMM /
         # bias / convolution-backward launches for outputs of 1..18 channels each.
-        heads = [self.heading_reg_predictor, self.heading_cls_predictor, self.box_predictor, self.objectness_predictor]
-        if self.num_class:
-            heads.append(self.sem_cls_predictor)
         out = F.conv1d(x, torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0))
         out = out.permute(0, 2, 1)
+        return self._split(out, heads, data_dict)
+
+    def _split(self, out, heads, data_dict):
         parts = torch.split(out, [h.weight.shape[0] for h in heads], dim=-1)
         heading_reg = parts[0]
         if self.num_class:

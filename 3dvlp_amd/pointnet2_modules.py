@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import pointnet2_utils
+from . import row_mlp
 from . import sa_fused
 from . import pytorch_utils as pt_utils
 
@@ -150,6 +151,7 @@ class PointnetFPModule(nn.Module):
     def __init__(self, *, mlp: List[int], bn: bool = True):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+        self.fused = bool(bn)  # False: the reference's literal op sequence (three_interpolate, cat, conv / BN / ReLU)
 
     @staticmethod
     @torch.no_grad()
@@ -160,6 +162,23 @@ class PointnetFPModule(nn.Module):
         return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
 
     def forward(self, unknown, known, unknow_feats, known_feats, geometry=None):
+        if self.fused and known is not None and unknow_feats is not None and known_feats.is_cuda:
+            # point-major rows end to end (csrc/rows_mlp.hip): interpolate + concat in one launch, the SharedMLP as MFMA
+            # products with BatchNorm / ReLU folded in; (B,C,n) in and out are VIEWS of point-major data (no transposes)
+            known_pm = known_feats.float().transpose(1, 2).contiguous()      # free when the producer was point-major
+            unknown_pm = unknow_feats.float().transpose(1, 2).contiguous()
+            layers = [(layer.conv.weight, None, layer.bn.bn) for layer in self.mlp]
+            B, n = unknown_pm.shape[:2]
+            if row_mlp.fp_rows_supported(known_pm, unknown_pm) and (B * n) % 32 == 0 and all(
+                    hasattr(layer, "bn") and layer.conv.bias is None for layer in self.mlp):
+                if geometry is not None:
+                    idx, weight = geometry
+                else:
+                    idx, weight = self.compute_geometry(unknown, known)
+                X = row_mlp.fp_rows(known_pm, unknown_pm, idx, weight)
+                if row_mlp.supported(X, layers):
+                    out = row_mlp.row_stack(X, layers)
+                    return out.view(B, n, -1).transpose(1, 2)
         known_feats = known_feats.float().contiguous()
         if known is not None:
             if geometry is not None:

@@ -1,0 +1,223 @@
+"""1x1 Conv(+bias) -> BatchNorm -> ReLU stacks on point-major rows (csrc/rows_mlp.hip), exact fp32.
+
+`row_stack(X, layers)` runs X (R, K0) through `layers` = [(weight, bias, bn), ...]:
+  * every layer but possibly the last has a BatchNorm (`bn` = the nn.BatchNorm1d/2d module, train or eval mode) followed by
+    ReLU; its conv bias (if any) cancels inside a train-mode BatchNorm and only moves running_mean;
+  * the last layer may be a plain biased linear layer (`bn` None): its output is returned raw.
+This is the arithmetic of SharedMLP / Conv1d+BatchNorm1d+ReLU chains in PointnetFPModule (pointnet2_modules.py:403-416),
+VotingModule (voting_module.py:33-60) and StandardROIHeads (roi_heads.py:15-147), on (rows, channels) matrices instead of
+(B, C, n[, 1]) tensors: no NCHW convolution, layout transposes, library BatchNorm or separate ReLU launches, and the
+autograd backward is the same handful of kernels run in reverse (BatchNorm / ReLU backward folded into the products).
+`fp_rows` is three_interpolate + concat of the FP module on point-major features.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as _ext
+
+_ext.load()
+_ZEROS = {}
+WGRAD_K = 256  # K-slice of one weight-gradient launch (the staging of csrc/sa_mlp.hip: wgrad_kernel covers K <= 288)
+
+
+def _zeros(n, device):
+    key = (n, str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZEROS[key]
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def supported(x, layers):
+    """fp32 CUDA rows, R % 32 == 0, every BatchNorm layer 64-aligned, input widths the weight-gradient kernel slices."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] % 32 == 0 and x.shape[0] >= 32):
+        return False
+    k = x.shape[1]
+    for i, (w, b, bn) in enumerate(layers):
+        n = w.shape[0]
+        if w.shape[1] != k or not (k in (32, 64, 128, 256) or (k > WGRAD_K and k % WGRAD_K == 0)):
+            return False
+        if bn is None:
+            if i != len(layers) - 1:
+                return False
+        elif n % 64 or not bn.affine:
+            return False
+        k = n
+    return not torch.is_autocast_enabled("cuda")
+
+
+class _RowStack(Function):
+    @staticmethod
+    def forward(ctx, x, bns, *params):
+        L = len(bns)
+        W, bias, gam, bet = params[0::4], params[1::4], params[2::4], params[3::4]
+        R, dev = x.shape[0], x.device
+        x = x.contiguous()
+        lib = _ext.load()
+        nslab = int(lib.vlp3d_rows_slabs(R))
+        Ys, vecs, Wp = [], [], []
+        A, lda, a_vec = x, x.shape[1], None
+        training = [bn is not None and (bn.training or not bn.track_running_stats) for bn in bns]
+        for l in range(L):
+            N, K = W[l].shape
+            Np = _round_up(N, 64)
+            w = W[l].contiguous()
+            b = bias[l]
+            if Np != N:  # only a final plain layer (259 = 3 + 256 vote channels, 28 ROI predictor channels)
+                w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
+                b = None if b is None else torch.nn.functional.pad(b, (0, Np - N))
+            Wp.append(w)
+            y = torch.empty((R, Np), dtype=torch.float32, device=dev)
+            bn = bns[l]
+            if bn is None:
+                _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None)
+                vec = None
+            else:
+                vec = torch.empty((4, Np), dtype=torch.float32, device=dev)
+                if training[l]:
+                    st = torch.empty((nslab, 2, Np), dtype=torch.float64, device=dev)
+                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, None, Np, y, Np, st)
+                    track = bn.track_running_stats and bn.training
+                    if track:
+                        if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once
+                            bn.num_batches_tracked.add_(1)
+                        mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+                    else:
+                        mom = 0.0
+                    _ext.call("vlp3d_sa_bn_fold", st, nslab, gam[l], bet[l], bn.running_mean if track else None,
+                              bn.running_var if track else None, Np, R, float(bn.eps), float(mom), 1, vec)
+                    if track and b is not None:  # the bias shifts the batch mean (and nothing else)
+                        bn.running_mean.add_(b.detach(), alpha=mom)
+                else:  # eval: y includes the bias, the running statistics normalise it
+                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None)
+                    _ext.call("vlp3d_sa_bn_fold", None, 1, gam[l], bet[l], bn.running_mean, bn.running_var, Np, R,
+                              float(bn.eps), 0.0, 0, vec)
+            Ys.append(y)
+            vecs.append(vec)
+            A, lda, a_vec = y, Np, vec
+        if bns[-1] is not None:
+            out = torch.empty_like(Ys[-1])
+            _ext.call("vlp3d_rows_act", Ys[-1], R, Ys[-1].shape[1], vecs[-1], out)
+        else:
+            out = Ys[-1][:, :W[-1].shape[0]]
+        ctx.save_for_backward(x, *Ys, *[v for v in vecs if v is not None], *Wp, *[g for g in gam if g is not None])
+        ctx.meta = (L, [v is not None for v in vecs], training, [b is not None for b in bias],
+                    [tuple(w.shape) for w in W])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, has_bn, training, has_bias, wshapes = ctx.meta
+        sv = list(ctx.saved_tensors)
+        x, Ys = sv[0], sv[1:1 + L]
+        nbn = sum(has_bn)
+        vlist, Wp, glist = sv[1 + L:1 + L + nbn], sv[1 + L + nbn:1 + 2 * L + nbn], sv[1 + 2 * L + nbn:]
+        vecs, gam, it_v, it_g = [], [], iter(vlist), iter(glist)
+        for l in range(L):
+            vecs.append(next(it_v) if has_bn[l] else None)
+            gam.append(next(it_g) if has_bn[l] else None)
+        R, dev = x.shape[0], x.device
+        lib = _ext.load()
+        nslab = int(lib.vlp3d_rows_slabs(R))
+        grads = [None] * (4 * L)
+        last = L - 1
+        Np = Ys[last].shape[1]
+        if has_bn[last]:
+            G = torch.empty((R, Np), dtype=torch.float32, device=dev)
+            tn = int(lib.vlp3d_rows_act_slabs(R))
+            t = torch.empty((tn, 2, Np), dtype=torch.float64, device=dev)
+            _ext.call("vlp3d_rows_act_bwd", dout.contiguous(), Ys[last], R, Np, vecs[last], G, t)
+        else:
+            N = wshapes[last][0]
+            G = dout if Np == N else torch.nn.functional.pad(dout, (0, Np - N))
+            G = G.contiguous()
+            t, tn = None, 0
+        dx = None
+        for l in range(L - 1, -1, -1):
+            N, K = wshapes[l]
+            Np = Ys[l].shape[1]
+            bn5 = None
+            if has_bn[l]:
+                bn5 = torch.empty((5, Np), dtype=torch.float32, device=dev)
+                dg = torch.empty((Np,), dtype=torch.float32, device=dev)
+                db = torch.empty((Np,), dtype=torch.float32, device=dev)
+                _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t, tn, Np, R, int(training[l]), bn5, dg, db)
+                grads[4 * l + 2], grads[4 * l + 3] = dg, db
+                if has_bias[l]:  # cancels inside a train-mode BatchNorm; in eval mode it is d(beta) scaled by gamma*rstd
+                    grads[4 * l + 1] = _zeros(N, dev) if training[l] else vecs[l][0] * db
+            A = x if l == 0 else Ys[l - 1]
+            lda = A.shape[1]
+            pv = None if l == 0 else vecs[l - 1]
+            dW = torch.empty((Np, K), dtype=torch.float32, device=dev)
+            want_db = (not has_bn[l]) and has_bias[l]
+            dbias = torch.empty((Np,), dtype=torch.float32, device=dev) if want_db else None
+            ks = min(K, WGRAD_K)
+            nblk = max(8, min(128, R // 64))
+            part = torch.empty((nblk, Np * ks + Np), dtype=torch.float32, device=dev)
+            for off in range(0, K, ks):
+                _ext.call("vlp3d_rows_wgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, A[:, off:], lda,
+                          None if pv is None else pv[0, off:], None if pv is None else pv[1, off:], R, ks, Np,
+                          dW[:, off:], K, dbias if off == 0 else None, part, nblk)
+            grads[4 * l] = dW[:N]
+            if want_db:
+                grads[4 * l + 1] = dbias[:N]
+            if l > 0:
+                Gp = torch.empty((R, K), dtype=torch.float32, device=dev)
+                tp = torch.empty((nslab, 2, K), dtype=torch.float64, device=dev)
+                _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, Ys[l - 1], K,
+                          vecs[l - 1], Gp, K, tp)
+                G, t, tn = Gp, tp, nslab
+            elif ctx.needs_input_grad[0]:
+                dx = torch.empty((R, K), dtype=torch.float32, device=dev)
+                _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, None, 0, None,
+                          dx, K, None)
+        return (dx, None, *grads)
+
+
+def row_stack(x, layers):
+    """x (R, K0) fp32 CUDA; layers = [(weight (N,K[,1[,1]]), bias or None, bn module or None), ...] -> (R, N_last)."""
+    bns = [bn for _, _, bn in layers]
+    params = []
+    for w, b, bn in layers:
+        params += [w.reshape(w.shape[0], w.shape[1]), b, None if bn is None else bn.weight, None if bn is None else bn.bias]
+    return _RowStack.apply(x, bns, *params)
+
+
+class _FPRows(Function):
+    """[three_interpolate(known, idx, weight) | unknown] on point-major features: (B,m,C1), (B,n,C2) -> (B*n, C1+C2)."""
+
+    @staticmethod
+    def forward(ctx, known, unknown, idx, weight):
+        known, unknown = known.contiguous().float(), unknown.contiguous().float()
+        B, m, C1 = known.shape
+        n, C2 = unknown.shape[1:]
+        X = torch.empty((B * n, C1 + C2), dtype=torch.float32, device=known.device)
+        _ext.call("vlp3d_fp_rows", known, unknown, idx.contiguous(), weight.contiguous(), B, n, m, C1, C2, X)
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, n, m, C1, C2)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        idx, weight = ctx.saved_tensors
+        B, n, m, C1, C2 = ctx.dims
+        dX = dX.contiguous()
+        dk = du = None
+        if ctx.needs_input_grad[0]:
+            dk = torch.empty((B, m, C1), dtype=torch.float32, device=dX.device)
+            _ext.call("vlp3d_fp_rows_grad", dX, idx.contiguous(), weight.contiguous(), B, n, m, C1, C1 + C2, dk)
+        if ctx.needs_input_grad[1]:
+            du = dX.view(B, n, C1 + C2)[:, :, C1:]
+        return dk, du, None, None
+
+
+def fp_rows_supported(known_pm, unknown_pm):
+    return (known_pm.is_cuda and known_pm.shape[2] % 16 == 0 and unknown_pm.shape[2] % 4 == 0
+            and known_pm.shape[1] <= 1024)
+
+
+def fp_rows(known_pm, unknown_pm, idx, weight):
+    return _FPRows.apply(known_pm, unknown_pm, idx, weight)

@@ -318,6 +318,39 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
                    int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, int bf16_mma,
                    int ldq, int ldk, int ldv, void *stream);
 
+/* ---- exact-fp32 dense stacks on point-major rows (csrc/rows_mlp.hip) -------------------------------------------
+ * The 1x1 Conv(+bias) -> BatchNorm -> ReLU chains of PointnetFPModule (pointnet2_modules.py:403-416), VotingModule
+ * (voting_module.py:33-60) and StandardROIHeads (roi_heads.py:15-147) as products on ROW-MAJOR matrices with the
+ * BatchNorm / ReLU stages folded into the neighbouring products (same scheme as vlp3d_sa_*; per-channel vectors come
+ * from vlp3d_sa_bn_fold / vlp3d_sa_bn_bwd_consts).  R % 32 == 0, R <= 2^24.
+ * rows_fwd:   Y (R x N, stride ldy) = A W^T [+ bias]; A = X or relu(X*scale + shift) with a_vec = [scale | shift | ..]
+ *             (length K each); stats != NULL (then bias must be NULL): per-column sums of Y into
+ *             [vlp3d_rows_slabs(R)][2][N] fp64 slabs.  W (N x K) row-major, K % 32 == 0, N % 32 == 0.
+ * rows_dgrad: dA (R x K) = dY W with dY = G or BatchNorm-backward(G, Ypre; bn5 [5][N]); p_vec != NULL masks with the
+ *             ReLU of the previous layer (Yprev, p_vec = its vec [4][K]) and writes the two BatchNorm-backward column
+ *             sums to tstats slabs [vlp3d_rows_slabs(R)][2][K].  K % 32 == 0, N % 32 == 0.
+ * rows_wgrad: dW[:, 0:K] (stride ldo) = dY^T A (+ dbias = column sums of G when bn5 == NULL); see csrc/sa_mlp.hip.
+ * rows_act / rows_act_bwd: the activation of the last BatchNorm layer and its backward (+ column sums, nslab =
+ *             vlp3d_rows_act_slabs(R)).
+ * fp_rows / fp_rows_grad: X = [three_interpolate(known) | unknown] on point-major features (pointnet2_modules.py:393-411,
+ *             blend order of interpolate_gpu.cu:103-104) and the adjoint w.r.t. known (m <= 1024). */
+int vlp3d_rows_slabs(long long R);
+int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W, const float *bias, int N,
+                   float *Y, int ldy, double *stats, void *stream);
+int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R, int N, int K,
+                     const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda, double *tstats, void *stream);
+int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
+                     const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo, float *dbias,
+                     float *partials, int max_blocks, void *stream);
+int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream);
+int vlp3d_rows_act_slabs(long long R);
+int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G, double *tstats,
+                       void *stream);
+int vlp3d_fp_rows(const float *known, const float *unknown, const int *idx, const float *weight, int B, int n, int m, int C1,
+                  int C2, float *X, void *stream);
+int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *weight, int B, int n, int m, int C1, int ld,
+                       float *d_known, void *stream);
+
 /* ---- hardware-denominator probes (csrc/hwprobe.hip; measurement only) --------------------
  * vlp3d_probe_read: streaming 16-byte-load read of `bytes` (multiple of 16, >= 16 KiB) with `blocks` workgroups;
  * vlp3d_probe_mfma_bf16: blocks*4 waves each issue iters*4 independent v_mfma_f32_32x32x16_bf16

@@ -501,3 +501,174 @@ def test_add_norm_fused_equals_torch_with_same_mask(R, D, p):
     ev = an.add_norm(x, y, norm, p, False)
     torch.testing.assert_close(ev, torch.nn.functional.layer_norm(x + y, (D,), norm.weight, norm.bias, norm.eps),
                                rtol=1e-5, atol=1e-5)
+
+
+def _grads_close(a, b, tol=2e-4):
+    """Norm-wise at `tol`, element-wise at 100 x tol: an activation within fp32 round-off of zero may take the other
+    side of a ReLU than in the fp64 formula, which moves a few gradient elements by one term of their sum."""
+    a, b = a.double(), b.double()
+    scale = b.abs().max().item()
+    assert (a - b).norm().item() <= tol * b.norm().item() + 1e-9, ((a - b).norm().item(), b.norm().item())
+    assert (a - b).abs().max().item() <= 100 * tol * scale + 1e-6, ((a - b).abs().max().item(), scale)
+
+
+def _bn_rows64(x, bn, training):
+    """BatchNorm over the rows of a (R, C) fp64 matrix with the module's parameters (batch statistics when training)."""
+    if training:
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+    else:
+        mean, var = bn.running_mean.double(), bn.running_var.double()
+    return (x - mean) / torch.sqrt(var + bn.eps) * bn.weight.double() + bn.bias.double()
+
+
+def _randomise_bn(mod):
+    with torch.no_grad():
+        for m_ in mod.modules():
+            if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm):
+                m_.weight.uniform_(0.5, 1.5); m_.bias.uniform_(-0.3, 0.3)
+                m_.running_mean.uniform_(-0.2, 0.2); m_.running_var.uniform_(0.5, 1.5)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_fp_module_rows_equals_fp64_formula(training):
+    """PointnetFPModule on point-major rows (csrc/rows_mlp.hip: interpolate + concat, MFMA products with BatchNorm / ReLU
+    folded in) == pointnet2_modules.py:393-416 evaluated in fp64 with torch ops (inverse-distance blend of the three
+    neighbours, concat, 1x1 conv, BatchNorm over B*n, ReLU): output, input gradients, parameter gradients, running
+    statistics — FP2 shape of cfg2.  (The library BatchNorm backward of the literal NCHW sequence is NOT used as the
+    reference: with non-default running statistics it returned gradients 10 % off the fp64 formula on this stack.)"""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    torch.manual_seed(4)
+    B, n, m = 4, 1024, 512
+    unknown = torch.rand(B, n, 3, device="cuda") * 4
+    known = unknown[:, torch.randperm(n)[:m]].contiguous() + 0.01
+    fp = pm.PointnetFPModule(mlp=[512, 256, 256]).cuda().train(training)
+    _randomise_bn(fp)
+    rm0 = [b.clone() for b in fp.buffers()]
+    uf0, kf0 = torch.randn(B, n, 256, device="cuda"), torch.randn(B, m, 256, device="cuda")
+    g = torch.randn(B, 256, n, device="cuda")
+    uf, kf = uf0.clone().requires_grad_(True), kf0.clone().requires_grad_(True)
+    out = fp(unknown, known, uf.transpose(1, 2), kf.transpose(1, 2))   # (B,C,n) views of point-major data
+    assert not out.is_contiguous()                                      # the rows path ran: (B,C,n) is a view of (B,n,C)
+    (out * g).sum().backward()
+    got = [out.detach(), uf.grad, kf.grad] + [p.grad.clone() for p in fp.parameters()]
+    # fp64 reference
+    idx, w = pm.PointnetFPModule.compute_geometry(unknown, known)
+    ufd, kfd = uf0.double().requires_grad_(True), kf0.double().requires_grad_(True)
+    base = (torch.arange(B, device="cuda") * m)[:, None, None]
+    nb = kfd.reshape(B * m, 256)[(idx.long() + base).reshape(-1, 3)]
+    x = torch.cat([(nb * w.double().reshape(-1, 3, 1)).sum(1), ufd.reshape(B * n, 256)], 1)
+    params64 = []
+    for layer in fp.mlp:
+        W = layer.conv.weight.detach().double()[:, :, 0, 0].requires_grad_(True)
+        bn = layer.bn.bn
+        gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        y = x @ W.t()
+        mean, var = (y.mean(0), y.var(0, unbiased=False)) if training else (bn.running_mean.double(), bn.running_var.double())
+        x = torch.relu((y - mean) / torch.sqrt(var + bn.eps) * gam + bet)
+        params64 += [(W, y.detach()), gam, bet]
+    ref = x.view(B, n, 256).transpose(1, 2)
+    (ref * g.double()).sum().backward()
+    torch.testing.assert_close(got[0].double(), ref.detach(), rtol=1e-4, atol=2e-5)
+    _grads_close(got[1], ufd.grad); _grads_close(got[2], kfd.grad)
+    exp = []
+    for W, gam, bet in zip(params64[0::3], params64[1::3], params64[2::3]):
+        exp += [W[0].grad[:, :, None, None], gam.grad, bet.grad]
+    for a, b in zip(got[3:], exp):
+        _grads_close(a, b)
+    if training:  # running statistics: momentum update with the batch mean / unbiased variance
+        R = B * n
+        for layer, (W, y) in zip(fp.mlp, params64[0::3]):
+            bn = layer.bn.bn
+        bufs = dict(fp.named_buffers())
+        i = 0
+        for li, layer in enumerate(fp.mlp):
+            y = params64[3 * li][1]
+            mom = layer.bn.bn.momentum
+            torch.testing.assert_close(bufs[f"mlp.layer{li}.bn.bn.running_mean"].double(),
+                                       (1 - mom) * rm0[3 * li].double() + mom * y.mean(0), rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(bufs[f"mlp.layer{li}.bn.bn.running_var"].double(),
+                                       (1 - mom) * rm0[3 * li + 1].double() + mom * y.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
+            assert int(bufs[f"mlp.layer{li}.bn.bn.num_batches_tracked"]) == int(rm0[3 * li + 2]) + 1
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("kind", ["voting", "roi"])
+def test_voting_and_roi_heads_rows_equal_fp64_formula(kind, training):
+    """VotingModule (voting_module.py:33-60) / StandardROIHeads (roi_heads.py:127-147) on csrc/rows_mlp.hip vs the same
+    Conv1d(+bias) -> BatchNorm1d -> ReLU chain evaluated in fp64: outputs, input gradient, every parameter gradient (a
+    bias in front of a train-mode BatchNorm: exactly zero), running statistics including the bias shift."""
+    det = importlib.import_module("3dvlp_amd.detection")
+    torch.manual_seed(6)
+    B, S = (4, 1024) if kind == "voting" else (8, 256)
+    C = 256 if kind == "voting" else 128
+    mod = (det.VotingModule(1, 256) if kind == "voting" else det.StandardROIHeads(1, 18)).cuda().train(training)
+    _randomise_bn(mod)
+    with torch.no_grad():
+        for n_, p in mod.named_parameters():
+            if n_.endswith("bias") and p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    buf0 = {n_: b.clone() for n_, b in mod.named_buffers()}
+    f = torch.randn(B, S, C, device="cuda").requires_grad_(True)
+    xyz = torch.rand(B, S, 3, device="cuda")
+    if kind == "voting":
+        convs, bns = [mod.conv1, mod.conv2, mod.conv3], [mod.bn1, mod.bn2, None]
+        vx, vf = mod(xyz, f.transpose(1, 2))
+        outs = [vx, vf.transpose(1, 2)]
+    else:
+        heads = [mod.heading_reg_predictor, mod.heading_cls_predictor, mod.box_predictor, mod.objectness_predictor,
+                 mod.sem_cls_predictor]
+        convs, bns = [mod.convs[0], mod.convs[3], None], [mod.convs[1], mod.convs[4], None]
+        d = mod(f.transpose(1, 2), {})
+        outs = [d["heading_residuals_normalized"], d["heading_scores"], d["rois"], d["objectness_scores"], d["sem_cls_scores"]]
+    gs_ = [torch.randn_like(o) for o in outs]
+    sum((o * g).sum() for o, g in zip(outs, gs_)).backward()
+    got = {n_: p.grad.clone() for n_, p in mod.named_parameters() if p.grad is not None}
+    # fp64 formula
+    fd = f.detach().double().requires_grad_(True)
+    P = {n_: p.detach().double().requires_grad_(True) for n_, p in mod.named_parameters()}
+    names = dict((id(m_), n_) for n_, m_ in mod.named_modules())
+    x = fd.reshape(B * S, C)
+    pre = []
+    for conv, bn in zip(convs, bns):
+        if conv is None:   # merged ROI predictors
+            W = torch.cat([P[names[id(h)] + ".weight"][:, :, 0] for h in heads], 0)
+            bb = torch.cat([P[names[id(h)] + ".bias"] for h in heads], 0)
+        else:
+            W, bb = P[names[id(conv)] + ".weight"][:, :, 0], P[names[id(conv)] + ".bias"]
+        y = x @ W.t() + bb
+        pre.append(y.detach())
+        if bn is None:
+            x = y
+            break
+        mean, var = (y.mean(0), y.var(0, unbiased=False)) if training else (bn.running_mean.double(), bn.running_var.double())
+        x = torch.relu((y - mean) / torch.sqrt(var + bn.eps) * P[names[id(bn)] + ".weight"] + P[names[id(bn)] + ".bias"])
+    if kind == "voting":
+        net = x.view(B, S, 1, 3 + C)
+        ref = [(xyz.double().unsqueeze(2) + net[..., 0:3]).reshape(B, S, 3), (fd.unsqueeze(2) + net[..., 3:]).reshape(B, S, C)]
+    else:
+        parts = torch.split(x.view(B, S, -1), [h.weight.shape[0] for h in heads], dim=-1)
+        ref = [parts[0], parts[1], parts[2].exp(), parts[3], parts[4]]
+    sum((o * g.double()).sum() for o, g in zip(ref, gs_)).backward()
+    for o, r in zip(outs, ref):
+        torch.testing.assert_close(o.double(), r.detach(), rtol=1e-4, atol=2e-5)
+    _grads_close(f.grad, fd.grad)
+    for n_, p64 in P.items():
+        if p64.grad is None:
+            assert n_ not in got, n_
+            continue
+        pre_bn_bias = training and n_ in ("conv1.bias", "conv2.bias", "convs.0.bias", "convs.3.bias")
+        if pre_bn_bias:  # cancels inside the BatchNorm: exactly zero here, round-off in any op-by-op evaluation
+            assert got[n_].abs().max().item() == 0 and p64.grad.abs().max().item() < 1e-8
+        else:
+            _grads_close(got[n_], p64.grad)
+    if training:
+        now = dict(mod.named_buffers())
+        for (conv, bn), y in zip(zip(convs, bns), pre):
+            if bn is None:
+                continue
+            nm = names[id(bn)]
+            mom = bn.momentum
+            torch.testing.assert_close(now[nm + ".running_mean"].double(), (1 - mom) * buf0[nm + ".running_mean"].double() + mom * y.mean(0),
+                                       rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(now[nm + ".running_var"].double(),
+                                       (1 - mom) * buf0[nm + ".running_var"].double() + mom * y.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
