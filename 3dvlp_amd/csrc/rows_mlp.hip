@@ -45,21 +45,21 @@ struct RowsArgs {
 __device__ __forceinline__ int acc_row(int i, int half) { return (i & 3) + 8 * (i >> 2) + 4 * half; }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-// Raw operands of one 32-wide K chunk for a lane: 4 steps x (A float4 [+ G float4], W float4), all requested before
-// anything is consumed.  The loader's per-column constants (L1-resident vectors) are fetched when the chunk is consumed —
-// behind the previous chunk's queued MFMAs — instead of riding along in the double buffer (160 more registers).
-template <int LOADER>
-struct Chunk {
-  float4 x[4], g[4], w[4];
+// A workgroup (4 waves) owns a 32-row x 128-column output tile.  The 32 x K A tile is loaded ONCE, cooperatively and
+// coalesced (consecutive lanes read consecutive 16-byte chunks of a row; a lane always stages the same four columns, so
+// the loader's per-column constants are fetched once per workgroup), transformed, and kept in LDS (rows padded by 16 B:
+// conflict-free ds_read_b128 fragment reads); wave w then walks K for columns 32w..32w+31 with its W fragments
+// double-buffered in registers, 32 columns of K ahead.  (First version: a wave per 32 x 32 tile with every operand
+// straight from memory — one exposed memory latency per 8 columns of K, 45 us for 8192 x 512 x 256; register-level
+// double buffering of both operands: 42 us; the products themselves are 7 us per wave.)
+struct WChunk {
+  float4 w[4];
 };
 
-template <int LOADER>
-__device__ __forceinline__ void chunk_load(const RowsArgs &a, long long row, int col, int kbase, int half, Chunk<LOADER> &c) {
+__device__ __forceinline__ void w_load(const RowsArgs &a, int col, int kbase, int half, WChunk &c) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k0 = kbase + 8 * s + 4 * half;  // lane half h covers columns 8s + 4h .. +3 of the chunk
-    c.x[s] = ld4(a.X + row * a.ldx + k0);
-    if (LOADER == BNBWD) c.g[s] = ld4(a.G + row * a.ldx + k0);
     if (a.wt) {  // K-major weight: four dword loads, each coalesced over the lanes' 32 output columns
       const float *wp = a.W + (long long)k0 * a.ldw + col;
       c.w[s] = make_float4(wp[0], wp[a.ldw], wp[2 * a.ldw], wp[3 * a.ldw]);
@@ -69,35 +69,10 @@ __device__ __forceinline__ void chunk_load(const RowsArgs &a, long long row, int
   }
 }
 
-template <int LOADER>
-__device__ __forceinline__ void chunk_mma(const RowsArgs &a, int kbase, int half, const Chunk<LOADER> &c, f32x16 &acc) {
-  float4 k_a[4], k_b[4], k_c[4], k_d[4], k_e[4];
+__device__ __forceinline__ void w_mma(const float *sa, int kbase, int half, const WChunk &c, f32x16 &acc) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int k0 = kbase + 8 * s + 4 * half;
-    if (LOADER == BNRELU) {
-      k_a[s] = ld4(a.a_scale + k0);
-      k_b[s] = ld4(a.a_shift + k0);
-    } else if (LOADER == BNBWD) {
-      k_a[s] = ld4(a.bn5 + k0);
-      k_b[s] = ld4(a.bn5 + a.K + k0);
-      k_c[s] = ld4(a.bn5 + 2 * a.K + k0);
-      k_d[s] = ld4(a.bn5 + 3 * a.K + k0);
-      k_e[s] = ld4(a.bn5 + 4 * a.K + k0);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    float4 av = c.x[s];
-    if (LOADER == BNRELU) {
-      const float4 sc = k_a[s], sh = k_b[s];
-      av = make_float4(fmaxf(0.f, av.x * sc.x + sh.x), fmaxf(0.f, av.y * sc.y + sh.y), fmaxf(0.f, av.z * sc.z + sh.z),
-                       fmaxf(0.f, av.w * sc.w + sh.w));
-    } else if (LOADER == BNBWD) {
-      const float4 x = c.x[s], g = c.g[s], rs = k_a[s], nm = k_b[s], k1 = k_c[s], k2 = k_d[s], k3 = k_e[s];
-      av = make_float4(k1.x * (g.x - k2.x - (x.x * rs.x + nm.x) * k3.x), k1.y * (g.y - k2.y - (x.y * rs.y + nm.y) * k3.y),
-                       k1.z * (g.z - k2.z - (x.z * rs.z + nm.z) * k3.z), k1.w * (g.w - k2.w - (x.w * rs.w + nm.w) * k3.w));
-    }
+    const float4 av = *reinterpret_cast<const float4 *>(sa + kbase + 8 * s + 4 * half);
     const float4 bv = c.w[s];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
@@ -107,74 +82,111 @@ __device__ __forceinline__ void chunk_mma(const RowsArgs &a, int kbase, int half
 }
 
 template <int LOADER, int EPI>
-__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {  // <= 256 registers: two waves per SIMD
-  __shared__ double red[4][2][32];
+__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sA[];  // [32][K + 4]
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c0 = blockIdx.y * 32, col = c0 + r;  // this block's 32 output columns
+  const int c0 = blockIdx.y * 128 + 32 * wave, col = c0 + r;  // this wave's 32 output columns
+  const bool active = c0 < a.N;                               // wave-uniform (N % 32 == 0)
+  const int lds_ld = a.K + 4, kq = a.K / 4;                   // kq = 16-byte chunks per A row
   const long long ntiles = a.R / 32;
+  // staging: chunk e = threadIdx.x + 256 j of the tile's 32 * kq 16-byte chunks -> (row e / kq, columns 4 (e % kq) ..).
+  // BatchNorm loaders need 256 % kq == 0 (host-checked): a thread then always stages the same four columns and its
+  // per-column constants are fetched once.
+  const int nch = 32 * kq, scol = (threadIdx.x % kq) * 4;
+  float4 k_a, k_b, k_c, k_d, k_e;
+  if (LOADER == BNRELU) {
+    k_a = ld4(a.a_scale + scol);
+    k_b = ld4(a.a_shift + scol);
+  } else if (LOADER == BNBWD) {
+    k_a = ld4(a.bn5 + scol); k_b = ld4(a.bn5 + a.K + scol); k_c = ld4(a.bn5 + 2 * a.K + scol);
+    k_d = ld4(a.bn5 + 3 * a.K + scol); k_e = ld4(a.bn5 + 4 * a.K + scol);
+  }
   double s1 = 0.0, s2 = 0.0;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
-    const long long row = tile * 32 + r;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long row0 = tile * 32;
+    WChunk wa, wb;
+    if (active) w_load(a, col, 0, half, wa);
+    // ---- stage the A tile: 8 chunks (+ 8 of G) per thread in flight, then transform and write to LDS
+    for (int e0 = threadIdx.x; e0 < nch; e0 += 256 * 8) {
+      float4 x[8], g[8];
+      int srow[8], scl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = min(e0 + 256 * j, nch - 1);  // clamped: unconditional loads, all in flight together
+        srow[j] = e / kq;
+        scl[j] = (e - srow[j] * kq) * 4;
+        x[j] = ld4(a.X + (row0 + srow[j]) * a.ldx + scl[j]);
+        if (LOADER == BNBWD) g[j] = ld4(a.G + (row0 + srow[j]) * a.ldx + scl[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (e0 + 256 * j >= nch) break;
+        float4 v = x[j];
+        if (LOADER == BNRELU) {
+          v = make_float4(fmaxf(0.f, v.x * k_a.x + k_b.x), fmaxf(0.f, v.y * k_a.y + k_b.y), fmaxf(0.f, v.z * k_a.z + k_b.z),
+                          fmaxf(0.f, v.w * k_a.w + k_b.w));
+        } else if (LOADER == BNBWD) {
+          const float4 y = x[j], gg = g[j];
+          v = make_float4(k_c.x * (gg.x - k_d.x - (y.x * k_a.x + k_b.x) * k_e.x), k_c.y * (gg.y - k_d.y - (y.y * k_a.y + k_b.y) * k_e.y),
+                          k_c.z * (gg.z - k_d.z - (y.z * k_a.z + k_b.z) * k_e.z), k_c.w * (gg.w - k_d.w - (y.w * k_a.w + k_b.w) * k_e.w));
+        }
+        *reinterpret_cast<float4 *>(sA + srow[j] * lds_ld + scl[j]) = v;
+      }
+    }
+    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // K in chunks of 32, software-pipelined by hand: chunk c+1's 8..32 loads are in flight while chunk c is on the matrix
-    // cores (a wave walks its tile alone; the one-step loop exposed a full memory latency per 8 columns: 45 us for
-    // 8192 x 512 x 256, the products themselves are ~7 us per wave)
-    Chunk<LOADER> ca, cb;
-    chunk_load<LOADER>(a, row, col, 0, half, ca);
-    for (int kb = 0; kb < a.K; kb += 64) {
-      if (kb + 32 < a.K) chunk_load<LOADER>(a, row, col, kb + 32, half, cb);
-      chunk_mma<LOADER>(a, kb, half, ca, acc);
-      if (kb + 32 >= a.K) break;
-      if (kb + 64 < a.K) chunk_load<LOADER>(a, row, col, kb + 64, half, ca);
-      chunk_mma<LOADER>(a, kb + 32, half, cb, acc);
-    }
-    // acc[i] = element (row tile*32 + acc_row(i, half), column col)
-    if (EPI == STORE) {
-      float ps = 0.f, pq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = acc[i];
-        a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = v;
-        ps += v;
-        pq += v * v;
+    if (active) {
+      const float *sa = sA + r * lds_ld;
+      for (int kb = 0; kb < a.K; kb += 64) {
+        if (kb + 32 < a.K) w_load(a, col, kb + 32, half, wb);
+        w_mma(sa, kb, half, wa, acc);
+        if (kb + 32 >= a.K) break;
+        if (kb + 64 < a.K) w_load(a, col, kb + 64, half, wa);
+        w_mma(sa, kb + 32, half, wb, acc);
       }
-      s1 += (double)ps;
-      s2 += (double)pq;
-    } else if (EPI == BIAS) {
-      const float bv = a.bias ? a.bias[col] : 0.f;
+      // acc[i] = element (row row0 + acc_row(i, half), column col)
+      if (EPI == STORE) {
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = acc[i] + bv;
-    } else {  // MASK
-      const float sc = a.p_vec[col], sh = a.p_vec[a.N + col], rs = a.p_vec[2 * a.N + col], nm = a.p_vec[3 * a.N + col];
-      float ps = 0.f, pq = 0.f;
-      float yv[16];
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[i];
+          a.Y[(row0 + acc_row(i, half)) * a.ldy + col] = v;
+          ps += v;
+          pq += v * v;
+        }
+        s1 += (double)ps;
+        s2 += (double)pq;
+      } else if (EPI == BIAS) {
+        const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) yv[i] = a.Yprev[(tile * 32 + acc_row(i, half)) * a.ldprev + col];
+        for (int i = 0; i < 16; ++i) a.Y[(row0 + acc_row(i, half)) * a.ldy + col] = acc[i] + bv;
+      } else {  // MASK
+        const float sc = a.p_vec[col], sh = a.p_vec[a.N + col], rs = a.p_vec[2 * a.N + col], nm = a.p_vec[3 * a.N + col];
+        float ps = 0.f, pq = 0.f;
+        float yv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float g = (yv[i] * sc + sh > 0.f) ? acc[i] : 0.f;
-        a.Y[(tile * 32 + acc_row(i, half)) * a.ldy + col] = g;
-        ps += g;
-        pq += g * (yv[i] * rs + nm);
+        for (int i = 0; i < 16; ++i) yv[i] = a.Yprev[(row0 + acc_row(i, half)) * a.ldprev + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float g = (yv[i] * sc + sh > 0.f) ? acc[i] : 0.f;
+          a.Y[(row0 + acc_row(i, half)) * a.ldy + col] = g;
+          ps += g;
+          pq += g * (yv[i] * rs + nm);
+        }
+        s1 += (double)ps;
+        s2 += (double)pq;
       }
-      s1 += (double)ps;
-      s2 += (double)pq;
     }
+    __syncthreads();  // every wave is done with the A tile before the next one is staged
   }
-  if (EPI == STORE || EPI == MASK) {  // this workgroup's share of the column reductions -> its slab, columns c0..c0+31
+  if ((EPI == STORE || EPI == MASK) && active) {  // this wave's share of the column reductions -> the workgroup's slab
     const double t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
     if (half == 0) {
-      red[wave][0][r] = t1;
-      red[wave][1][r] = t2;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-      a.stats[((size_t)blockIdx.x * 2 + which) * a.N + c0 + c] =
-          (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+      a.stats[((size_t)blockIdx.x * 2) * a.N + col] = t1;
+      a.stats[((size_t)blockIdx.x * 2 + 1) * a.N + col] = t2;
     }
   }
 }
@@ -278,34 +290,42 @@ __global__ __launch_bounds__(256) void fp_rows_grad_kernel(const float *__restri
   }
 }
 
+unsigned rows_blocks(long long R) {
+  const long long t = R / 32;
+  return (unsigned)(t < 1024 ? t : 1024);
+}
+
 template <int LOADER, int EPI>
 int launch(const RowsArgs &a, hipStream_t s) {
-  const long long blocks = (a.R / 32 + 3) / 4;
-  const dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024), a.N / 32);
-  hipLaunchKernelGGL((rows_gemm_kernel<LOADER, EPI>), grid, dim3(256), 0, s, a);
+  const dim3 grid(rows_blocks(a.R), (a.N + 127) / 128);
+  const size_t lds = (size_t)32 * (a.K + 4) * sizeof(float);
+  auto kern = rows_gemm_kernel<LOADER, EPI>;
+  if (lds > 64 * 1024) {
+    if (lds > 150 * 1024) return VLP3D_EINVAL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
 
 bool bad_gemm(const float *X, const float *W, const float *Y, long long R, int K, int N, int ldx, int ldw, int ldy) {
-  return !X || !W || !Y || R < 32 || (R & 31) || R > (1ll << 24) || K < 32 || (K & 31) || N < 32 || (N & 31) || ldx < K ||
+  return !X || !W || !Y || R < 32 || (R & 31) || R > (1ll << 24) || K < 32 || (K & 31) || K > 1024 || N < 32 || (N & 31) || ldx < K ||
          (ldx & 3) || ldw < 1 || ldy < N;
 }
 
 }  // namespace
 
 // workgroups (= statistic slabs of 2*N doubles each) a rows product over R rows is launched with
-extern "C" int vlp3d_rows_slabs(long long R) {
-  const long long blocks = (R / 32 + 3) / 4;
-  return (int)(blocks < 1024 ? blocks : 1024);
-}
+extern "C" int vlp3d_rows_slabs(long long R) { return R < 32 ? 0 : (int)rows_blocks(R); }
 
 // Y (R x N, row stride ldy) = A W^T [+ bias], A = X (a_vec NULL) or relu(X*scale + shift) (a_vec = [scale | shift | ..],
 // each of length K: the `vec` of vlp3d_sa_bn_fold).  stats != NULL: no bias, per-column sums of Y -> slabs
 // [vlp3d_rows_slabs(R)][2][N] for vlp3d_sa_bn_fold.  W (N x K) row-major.  R % 32 == 0, K % 32 == 0, N % 32 == 0.
 extern "C" int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W,
                               const float *bias, int N, float *Y, int ldy, double *stats, void *stream) {
-  if (bad_gemm(X, W, Y, R, K, N, ldx, K, ldy) || (stats && bias)) return VLP3D_EINVAL;
+  if (bad_gemm(X, W, Y, R, K, N, ldx, K, ldy) || (stats && bias) || (a_vec && (256 % (K / 4)))) return VLP3D_EINVAL;
   RowsArgs a = {};
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = K; a.K = K; a.N = N; a.R = R; a.Y = Y; a.ldy = ldy; a.bias = bias; a.stats = stats;
   if (a_vec) { a.a_scale = a_vec; a.a_shift = a_vec + K; }
@@ -322,7 +342,8 @@ extern "C" int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const
 extern "C" int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R,
                                 int N, int K, const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda,
                                 double *tstats, void *stream) {
-  if (bad_gemm(G, W, dA, R, N, K, ldg, K, lda) || (bn5 && !Ypre) || (p_vec && (!Yprev || !tstats || ldprev < K)))
+  if (bad_gemm(G, W, dA, R, N, K, ldg, K, lda) || (bn5 && (!Ypre || (256 % (N / 4)))) ||
+      (p_vec && (!Yprev || !tstats || ldprev < K)))
     return VLP3D_EINVAL;
   RowsArgs a = {};
   a.ldx = ldg; a.W = W; a.ldw = K; a.wt = 1; a.K = N; a.N = K; a.R = R; a.Y = dA; a.ldy = lda;

@@ -503,13 +503,62 @@ def test_add_norm_fused_equals_torch_with_same_mask(R, D, p):
                                rtol=1e-5, atol=1e-5)
 
 
-def _grads_close(a, b, tol=2e-4):
-    """Norm-wise at `tol`, element-wise at 100 x tol: an activation within fp32 round-off of zero may take the other
-    side of a ReLU than in the fp64 formula, which moves a few gradient elements by one term of their sum."""
+def _grads_close(a, b, tol=5e-3):
+    """Module-level comparison against an fp64 formula, norm-wise.  The tolerance is NOT the kernels' accuracy (that is
+    test_row_stack_exact_vs_fp64: 1e-5): an activation within fp32 round-off of zero takes the other side of a ReLU than
+    in fp64, which changes one row's whole contribution to a weight gradient (measured: 1.7e-3 of the norm for conv1 of the
+    eval-mode voting module, identically for the rows kernels and for the library Conv1d/BatchNorm1d sequence in fp32)."""
     a, b = a.double(), b.double()
-    scale = b.abs().max().item()
     assert (a - b).norm().item() <= tol * b.norm().item() + 1e-9, ((a - b).norm().item(), b.norm().item())
-    assert (a - b).abs().max().item() <= 100 * tol * scale + 1e-6, ((a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("R,dims,last_plain", [(4096, [512, 256, 256], False), (8192, [256, 256, 256, 259], True),
+                                               (2048, [128, 128, 128, 28], True), (4096, [256, 128, 256], False),
+                                               (64, [64, 64], False)])
+def test_row_stack_exact_vs_fp64(R, dims, last_plain, training):
+    """row_mlp.row_stack (csrc/rows_mlp.hip + the weight-gradient kernel of csrc/sa_mlp.hip) against Linear(+bias) ->
+    BatchNorm1d -> ReLU in fp64 on random data: output, input gradient and every parameter gradient to 1e-5 of their
+    scale (seeded inputs: no activation sits within round-off of a ReLU threshold here)."""
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    torch.manual_seed(R + len(dims))
+    L = len(dims) - 1
+    Ws = [torch.randn(dims[i + 1], dims[i], device="cuda") * 0.1 for i in range(L)]
+    bs = [torch.randn(dims[i + 1], device="cuda") * 0.1 for i in range(L)]
+    bns = [None if (last_plain and i == L - 1) else torch.nn.BatchNorm1d(dims[i + 1]).cuda().train(training) for i in range(L)]
+    for bn in bns:
+        if bn is not None:
+            _randomise_bn(bn)
+    x0, go = torch.randn(R, dims[0], device="cuda"), torch.randn(R, dims[-1], device="cuda")
+    x = x0.clone().requires_grad_(True)
+    W = [w.clone().requires_grad_(True) for w in Ws]
+    b = [t.clone().requires_grad_(True) for t in bs]
+    assert rm.supported(x, [(W[i], b[i], bns[i]) for i in range(L)])
+    y = rm.row_stack(x, [(W[i], b[i], bns[i]) for i in range(L)])
+    (y * go).sum().backward()
+    got = [y.detach(), x.grad] + [w.grad for w in W] + [t.grad for t in b] + \
+          [bn.weight.grad for bn in bns if bn is not None] + [bn.bias.grad for bn in bns if bn is not None]
+    xd = x0.double().requires_grad_(True)
+    Wd = [w.double().requires_grad_(True) for w in Ws]
+    bd = [t.double().requires_grad_(True) for t in bs]
+    gd = [bn.weight.detach().double().requires_grad_(True) for bn in bns if bn is not None]
+    ed = [bn.bias.detach().double().requires_grad_(True) for bn in bns if bn is not None]
+    h, j = xd, 0
+    for i in range(L):
+        h = h @ Wd[i].t() + bd[i]
+        if bns[i] is not None:
+            mean, var = (h.mean(0), h.var(0, unbiased=False)) if training else (bns[i].running_mean.double(), bns[i].running_var.double())
+            h = torch.relu((h - mean) / torch.sqrt(var + bns[i].eps) * gd[j] + ed[j])
+            j += 1
+    (h * go.double()).sum().backward()
+    exp = [h.detach(), xd.grad] + [w.grad for w in Wd] + [t.grad for t in bd] + [t.grad for t in gd] + [t.grad for t in ed]
+    for k, (a_, e_) in enumerate(zip(got, exp)):
+        pre_bn_bias = training and 2 + L <= k < 2 + 2 * L and bns[k - 2 - L] is not None
+        if pre_bn_bias:
+            assert a_.abs().max().item() == 0 and e_.abs().max().item() < 1e-8   # cancels inside a train-mode BatchNorm
+            continue
+        scale = e_.abs().max().item()
+        assert (a_.double() - e_).abs().max().item() <= 1e-5 * scale + 1e-7, (k, (a_.double() - e_).abs().max().item(), scale)
 
 
 def _bn_rows64(x, bn, training):
@@ -569,7 +618,7 @@ def test_fp_module_rows_equals_fp64_formula(training):
     ref = x.view(B, n, 256).transpose(1, 2)
     (ref * g.double()).sum().backward()
     torch.testing.assert_close(got[0].double(), ref.detach(), rtol=1e-4, atol=2e-5)
-    _grads_close(got[1], ufd.grad); _grads_close(got[2], kfd.grad)
+    _grads_close(got[1], ufd.grad, 2e-4); _grads_close(got[2], kfd.grad, 2e-4)
     exp = []
     for W, gam, bet in zip(params64[0::3], params64[1::3], params64[2::3]):
         exp += [W[0].grad[:, :, None, None], gam.grad, bet.grad]
