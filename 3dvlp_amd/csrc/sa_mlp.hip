@@ -55,6 +55,9 @@ __device__ __forceinline__ short bf16_bits(float v) {
   return *reinterpret_cast<short *>(&h);
 }
 
+#ifndef VLP3D_GATHER_PREFETCH
+#define VLP3D_GATHER_PREFETCH 1  // hold the NEXT tile's gathered rows in registers across the products (153 -> 114 us at SA1)
+#endif
 enum Loader { GATHER = 0, BNRELU = 1, BNBWD = 2, PLAIN = 3 };
 enum Epilogue { STORE = 0, MASK = 1, SCATTER = 2, BIAS = 3, BIAS_WT = 4 };  // BIAS_WT: BIAS with a K-major weight
 
@@ -385,6 +388,38 @@ __device__ __forceinline__ void unpack8(const uint4 &u, float (&f)[8]) {
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+// slim operand pair of the cross-tile prefetch (no pooled-gradient fields: those kernels keep the batch form)
+template <bool WITH_G>
+struct RawPF {
+  uint4 y;
+};
+template <>
+struct RawPF<true> {
+  uint4 y, g;
+};
+template <int LOADER>
+__device__ __forceinline__ void raw_load_pf(const RowGemmArgs &a, int row, int col0, RawPF<LOADER == BNBWD> &w) {
+  w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
+  if constexpr (LOADER == BNBWD)
+    w.g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0);
+}
+template <int LOADER>
+__device__ __forceinline__ uint4 finish_pf(const RawPF<LOADER == BNBWD> &w, const float (&ca)[8], const float (&cb)[8],
+                                           const float (&cc)[8]) {
+  float y[8], o[8];
+  unpack8(w.y, y);
+  if constexpr (LOADER == BNBWD) {
+    float g[8];
+    unpack8(w.g, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], __builtin_fmaf(cb[i], y[i], cc[i]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(0.f, __builtin_fmaf(y[i], ca[i], cb[i]));
+  }
+  return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
+}
+
 template <int LOADER>
 __device__ __forceinline__ void hoist_consts(const RowGemmArgs &a, int col0, float (&ca)[8], float (&cb)[8], float (&cc)[8]) {
 #pragma unroll
@@ -488,9 +523,59 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   // generic path below spends three integer divisions per chunk (27 per lane and tile at SA1 — more VALU work than
   // the tile's matrix products) and waits for idx before it can ask for a feature row.
   constexpr int MAXCH = 10;  // chunks per lane: 32 * (K/8) / 64, K <= 160
+  constexpr bool GATHER_PREFETCH = VLP3D_GATHER_PREFETCH != 0;
   const bool fastg = LOADER == GATHER && a.tile_scene && nch <= 64 * MAXCH;
   int crow[MAXCH], ccol[MAXCH], pidx[MAXCH];
   const long long tile_step = (long long)gridDim.x * 4;
+  // The gathered rows of tile t+1 are requested BEFORE tile t goes to the matrix cores and stay in registers (gv0 / gv1)
+  // through its products and epilogue; the ball-query indices run one tile further ahead still.  (One tile at a time —
+  // request, wait, LDS, products, epilogue — left a wave idle for two memory latencies per tile at two waves per SIMD:
+  // 20 us per tile.)
+  float4 gv0[MAXCH], gv1[MAXCH];
+  // the [dx, dy, dz, 0] columns are written by a separate pass (lane = row, lanes 0..31): inside the chunk loop the
+  // three divisions by the radius were a ~40-instruction sequence executed for EVERY chunk batch (some lane of the wave
+  // always holds a row's xyz chunk) — a quarter of the kernel's vector instructions
+  int prow = 0;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  const float inv_radius = 1.f / a.radius;
+  auto gather_issue = [&](long long tile) {  // pidx / prow hold the indices of `tile`
+    const int row0 = (int)(tile * 32);
+    const int scene = row0 / (a.M * a.S);  // wave-uniform (R < 2^31)
+    const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
+    const float *xbase = a.xyz + (long long)scene * a.N * 3;
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+      const float *fr = fbase + (long long)pidx[u] * a.C;
+      const int col = ccol[u];
+      gv0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gv1[u] = gv0[u];
+      if (64 * u < nch) {  // uniform
+        if (col < a.C) gv0[u] = ld4(fr + col);
+        if (col + 4 < a.C) gv1[u] = ld4(fr + col + 4);
+      }
+    }
+    const float *q = xbase + (long long)prow * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+  };
+  auto gather_commit = [&](long long tile) {  // registers -> this wave's LDS tile (bf16)
+    const int row0 = (int)(tile * 32);
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+      if (64 * u + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[u] * ldw + ccol[u]) = pack8(gv0[u], gv1[u]);
+    if (lane < 32) {  // same wave, later instruction: lands after the chunk writes above
+      const int rr = row0 + lane;
+      const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+      const float *cc3 = a.new_xyz + (long long)bm * 3;  // a handful of L1-resident centres per tile
+      *reinterpret_cast<uint2 *>(sA + lane * ldw + a.C) =
+          pack4(make_float4((qx - cc3[0]) * inv_radius, (qy - cc3[1]) * inv_radius, (qz - cc3[2]) * inv_radius, 0.f));
+    }
+  };
+  // Processing order: plain grid stride over the tiles in row (= FPS) order.  Tried and rejected: walking a scene's
+  // balls in Morton order of their centres, alone (133 us vs 114 us for SA1 layer 1) or with each XCD working through one
+  // contiguous eighth of that order (125 us) — the gathered rows come from L2 / the Infinity Cache either way, and
+  // neighbouring waves asking for the SAME lines at the same time is slower than a random spread.
+  const long long vt0 = (long long)blockIdx.x * 4 + wave, vstep = tile_step, vend = ntiles;
+  auto map_tile = [&](long long v) -> long long { return v; };
   if (fastg) {
 #pragma unroll
     for (int u = 0; u < MAXCH; ++u) {
@@ -498,55 +583,82 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       crow[u] = c / kc;
       ccol[u] = (c - crow[u] * kc) * 8;
     }
-    const long long t0 = (long long)blockIdx.x * 4 + wave;
-    if (t0 < ntiles) {
+    if (vt0 < vend) {
+      const long long t0 = map_tile(vt0);
 #pragma unroll
       for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t0 * 32 + crow[u]];
+      prow = a.idx[t0 * 32 + (lane & 31)];
+      if (GATHER_PREFETCH) {
+        gather_issue(t0);
+        const long long t1 = map_tile(vt0 + vstep < vend ? vt0 + vstep : vt0);
+#pragma unroll
+        for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t1 * 32 + crow[u]];
+        prow = a.idx[t1 * 32 + (lane & 31)];
+      }
     }
   }
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
+  // cross-tile prefetch buffer of the BN loaders (see the tile loop); pooled-gradient operands keep the batch form
+  // (BN-backward operands are twice as wide: four chunks, i.e. K <= 64, or the kernel spills)
+  constexpr int HP = (HOIST && LOADER == BNBWD) ? 4 : 8;
+  constexpr bool PF = HOIST && !(LOADER == BNBWD && COUT >= 128);  // those kernels sit at the 256-register line already
+  const bool hoist_pf = PF && nch <= 64 * HP && a.pool_g == nullptr;
+  RawPF<HOIST && LOADER == BNBWD> hp[PF ? HP : 1];
+  if (PF && hoist_pf && vt0 < vend) {
+    const int kshift = __builtin_ctz(kc);
+#pragma unroll
+    for (int u = 0; u < (PF ? HP : 1); ++u) {
+      const int c = min(64 * u + lane, nch - 1);
+      raw_load_pf<HOIST ? LOADER : BNRELU>(a, (int)(vt0 * 32) + (c >> kshift), (c & (kc - 1)) * 8, hp[u]);
+    }
+  }
+  for (long long vt = vt0; vt < vend; vt += vstep) {
+    const long long tile = map_tile(vt);
     const int row0 = (int)(tile * 32);
     if (fastg) {
-      const int scene = row0 / (a.M * a.S);  // wave-uniform (R < 2^31)
-      const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
-      const float *xbase = a.xyz + (long long)scene * a.N * 3;
-      const long long tnext = tile + tile_step < ntiles ? tile + tile_step : tile;
-      for (int u0 = 0; u0 < MAXCH; u0 += 5) {
-        float4 v0[5], v1[5];
+      if (!GATHER_PREFETCH) gather_issue(tile);
+      gather_commit(tile);
+      const long long vnext = vt + vstep;
+      if (GATHER_PREFETCH) {
+        if (vnext < vend) {
+          gather_issue(map_tile(vnext));  // in flight during the MFMAs / epilogue of this tile
+          const long long t2 = map_tile(vnext + vstep < vend ? vnext + vstep : vnext);
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {  // five chunk pairs in flight, addresses need no further loads
-          const int uu = u0 + u;
-          const float *fr = fbase + (long long)pidx[uu] * a.C;
-          const int col = ccol[uu];
-          v0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          v1[u] = v0[u];
-          if (64 * uu < nch) {  // uniform
-            if (col < a.C) v0[u] = ld4(fr + col);
-            if (col + 4 < a.C) v1[u] = ld4(fr + col + 4);
-            if (col == a.C || col + 4 == a.C) {  // the [dx, dy, dz, 0] chunk
-              const float *q = xbase + (long long)pidx[uu] * 3;
-              const int rr = row0 + crow[uu];
-              const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
-              const float *cc3 = a.new_xyz + (long long)bm * 3;
-              const float4 g = make_float4((q[0] - cc3[0]) / a.radius, (q[1] - cc3[1]) / a.radius,
-                                           (q[2] - cc3[2]) / a.radius, 0.f);
-              if (col == a.C) v0[u] = g; else v1[u] = g;
-            }
-          }
+          for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t2 * 32 + crow[u]];
+          prow = a.idx[t2 * 32 + (lane & 31)];
         }
+      } else {
+        const long long t1 = map_tile(vnext < vend ? vnext : vt);
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const int uu = u0 + u;
-          if (64 * uu + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[uu] * ldw + ccol[uu]) = pack8(v0[u], v1[u]);
+        for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t1 * 32 + crow[u]];  // in flight during the MFMAs / epilogue
+        prow = a.idx[t1 * 32 + (lane & 31)];
+      }
+    }
+    // BN loaders with K <= 128 (at most 8 chunks per lane): the whole NEXT tile is requested before this tile goes to the
+    // matrix cores and waits in registers (hp) through products and epilogue, like the gathered operand above.
+    if (PF && hoist_pf) {
+      const int kshift = __builtin_ctz(kc);
+#pragma unroll
+      for (int u = 0; u < (PF ? HP : 1); ++u) {
+        const int c = 64 * u + lane;
+        if (c < nch) {
+          const int row = c >> kshift, ch = c & (kc - 1);
+          *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish_pf<HOIST ? LOADER : BNRELU>(hp[u], ca, cb, cc);
         }
       }
+      const long long vnext = vt + vstep;
+      if (vnext < vend) {
+        const int nrow0 = (int)(vnext * 32);
 #pragma unroll
-      for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[tnext * 32 + crow[u]];  // in flight during the MFMAs / epilogue
+        for (int u = 0; u < (PF ? HP : 1); ++u) {
+          const int c = min(64 * u + lane, nch - 1);
+          raw_load_pf<HOIST ? LOADER : BNRELU>(a, nrow0 + (c >> kshift), (c & (kc - 1)) * 8, hp[u]);
+        }
+      }
     }
     // chunks in flight per lane: four, two for the wide BN-backward kernels (their raw operands — y, g or the pooled
     // triple — at four in flight pushed the kernel over 256 registers: one wave per SIMD)
     constexpr int UB = (LOADER == BNBWD && COUT >= 128) ? 2 : 4;
-    for (int c0 = 0; !fastg && c0 < nch; c0 += (HOIST ? 64 * UB : 256)) {
+    for (int c0 = 0; !fastg && !(PF && hoist_pf) && c0 < nch; c0 += (HOIST ? 64 * UB : 256)) {
       if (HOIST) {
         Raw8 raw[UB];
         const int kshift = __builtin_ctz(kc);  // kc | 64: a power of two (shifts instead of eight divisions per batch)

@@ -159,9 +159,10 @@ class GroundingStep:
 
     @staticmethod
     def _copy_geometry(dst, src):
-        for k in src:
-            for a, b in zip(dst[k], src[k]):
-                a.copy_(b)
+        """All index / coordinate tensors of the backbone geometry in ONE multi-tensor copy (was 16 small copies)."""
+        d = [a for k in src for a in dst[k]]
+        s_ = [b for k in src for b in src[k]]
+        torch._foreach_copy_(d, s_)
 
     @staticmethod
     def _tag(batch):

@@ -109,7 +109,6 @@ class PointnetSAModuleVotes(nn.Module):
         # autocast the previous layer hands over bf16 activations
         xyz = xyz.float()
         features = features.float() if features is not None else None
-        xyz_flipped = xyz.transpose(1, 2).contiguous()
         use_rows = self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda
         if geometry is not None:
             assert use_rows, "precomputed geometry needs the fused path"
@@ -121,6 +120,7 @@ class PointnetSAModuleVotes(nn.Module):
         if use_rows:
             return self._forward_rows(xyz, features, inds)
         features = features.contiguous() if features is not None else None
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = (pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
                    if self.npoint is not None else None)
 

@@ -34,7 +34,7 @@ with Mode():
     d = dict(batch); d["epoch"] = step.epoch
     d = step.model(d)
     phase[0] = "loss"
-    loss = gs.grounding_loss(d, step.model.mean_size_arr)
+    loss = gs.grounding_loss(d, step.model.dataset_config)
     phase[0] = "backward"
     loss.backward()
     phase[0] = "collect+opt"
