@@ -72,6 +72,16 @@ SIGNATURES = {
     "vlp3d_rows_act_bwd": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_fp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_fp_rows_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_roi_split": [_vp, _i, ctypes.c_longlong, _i, _i, _f] + [_vp] * 8 + [_vp],
+    "vlp3d_roi_split_bwd": [_vp] * 7 + [ctypes.c_longlong, _i, _i, _f, _vp, _i, _vp],
+    "vlp3d_vote_epilogue": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_vote_epilogue_bwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp],
+    "vlp3d_l2norm_rows": [_vp, ctypes.c_longlong, _i, _f, _vp, _vp, _vp],
+    "vlp3d_l2norm_rows_bwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _vp],
+    "vlp3d_relation_inputs": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_copy_paste_map": [_vp, _i, _i, _vp, _vp, _vp],
+    "vlp3d_gather_rows": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
+    "vlp3d_scatter_rows_add": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_probe_read": [_vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],

@@ -1,0 +1,340 @@
+// Small fused "glue" kernels: each replaces a dozen element-wise / index framework launches (~5 us apiece inside the
+// replayed graph) between the matrix-core kernels of the grounding step.
+//   roi_split        roi_heads.py:135-147   column blocks of the merged predictor output -> contiguous tensors (+ exp, scale,
+//                                           arg-max masks); backward = one gather of the five gradient pieces
+//   vote_epilogue    voting_module.py:51-58 + jointnet.py:148-149   vote_xyz = seed_xyz + offset, vote_features =
+//                                           (seed_features + residual) / |.|_2   (vote_factor 1), and its backward
+//   l2norm_rows      F.normalize(x, dim=-1) of constrast_module.py:97-117 (eps 1e-12), and its backward
+//   relation_inputs  relation_module.py:95-122   object "multiview" feature rows (the reference's indexing quirk), box
+//                                           centre + corner offsets (27), corner mean (no gradient: detached inputs)
+//   copy_paste       match_module.py:97-121  object-feature copy-paste augmentation as a fixed-shape gather, and its adjoint
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---- roi_split -------------------------------------------------------------------------------------------------------
+// out (R x ld): [heading_reg NH | heading_cls NH | box 6 | objectness 2 | sem NC]
+__global__ __launch_bounds__(256) void roi_split_kernel(const float *__restrict__ out, int ld, long long R, int NH, int NC,
+                                                        float res_scale, float *__restrict__ hreg, float *__restrict__ hres,
+                                                        float *__restrict__ hcls, float *__restrict__ rois,
+                                                        float *__restrict__ obj, float *__restrict__ sem,
+                                                        long long *__restrict__ obj_mask, long long *__restrict__ sem_arg) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float *o = out + r * ld;
+  for (int c = 0; c < NH; ++c) {
+    hreg[r * NH + c] = o[c];
+    hres[r * NH + c] = o[c] * res_scale;
+    hcls[r * NH + c] = o[NH + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) rois[r * 6 + c] = expf(o[2 * NH + c]);
+  const float o0 = o[2 * NH + 6], o1 = o[2 * NH + 7];
+  obj[r * 2] = o0;
+  obj[r * 2 + 1] = o1;
+  obj_mask[r] = o1 > o0 ? 1 : 0;  // argmax, first maximum
+  int best = 0;
+  float bv = o[2 * NH + 8];
+  for (int c = 0; c < NC; ++c) {
+    const float v = o[2 * NH + 8 + c];
+    sem[r * NC + c] = v;
+    if (v > bv) { bv = v; best = c; }
+  }
+  sem_arg[r] = best;
+}
+
+// d(out) from the gradients of the pieces (any may be NULL = zero); columns past the 2NH + 8 + NC used ones are zeroed
+__global__ __launch_bounds__(256) void roi_split_bwd_kernel(const float *__restrict__ d_hreg, const float *__restrict__ d_hres,
+                                                            const float *__restrict__ d_hcls, const float *__restrict__ d_rois,
+                                                            const float *__restrict__ d_obj, const float *__restrict__ d_sem,
+                                                            const float *__restrict__ rois, long long R, int NH, int NC,
+                                                            float res_scale, float *__restrict__ d_out, int ld) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float *o = d_out + r * ld;
+  for (int c = 0; c < NH; ++c) {
+    o[c] = (d_hreg ? d_hreg[r * NH + c] : 0.f) + (d_hres ? d_hres[r * NH + c] * res_scale : 0.f);
+    o[NH + c] = d_hcls ? d_hcls[r * NH + c] : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o[2 * NH + c] = d_rois ? d_rois[r * 6 + c] * rois[r * 6 + c] : 0.f;
+  o[2 * NH + 6] = d_obj ? d_obj[r * 2] : 0.f;
+  o[2 * NH + 7] = d_obj ? d_obj[r * 2 + 1] : 0.f;
+  for (int c = 0; c < NC; ++c) o[2 * NH + 8 + c] = d_sem ? d_sem[r * NC + c] : 0.f;
+  for (int c = 2 * NH + 8 + NC; c < ld; ++c) o[c] = 0.f;
+}
+
+// ---- vote_epilogue: one wave per seed ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vote_epilogue_kernel(const float *__restrict__ seed_xyz, const float *__restrict__ seed_f,
+                                                            const float *__restrict__ net, int ld, long long R, int C,
+                                                            float *__restrict__ vote_xyz, float *__restrict__ vote_f,
+                                                            float *__restrict__ norm) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float *n = net + r * ld;
+  if (lane < 3) vote_xyz[r * 3 + lane] = seed_xyz[r * 3 + lane] + n[lane];
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = seed_f[r * C + c] + n[3 + c];
+    ss += v * v;
+  }
+  const float nr = sqrtf(wave_sum(ss));
+  for (int c = lane; c < C; c += 64) vote_f[r * C + c] = (seed_f[r * C + c] + n[3 + c]) / nr;
+  if (lane == 0) norm[r] = nr;
+}
+
+// v = out * norm;  d_v = (g - out * <out, g>) / norm;  d_seed_f = d_v (+ nothing else here), d_net = [d_vote_xyz | d_v | 0]
+__global__ __launch_bounds__(256) void vote_epilogue_bwd_kernel(const float *__restrict__ d_xyz, const float *__restrict__ d_f,
+                                                                const float *__restrict__ vote_f, const float *__restrict__ norm,
+                                                                long long R, int C, float *__restrict__ d_seed_f,
+                                                                float *__restrict__ d_net, int ld) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float dot = 0.f;
+  if (d_f)
+    for (int c = lane; c < C; c += 64) dot += vote_f[r * C + c] * d_f[r * C + c];
+  dot = wave_sum(dot);
+  const float inv = 1.f / norm[r];
+  float *dn = d_net + r * ld;
+  if (lane < 3) dn[lane] = d_xyz ? d_xyz[r * 3 + lane] : 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float dv = d_f ? (d_f[r * C + c] - vote_f[r * C + c] * dot) * inv : 0.f;
+    d_seed_f[r * C + c] = dv;
+    dn[3 + c] = dv;
+  }
+  for (int c = 3 + C + lane; c < ld; c += 64) dn[c] = 0.f;
+}
+
+// ---- l2norm_rows: one wave per row ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ x, long long R, int C, float eps,
+                                                          float *__restrict__ y, float *__restrict__ norm) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += x[r * C + c] * x[r * C + c];
+  const float nr = fmaxf(sqrtf(wave_sum(ss)), eps);  // F.normalize: x / max(|x|, eps)
+  for (int c = lane; c < C; c += 64) y[r * C + c] = x[r * C + c] / nr;
+  if (lane == 0) norm[r] = nr;
+}
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                              const float *__restrict__ norm, long long R, int C, float eps,
+                                                              float *__restrict__ dx) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += y[r * C + c] * g[r * C + c];
+  dot = wave_sum(dot);
+  const float nr = norm[r];
+  const float k = nr > eps ? dot : 0.f;  // clamped norm: the denominator is a constant, no projection term
+  for (int c = lane; c < C; c += 64) dx[r * C + c] = (g[r * C + c] - y[r * C + c] * k) / nr;
+}
+
+// ---- relation_inputs: one wave per proposal ---------------------------------------------------------------------------
+// obj_feat[b,k,:]: 128 consecutive elements of the channel-major (B,128,N) multiview block starting at flat element
+// (src + 128 b) * 128, src = seed_inds[b][vote_inds[b][k]] (relation_module.py:98-113: ids offset by b*128, rows taken
+// from the channel-major reshape) read from the point-major point cloud pc (B,N,3+3+128..): element e of that block ->
+// batch e / (128 N), channel (e % (128 N)) / N, point e % N, stored at pc[batch][point][6 + channel].
+__global__ __launch_bounds__(256) void relation_inputs_kernel(const float *__restrict__ pc, int Cpc, int N,
+                                                              const int *__restrict__ seed_inds, int S,
+                                                              const int *__restrict__ vote_inds, const float *__restrict__ corners,
+                                                              int B, int K, float *__restrict__ obj_feat,
+                                                              float *__restrict__ bbox_feat, float *__restrict__ centre) {
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= (long long)B * K) return;
+  const int b = (int)(t / K);
+  const int src = seed_inds[(long long)b * S + vote_inds[t]];
+  const long long row_id = (long long)src + (long long)b * 128;
+  for (int c = lane; c < 128; c += 64) {
+    const long long flat = row_id * 128 + c;
+    const long long fb = flat / (128ll * N), rem = flat - fb * 128ll * N;
+    const long long ch = rem / N, pt = rem - ch * N;
+    obj_feat[t * 128 + c] = fb < B ? pc[(fb * N + pt) * Cpc + 6 + ch] : 0.f;
+  }
+  if (lane < 3) {  // per coordinate: min / max / mean over the 8 corners
+    const float *cr = corners + t * 24 + lane;
+    float mn = cr[0], mx = cr[0], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = cr[3 * j];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+      sum += v;
+    }
+    const float bc = (mn + mx) / 2.f;
+    bbox_feat[t * 27 + lane] = bc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bbox_feat[t * 27 + 3 + 3 * j + lane] = cr[3 * j] - bc;
+    centre[t * 3 + lane] = sum / 8.f;
+  }
+}
+
+// ---- copy_paste -------------------------------------------------------------------------------------------------------
+// src[b*K + k] = flat source slot of proposal (b,k) after the augmentation (its own slot when nothing is pasted):
+// background slot of rank r in scene i  <-  pool[(J_i + r) mod total]  if r < total - n_i  (match_module.py:97-121),
+// J_i = objects in scenes 0..i, pool = object proposals in (scene, proposal) order.  One workgroup, B*K <= 8192.
+__global__ __launch_bounds__(1024) void copy_paste_map_kernel(const long long *__restrict__ obj_mask, int B, int K,
+                                                              const float *__restrict__ coin, int *__restrict__ src) {
+  extern __shared__ int sm[];  // [B*K] object flags -> pool positions; [B] n_obj; [B] J
+  int *flag = sm, *pool = sm + B * K, *nobj = pool + B * K, *J = nobj + B;
+  const int n = B * K;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) flag[i] = obj_mask[i] != 0;
+  __syncthreads();
+  if ((int)threadIdx.x < B) {
+    int c = 0;
+    for (int k = 0; k < K; ++k) c += flag[threadIdx.x * K + k];
+    nobj[threadIdx.x] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) { acc += nobj[b]; J[b] = acc; }
+  }
+  __syncthreads();
+  const int total = J[B - 1];
+  // pool: object slots in (scene, proposal) order; one thread per scene walks its K slots (B <= 32, K <= 1024)
+  if ((int)threadIdx.x < B) {
+    const int b = threadIdx.x;
+    int p = J[b] - nobj[b];
+    for (int k = 0; k < K; ++k)
+      if (flag[b * K + k]) pool[p++] = b * K + k;
+  }
+  __syncthreads();
+  const bool use = coin[0] < 0.5f;
+  if ((int)threadIdx.x < B) {
+    const int b = threadIdx.x;
+    int rank = 0;
+    for (int k = 0; k < K; ++k) {
+      const int i = b * K + k;
+      int s = i;
+      if (!flag[i]) {
+        if (use && total > 0 && rank < total - nobj[b]) s = pool[(J[b] + rank) % total];
+        ++rank;
+      }
+      src[i] = s;
+    }
+  }
+}
+
+// out[i,:] = x[src[i],:]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int *__restrict__ src, long long R,
+                                                          int D, float *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int q = D / 4;
+  if (t >= R * q) return;
+  const long long i = t / q;
+  const int c = (int)(t - i * q) * 4;
+  *reinterpret_cast<float4 *>(out + i * D + c) = *reinterpret_cast<const float4 *>(x + (long long)src[i] * D + c);
+}
+// dx[src[i],:] += g[i,:]   (dx zeroed by the caller; several proposals may copy the same object row)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restrict__ g, const int *__restrict__ src, long long R,
+                                                           int D, float *__restrict__ dx) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= R * D) return;
+  const long long i = t / D;
+  const int c = (int)(t - i * D);
+  atomicAdd(dx + (long long)src[i] * D + c, g[i * D + c]);
+}
+
+unsigned blocks_of(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int vlp3d_roi_split(const float *out, int ld, long long R, int NH, int NC, float res_scale, float *hreg, float *hres,
+                               float *hcls, float *rois, float *obj, float *sem, long long *obj_mask, long long *sem_arg,
+                               void *stream) {
+  if (!out || !hreg || !hres || !hcls || !rois || !obj || !sem || !obj_mask || !sem_arg || R < 1 || NH < 1 || NC < 1 ||
+      ld < 2 * NH + 8 + NC)
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(roi_split_kernel, dim3(blocks_of(R, 256)), dim3(256), 0, (hipStream_t)stream, out, ld, R, NH, NC, res_scale,
+                     hreg, hres, hcls, rois, obj, sem, obj_mask, sem_arg);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_roi_split_bwd(const float *d_hreg, const float *d_hres, const float *d_hcls, const float *d_rois,
+                                   const float *d_obj, const float *d_sem, const float *rois, long long R, int NH, int NC,
+                                   float res_scale, float *d_out, int ld, void *stream) {
+  if (!rois || !d_out || R < 1 || NH < 1 || NC < 1 || ld < 2 * NH + 8 + NC) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(roi_split_bwd_kernel, dim3(blocks_of(R, 256)), dim3(256), 0, (hipStream_t)stream, d_hreg, d_hres, d_hcls,
+                     d_rois, d_obj, d_sem, rois, R, NH, NC, res_scale, d_out, ld);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_vote_epilogue(const float *seed_xyz, const float *seed_f, const float *net, int ld, long long R, int C,
+                                   float *vote_xyz, float *vote_f, float *norm, void *stream) {
+  if (!seed_xyz || !seed_f || !net || !vote_xyz || !vote_f || !norm || R < 1 || C < 1 || ld < 3 + C) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(vote_epilogue_kernel, dim3(blocks_of(R, 4)), dim3(256), 0, (hipStream_t)stream, seed_xyz, seed_f, net, ld, R,
+                     C, vote_xyz, vote_f, norm);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_vote_epilogue_bwd(const float *d_vote_xyz, const float *d_vote_f, const float *vote_f, const float *norm,
+                                       long long R, int C, float *d_seed_f, float *d_net, int ld, void *stream) {
+  if (!vote_f || !norm || !d_seed_f || !d_net || R < 1 || C < 1 || ld < 3 + C) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(vote_epilogue_bwd_kernel, dim3(blocks_of(R, 4)), dim3(256), 0, (hipStream_t)stream, d_vote_xyz, d_vote_f,
+                     vote_f, norm, R, C, d_seed_f, d_net, ld);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_l2norm_rows(const float *x, long long R, int C, float eps, float *y, float *norm, void *stream) {
+  if (!x || !y || !norm || R < 1 || C < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(blocks_of(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, eps, y, norm);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_l2norm_rows_bwd(const float *g, const float *y, const float *norm, long long R, int C, float eps, float *dx,
+                                     void *stream) {
+  if (!g || !y || !norm || !dx || R < 1 || C < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(blocks_of(R, 4)), dim3(256), 0, (hipStream_t)stream, g, y, norm, R, C, eps, dx);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_relation_inputs(const float *pc, int Cpc, int N, const int *seed_inds, int S, const int *vote_inds,
+                                     const float *corners, int B, int K, float *obj_feat, float *bbox_feat, float *centre,
+                                     void *stream) {
+  if (!pc || !seed_inds || !vote_inds || !corners || !obj_feat || !bbox_feat || !centre || B < 1 || K < 1 || N < 1 || S < 1 ||
+      Cpc < 6 + 128)
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(relation_inputs_kernel, dim3(blocks_of((long long)B * K, 4)), dim3(256), 0, (hipStream_t)stream, pc, Cpc, N,
+                     seed_inds, S, vote_inds, corners, B, K, obj_feat, bbox_feat, centre);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_copy_paste_map(const long long *obj_mask, int B, int K, const float *coin, int *src, void *stream) {
+  if (!obj_mask || !coin || !src || B < 1 || B > 1024 || K < 1 || (long long)B * K > 8192) return VLP3D_EINVAL;
+  const size_t lds = ((size_t)2 * B * K + 2 * B) * sizeof(int);
+  hipLaunchKernelGGL(copy_paste_map_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, obj_mask, B, K, coin, src);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_gather_rows(const float *x, const int *src, long long R, int D, float *out, void *stream) {
+  if (!x || !src || !out || R < 1 || D < 4 || (D & 3)) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_of(R * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, src, R, D, out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_scatter_rows_add(const float *g, const int *src, long long R, int D, float *dx, void *stream) {
+  if (!g || !src || !dx || R < 1 || D < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks_of(R * D, 256)), dim3(256), 0, (hipStream_t)stream, g, src, R, D, dx);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

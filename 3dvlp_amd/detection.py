@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
-from . import row_mlp
+from . import glue, row_mlp
 from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
@@ -103,6 +103,24 @@ class VotingModule(nn.Module):
         self.bn2 = nn.BatchNorm1d(self.in_dim)
         self.fused = True  # csrc/rows_mlp.hip on CUDA tensors; False = the reference's Conv1d / BatchNorm1d / ReLU sequence
 
+    def _layers(self):
+        return [(self.conv1.weight, self.conv1.bias, self.bn1), (self.conv2.weight, self.conv2.bias, self.bn2),
+                (self.conv3.weight, self.conv3.bias, None)]
+
+    def forward_normalized(self, seed_xyz, seed_features):
+        """forward() followed by jointnet.py:148-149's `features / |features|_2` with the whole epilogue in one kernel
+        (csrc/glue.hip: vote_epilogue); None when the fused path does not apply (the caller then runs forward())."""
+        if not (self.fused and seed_features.is_cuda and self.vote_factor == 1):
+            return None
+        B, num_seed = seed_xyz.shape[:2]
+        seed_pm = seed_features.float().transpose(1, 2).contiguous()
+        X = seed_pm.view(B * num_seed, self.in_dim)
+        if not row_mlp.supported(X, self._layers()):
+            return None
+        net = row_mlp.row_stack(X, self._layers(), keep_pad=True)           # (R, 320): [offset 3 | residual C | 0]
+        vote_xyz, vote_features = glue.vote_epilogue(seed_xyz.float(), seed_pm, net)
+        return vote_xyz, vote_features.transpose(2, 1)                      # (B,C,num_vote) view of point-major data
+
     def forward(self, seed_xyz, seed_features):
         B, num_seed = seed_xyz.shape[:2]
         num_vote = num_seed * self.vote_factor
@@ -165,8 +183,14 @@ class StandardROIHeads(nn.Module):
                       (self.convs[3].weight, self.convs[3].bias, self.convs[4]),
                       (torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0), None)]
             if row_mlp.supported(X, layers):
-                out = row_mlp.row_stack(X, layers).view(B, K, -1)
-                return self._split(out, heads, data_dict)
+                out = row_mlp.row_stack(X, layers, keep_pad=True)              # (R, 64): the 28 predictor channels + 0
+                (heading_reg, hres, hcls, rois, obj, sem, omask, sarg) = glue.roi_split(
+                    out.view(B, K, -1), self.num_heading_bin, self.num_class)
+                data_dict["sem_cls_scores"], data_dict["heading_scores"] = sem, hcls
+                data_dict["heading_residuals_normalized"], data_dict["heading_residuals"] = heading_reg, hres
+                data_dict["rois"], data_dict["objectness_scores"] = rois, obj
+                data_dict["bbox_mask"], data_dict["pred_bbox_sems"] = omask, sarg
+                return data_dict
         x = self.convs(ROI_features)
         if self.use_kl_loss:
             data_dict["alpha"] = self.alpha_activation(self.alpha_predictor(x).permute(0, 2, 1)) * 0.1 - 0.05
@@ -317,8 +341,10 @@ class ProposalModule(nn.Module):
     def decode_scores(self, data_dict):
         data_dict = self.decode_pred_box(data_dict)
         data_dict["pred_bbox_feature"] = data_dict["aggregated_vote_features"]
-        data_dict["pred_bbox_mask"] = data_dict["objectness_scores"].argmax(-1)
-        data_dict["pred_bbox_sems"] = data_dict["sem_cls_scores"].argmax(-1)
+        data_dict["pred_bbox_mask"] = data_dict["bbox_mask"] if "bbox_mask" in data_dict else \
+            data_dict["objectness_scores"].argmax(-1)
+        if "pred_bbox_sems" not in data_dict:  # the fused ROI split already produced both arg-max masks
+            data_dict["pred_bbox_sems"] = data_dict["sem_cls_scores"].argmax(-1)
         return data_dict
 
     def mask(self, pred_center, pred_box_size):
@@ -389,8 +415,12 @@ class RelationModule(nn.Module):
         B, K = features.shape[:2]
         corners = data_dict["pred_bbox_corner"]
 
+        fused_inputs = self.fused_bias and corners.is_cuda and data_dict["point_clouds"].shape[-1] >= 134
+        if fused_inputs:  # obj_feat, manual_bbox_feat and the corner mean in ONE launch (csrc/glue.hip), no gradient
+            obj_feat, manual_bbox_feat, centre = glue.relation_inputs(
+                data_dict["point_clouds"], data_dict["seed_inds"], data_dict["aggregated_vote_inds"], corners)
         # pairwise geometry (layer-independent): delta[b,i,j] = centre_j - centre_i, plus its norm
-        centre = corners.mean(dim=-2)
+        centre = centre if fused_inputs else corners.mean(dim=-2)
         pair = None
         if not (self.fused_bias and centre.is_cuda):
             delta = centre[:, None, :, :] - centre[:, :, None, :]
@@ -401,18 +431,19 @@ class RelationModule(nn.Module):
         # ids by b*128 (obj_feat.shape[1] AFTER its permute = the channel count, not N) and takes ROWS OF
         # 128 CONSECUTIVE ELEMENTS of the channel-major (B,128,N) copy, so "row id" is the flat element
         # range [id*128, id*128+128) of that layout.  Same values here, without the 164 MB copy.
-        pc = data_dict["point_clouds"]
-        N = pc.shape[1]
-        seed_inds = data_dict["seed_inds"].long()
-        src = torch.gather(seed_inds, 1, data_dict["aggregated_vote_inds"].long())  # (B,K)
-        row_id = src + torch.arange(B, device=src.device)[:, None] * 128
-        flat = row_id.unsqueeze(-1) * 128 + torch.arange(128, device=src.device)  # (B,K,128) into (B,128,N)
-        fb, rem = flat // (128 * N), flat % (128 * N)
-        obj_feat = pc[fb, rem % N, 6 + rem // N]
+        if not fused_inputs:
+            pc = data_dict["point_clouds"]
+            N = pc.shape[1]
+            seed_inds = data_dict["seed_inds"].long()
+            src = torch.gather(seed_inds, 1, data_dict["aggregated_vote_inds"].long())  # (B,K)
+            row_id = src + torch.arange(B, device=src.device)[:, None] * 128
+            flat = row_id.unsqueeze(-1) * 128 + torch.arange(128, device=src.device)  # (B,K,128) into (B,128,N)
+            fb, rem = flat // (128 * N), flat % (128 * N)
+            obj_feat = pc[fb, rem % N, 6 + rem // N]
 
-        cmin, cmax = corners.min(dim=2)[0], corners.max(dim=2)[0]
-        box_centre = (cmin + cmax) / 2
-        manual_bbox_feat = torch.cat([box_centre, (corners - box_centre[:, :, None, :]).reshape(B, K, -1)], -1).float()
+            cmin, cmax = corners.min(dim=2)[0], corners.max(dim=2)[0]
+            box_centre = (cmin + cmax) / 2
+            manual_bbox_feat = torch.cat([box_centre, (corners - box_centre[:, :, None, :]).reshape(B, K, -1)], -1).float()
 
         dist_weights = None
         for i in range(self.depth):

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as _ext
+from . import glue
 from .mfma_linear import linear as _linear
 from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
 
@@ -65,11 +66,10 @@ class MatchModule(nn.Module):
         return torch.where(take.unsqueeze(-1), pasted, features)
 
     def forward(self, data_dict):
-        objectness_masks = data_dict["objectness_scores"].max(2)[1].float().unsqueeze(2)
         features = data_dict["bbox_feature"]  # (B, K, hidden)
         B, K = features.shape[:2]
         L = data_dict["input_ids"].shape[1]
-        feature0 = features.clone()
+        feature0 = features
         if data_dict["istrain"][0] == 1:
             # the reference draws random.random() < 0.5 on the host; a device-side draw keeps the step free of
             # host decisions (graph-capturable) with the same 50 % rate
@@ -77,11 +77,16 @@ class MatchModule(nn.Module):
             if coin is None:
                 coin = torch.rand((), device=features.device)
             data_dict["random"] = coin
-            use = torch.as_tensor(coin, device=features.device) < 0.5
-            feature0 = torch.where(use, self._copy_paste(features, objectness_masks), feature0)
+            coin = torch.as_tensor(coin, device=features.device)
+            obj_mask = data_dict["bbox_mask"] if "bbox_mask" in data_dict else data_dict["objectness_scores"].max(2)[1]
+            if features.is_cuda and features.dtype == torch.float32 and B * K <= 8192 and features.shape[-1] % 4 == 0:
+                feature0 = glue.copy_paste(features, obj_mask, coin)  # index map + row gather: two launches
+            else:
+                feature0 = torch.where(coin < 0.5, self._copy_paste(features, obj_mask.float().unsqueeze(2)), features)
 
         feature1 = feature0[:, None, :, :].expand(B, L, K, feature0.shape[-1]).reshape(B * L, K, -1)
-        lang_fea = data_dict["lang_fea"][:, 1:]  # K/V = the tokens after [CLS]
+        # K/V = the tokens after [CLS]; the loader may hand over the contiguous copy (grounding_step.batch_to_device)
+        lang_fea = data_dict["k/lang_kv"] if "k/lang_kv" in data_dict else data_dict["lang_fea"][:, 1:]
 
         for layer in self.grounding_cross_attn:
             feature1 = layer(feature1, lang_fea, lang_fea)  # (B*L, K, hidden)
@@ -194,14 +199,15 @@ class ContrastModule(nn.Module):
         if self._mean_size is None or self._mean_size.device != features.device:
             self._mean_size = torch.as_tensor(self.config.mean_size_arr, dtype=torch.float32, device=features.device)
         mean_size = self._mean_size
-        gt_size = mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
+        gt_size = data_dict["k/ref_size"] if "k/ref_size" in data_dict else \
+            mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
         lang_emb = data_dict["lang_emb"].view(B, -1, data_dict["lang_emb"].shape[-1])[:, :L]
         obj = data_dict["objectness_scores"].max(2)[1].float()  # (B,K) 1 = takes part
         if self.fused and features.is_cuda and K <= 1024 and L <= 64 and features.shape[-1] % 4 == 0:
             # three launches (csrc/contrast.hip) instead of ~45 + ~45 in autograd's backward
-            text = F.normalize(_linear(lang_emb.contiguous(), self.text_proj.weight), dim=-1)
-            box = F.normalize(_linear(features, self.pc_proj.weight), dim=-1)
-            boxi = F.normalize(_linear(features, self.pc_proj_iou[0].weight), dim=-1)
+            text = glue.l2norm_rows(_linear(lang_emb.contiguous(), self.text_proj.weight))
+            box = glue.l2norm_rows(_linear(features, self.pc_proj.weight))
+            boxi = glue.l2norm_rows(_linear(features, self.pc_proj_iou[0].weight))
             data_dict["lang_con_loss"], data_dict["iou_con_loss"] = _ContrastCore.apply(
                 text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, data_dict["lang_num"])
             return data_dict

@@ -49,8 +49,12 @@ class GroundingNet(nn.Module):
         data_dict = self.backbone_net(data_dict)
         xyz, features = data_dict["fp2_xyz"], data_dict["fp2_features"]
         data_dict["seed_inds"], data_dict["seed_xyz"], data_dict["seed_features"] = data_dict["fp2_inds"], xyz, features
-        xyz, features = self.vgen(xyz, features)
-        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        fused = self.vgen.forward_normalized(xyz, features)  # votes + jointnet.py:148-149's L2 norm in one epilogue kernel
+        if fused is not None:
+            xyz, features = fused
+        else:
+            xyz, features = self.vgen(xyz, features)
+            features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
         data_dict["vote_xyz"], data_dict["vote_features"] = xyz, features
         data_dict = self.proposal(xyz, features, data_dict)
         data_dict = self.relation(data_dict)
@@ -71,9 +75,24 @@ def grounding_loss(d, config, args=None, impl=None):
     return d["loss"]
 
 
-def batch_to_device(batch, device):
+def batch_to_device(batch, device, mean_size_arr=None):
+    """Host batch (numpy, the reference's keys and dtypes) -> device tensors, plus the KERNEL-READY forms of pure input
+    data that the step would otherwise re-derive with a dozen small launches every iteration (this is loader work: it
+    depends on the batch only, never on the model):
+      k/vote_label_mask f32, k/{heading_class,size_class,sem_cls}_label i32, k/lang_num i32 — dtypes the loss kernel
+      reads (lib/joint/dataset.py hands them over as int64);  k/ref_size — decoded size of the referred boxes
+      (class2size, model_util_scannet.py:183-185; consumed by the DIoU loss and the contrast module);
+      k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134)."""
     out = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     out["istrain"] = [1]
+    mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32,
+                           device=device)
+    out["k/vote_label_mask"] = out["vote_label_mask"].float()
+    for k in ("heading_class_label", "size_class_label", "sem_cls_label", "lang_num"):
+        if k in out:
+            out["k/" + k] = out[k].to(torch.int32)
+    out["k/ref_size"] = (mean[out["ref_size_class_label_list"]] + out["ref_size_residual_label_list"]).float().contiguous()
+    out["k/lang_kv"] = out["lang_fea"][:, 1:].contiguous()
     return out
 
 

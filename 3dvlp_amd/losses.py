@@ -267,15 +267,17 @@ def _labels(data_dict, config, device):
     f = lambda t: t.contiguous().float()
     i32 = lambda t: t.contiguous().to(torch.int32)
     mean = _const(("mean_size", id(config)), lambda: torch.as_tensor(np.asarray(config.mean_size_arr, np.float32)), device)
-    ref_size = (mean[d["ref_size_class_label_list"]] + d["ref_size_residual_label_list"]).float().contiguous()
+    ref_size = d["k/ref_size"] if "k/ref_size" in d else \
+        (mean[d["ref_size_class_label_list"]] + d["ref_size_residual_label_list"]).float().contiguous()
+    k = lambda name, conv: d["k/" + name] if ("k/" + name) in d else conv(d[name])  # loader-prepared form when present
     if d["istrain"][0] == 1 and "random" in d:
         coin = torch.as_tensor(d["random"], device=device, dtype=torch.float32).reshape(1)
     else:
         coin = _const("coin_off", lambda: torch.ones(1), device)  # >= 0.5: no objectness gating of the IoUs
-    return (f(d["seed_xyz"]), i32(d["seed_inds"]), f(d["vote_label"]), f(d["vote_label_mask"]),
-            f(d["center_label"][:, :, 0:3]), i32(d["heading_class_label"]), f(d["heading_residual_label"]),
-            i32(d["size_class_label"]), f(d["size_residual_label"]), i32(d["sem_cls_label"]),
-            f(d["ref_center_label_list"][..., 0:3]), ref_size, i32(d["lang_num"]), coin, mean.contiguous())
+    return (f(d["seed_xyz"]), i32(d["seed_inds"]), f(d["vote_label"]), k("vote_label_mask", f),
+            f(d["center_label"][:, :, 0:3]), k("heading_class_label", i32), f(d["heading_residual_label"]),
+            k("size_class_label", i32), f(d["size_residual_label"]), k("sem_cls_label", i32),
+            f(d["ref_center_label_list"][..., 0:3]), ref_size, k("lang_num", i32), coin, mean.contiguous())
 
 
 class _Args:
@@ -343,7 +345,7 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
         d["lang_loss"] = compute_lang_classification_loss(d)
         loss = loss + 0.3 * d["lang_loss"]
     else:
-        d["lang_loss"] = torch.zeros((), device=dev)
+        d["lang_loss"] = _const("zero", lambda: torch.zeros(()), dev)
     if getattr(args, "use_con", False):
         if d["epoch"] >= 50:
             d["con_loss"] = 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]   # loss_joint.py:208
@@ -351,6 +353,6 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
     else:
         d["con_loss"] = torch.zeros(1)
     for k in ("cap_loss", "cap_acc", "ori_loss", "ori_acc", "dist_loss", "mlm_loss"):
-        d[k] = torch.zeros((), device=dev)
+        d[k] = _const("zero", lambda: torch.zeros(()), dev)
     d["loss"] = loss
     return d

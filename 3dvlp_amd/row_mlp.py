@@ -51,7 +51,7 @@ def supported(x, layers):
 
 class _RowStack(Function):
     @staticmethod
-    def forward(ctx, x, bns, *params):
+    def forward(ctx, x, bns, keep_pad, *params):
         L = len(bns)
         W, bias, gam, bet = params[0::4], params[1::4], params[2::4], params[3::4]
         R, dev = x.shape[0], x.device
@@ -102,7 +102,7 @@ class _RowStack(Function):
             out = torch.empty_like(Ys[-1])
             _ext.call("vlp3d_rows_act", Ys[-1], R, Ys[-1].shape[1], vecs[-1], out)
         else:
-            out = Ys[-1][:, :W[-1].shape[0]]
+            out = Ys[-1] if keep_pad else Ys[-1][:, :W[-1].shape[0]]
         ctx.save_for_backward(x, *Ys, *[v for v in vecs if v is not None], *Wp, *[g for g in gam if g is not None])
         ctx.meta = (L, [v is not None for v in vecs], training, [b is not None for b in bias],
                     [tuple(w.shape) for w in W])
@@ -132,7 +132,7 @@ class _RowStack(Function):
             _ext.call("vlp3d_rows_act_bwd", dout.contiguous(), Ys[last], R, Np, vecs[last], G, t)
         else:
             N = wshapes[last][0]
-            G = dout if Np == N else torch.nn.functional.pad(dout, (0, Np - N))
+            G = dout if dout.shape[1] == Np else torch.nn.functional.pad(dout, (0, Np - N))
             G = G.contiguous()
             t, tn = None, 0
         dx = None
@@ -174,16 +174,18 @@ class _RowStack(Function):
                 dx = torch.empty((R, K), dtype=torch.float32, device=dev)
                 _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, None, 0, None,
                           dx, K, None)
-        return (dx, None, *grads)
+        return (dx, None, None, *grads)
 
 
-def row_stack(x, layers):
-    """x (R, K0) fp32 CUDA; layers = [(weight (N,K[,1[,1]]), bias or None, bn module or None), ...] -> (R, N_last)."""
+def row_stack(x, layers, keep_pad=False):
+    """x (R, K0) fp32 CUDA; layers = [(weight (N,K[,1[,1]]), bias or None, bn module or None), ...] -> (R, N_last).
+    keep_pad: return the final plain layer's full 64-aligned buffer (R, round_up(N, 64)); the columns past N are zero
+    and take no gradient — lets a consumer kernel address column blocks without a slice copy either way."""
     bns = [bn for _, _, bn in layers]
     params = []
     for w, b, bn in layers:
         params += [w.reshape(w.shape[0], w.shape[1]), b, None if bn is None else bn.weight, None if bn is None else bn.bias]
-    return _RowStack.apply(x, bns, *params)
+    return _RowStack.apply(x, bns, bool(keep_pad), *params)
 
 
 class _FPRows(Function):

@@ -351,6 +351,37 @@ int vlp3d_fp_rows(const float *known, const float *unknown, const int *idx, cons
 int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *weight, int B, int n, int m, int C1, int ld,
                        float *d_known, void *stream);
 
+/* ---- fused glue between the matrix-core kernels (csrc/glue.hip) ---------------------------------------------
+ * roi_split: out (R x ld) = [heading_reg NH | heading_cls NH | box 6 | objectness 2 | sem NC] of the merged ROI
+ *   predictors (roi_heads.py:135-147) -> contiguous heading_residuals_normalized, heading_residuals (x res_scale),
+ *   heading_scores, rois = exp(box), objectness_scores, sem_cls_scores, objectness arg-max and sem arg-max (int64).
+ *   roi_split_bwd gathers the six gradient pieces (NULL = zero) into d(out), zeroing the unused columns.
+ * vote_epilogue: vote_xyz = seed_xyz + net[:, 0:3], vote_features = normalise(seed_f + net[:, 3:3+C]) (voting_module.py:
+ *   51-58 with vote_factor 1, jointnet.py:148-149); norm (R) is kept for the backward, which writes d(seed_f) and
+ *   d(net) (R x ld, fully).
+ * l2norm_rows(_bwd): F.normalize(x, dim=-1, eps) on (R x C) rows and its backward.
+ * relation_inputs: relation_module.py:95-122 — obj_feat (B,K,128) rows of the point cloud's multiview block with the
+ *   reference's indexing, manual_bbox_feat (B,K,27) = [box centre | corners - centre], centre (B,K,3) = corner mean.
+ * copy_paste_map: match_module.py:97-121 as an index map src (B*K) i32 (identity when coin >= 0.5); gather_rows /
+ *   scatter_rows_add: out[i] = x[src[i]] and its adjoint (dx zeroed by the caller).  B*K <= 8192. */
+int vlp3d_roi_split(const float *out, int ld, long long R, int NH, int NC, float res_scale, float *hreg, float *hres,
+                    float *hcls, float *rois, float *obj, float *sem, long long *obj_mask, long long *sem_arg, void *stream);
+int vlp3d_roi_split_bwd(const float *d_hreg, const float *d_hres, const float *d_hcls, const float *d_rois, const float *d_obj,
+                        const float *d_sem, const float *rois, long long R, int NH, int NC, float res_scale, float *d_out,
+                        int ld, void *stream);
+int vlp3d_vote_epilogue(const float *seed_xyz, const float *seed_f, const float *net, int ld, long long R, int C,
+                        float *vote_xyz, float *vote_f, float *norm, void *stream);
+int vlp3d_vote_epilogue_bwd(const float *d_vote_xyz, const float *d_vote_f, const float *vote_f, const float *norm, long long R,
+                            int C, float *d_seed_f, float *d_net, int ld, void *stream);
+int vlp3d_l2norm_rows(const float *x, long long R, int C, float eps, float *y, float *norm, void *stream);
+int vlp3d_l2norm_rows_bwd(const float *g, const float *y, const float *norm, long long R, int C, float eps, float *dx,
+                          void *stream);
+int vlp3d_relation_inputs(const float *pc, int Cpc, int N, const int *seed_inds, int S, const int *vote_inds,
+                          const float *corners, int B, int K, float *obj_feat, float *bbox_feat, float *centre, void *stream);
+int vlp3d_copy_paste_map(const long long *obj_mask, int B, int K, const float *coin, int *src, void *stream);
+int vlp3d_gather_rows(const float *x, const int *src, long long R, int D, float *out, void *stream);
+int vlp3d_scatter_rows_add(const float *g, const int *src, long long R, int D, float *dx, void *stream);
+
 /* ---- hardware-denominator probes (csrc/hwprobe.hip; measurement only) --------------------
  * vlp3d_probe_read: streaming 16-byte-load read of `bytes` (multiple of 16, >= 16 KiB) with `blocks` workgroups;
  * vlp3d_probe_mfma_bf16: blocks*4 waves each issue iters*4 independent v_mfma_f32_32x32x16_bf16

@@ -721,3 +721,74 @@ def test_voting_and_roi_heads_rows_equal_fp64_formula(kind, training):
                                        rtol=1e-4, atol=1e-6)
             torch.testing.assert_close(now[nm + ".running_var"].double(),
                                        (1 - mom) * buf0[nm + ".running_var"].double() + mom * y.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
+
+
+def test_glue_kernels_equal_torch_ops():
+    """csrc/glue.hip vs the op sequences they replace: ROI split (+exp, scale, arg-max), vote epilogue (+L2 norm), row
+    L2 normalisation, copy-paste augmentation — values and gradients."""
+    glue = importlib.import_module("3dvlp_amd.glue")
+    grd = importlib.import_module("3dvlp_amd.grounding")
+    torch.manual_seed(12)
+    dev = "cuda"
+    # --- roi_split
+    B, K, NH, NC, ld = 4, 256, 1, 18, 64
+    out0 = torch.randn(B, K, ld, device=dev)
+    ws = [torch.randn(B, K, n, device=dev) for n in (NH, NH, NH, 6, 2, NC)]
+    a = out0.clone().requires_grad_(True)
+    got = glue.roi_split(a, NH, NC)
+    sum((g * w).sum() for g, w in zip(got[:6], ws)).backward()
+    b = out0.clone().requires_grad_(True)
+    parts = torch.split(b[..., :2 * NH + 8 + NC], [NH, NH, 6, 2, NC], dim=-1)
+    exp = [parts[0], parts[0] * (np.pi / NH), parts[1], parts[2].exp(), parts[3], parts[4]]
+    sum((g * w).sum() for g, w in zip(exp, ws)).backward()
+    for x, y in zip(got[:6], exp):
+        torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got[6], exp[4].argmax(-1)) and torch.equal(got[7], exp[5].argmax(-1))
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-6, atol=1e-6)
+    # --- vote epilogue
+    S, C, ldn = 1024, 256, 320
+    sx, sf = torch.rand(B, S, 3, device=dev), torch.randn(B, S, C, device=dev)
+    net0 = torch.randn(B * S, ldn, device=dev)
+    w1, w2 = torch.randn(B, S, 3, device=dev), torch.randn(B, S, C, device=dev)
+    res = []
+    for fused in (True, False):
+        f = sf.clone().requires_grad_(True)
+        n = net0.clone().requires_grad_(True)
+        if fused:
+            vx, vf = glue.vote_epilogue(sx, f, n)
+        else:
+            net = n[:, :3 + C].view(B, S, 3 + C)
+            vx = sx + net[..., :3]
+            v = f + net[..., 3:]
+            vf = v / torch.norm(v, p=2, dim=-1, keepdim=True)
+        ((vx * w1).sum() + (vf * w2).sum()).backward()
+        res.append((vx.detach(), vf.detach(), f.grad, n.grad))
+    for x, y in zip(*res):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+    # --- l2norm rows
+    x0 = torch.randn(2112, 128, device=dev)
+    x0[5] = 0
+    g = torch.randn_like(x0)
+    x1, x2 = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    y1 = glue.l2norm_rows(x1)
+    y2 = torch.nn.functional.normalize(x2, dim=-1)
+    (y1 * g).sum().backward(); (y2 * g).sum().backward()
+    torch.testing.assert_close(y1, y2, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(x1.grad[6:], x2.grad[6:], rtol=1e-5, atol=1e-6)
+    assert torch.isfinite(x1.grad).all()
+    # --- copy-paste (random objectness patterns, both coin sides, degenerate: no objects / all objects)
+    for trial in range(12):
+        Bc, Kc, D = 8, 256, 128
+        feats = torch.randn(Bc, Kc, D, device=dev)
+        p = [0.0, 1.0, 0.1, 0.5][trial % 4] if trial < 8 else torch.rand(()).item()
+        mask = (torch.rand(Bc, Kc, device=dev) < p).long()
+        for coin in (0.2, 0.8):
+            c = torch.tensor(coin, device=dev)
+            fa = feats.clone().requires_grad_(True)
+            oa = glue.copy_paste(fa, mask, c)
+            fb = feats.clone().requires_grad_(True)
+            ob = torch.where(c < 0.5, grd.MatchModule._copy_paste(fb, mask.float().unsqueeze(2)), fb)
+            assert torch.equal(oa, ob), (trial, coin)
+            w = torch.randn_like(oa)
+            (oa * w).sum().backward(); (ob * w).sum().backward()
+            torch.testing.assert_close(fa.grad, fb.grad, rtol=1e-5, atol=1e-5)
