@@ -82,6 +82,7 @@ SIGNATURES = {
     "vlp3d_copy_paste_map": [_vp, _i, _i, _vp, _vp, _vp],
     "vlp3d_gather_rows": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_scatter_rows_add": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
+    "vlp3d_adamw_flat": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _f, _f, _f, _f, _f, _f, _vp],
     "vlp3d_probe_read": [_vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],

@@ -338,3 +338,36 @@ extern "C" int vlp3d_scatter_rows_add(const float *g, const int *src, long long 
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
+
+// ---- AdamW on ONE flat parameter / gradient buffer ---------------------------------------------------------------------
+// torch.optim.AdamW's update (decoupled weight decay, bias correction) for every element whose parameter took part in the
+// step (active[seg[i]] != 0; parameters without gradient are skipped like torch skips grad-None parameters):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / c1) * m / (sqrt(v) / sqrt(c2) + eps)
+// with c1 = 1 - b1^t, c2 = 1 - b2^t computed on the host.  One launch instead of the multi-tensor optimiser's six.
+namespace {
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, const unsigned char *__restrict__ active,
+                                                         long long n, float lr, float b1, float b2, float eps, float wd,
+                                                         float c1, float sqrt_c2) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !active[i]) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  pi -= (lr / c1) * (mi / (sqrtf(vi) / sqrt_c2 + eps));
+  p[i] = pi;
+}
+}  // namespace
+
+extern "C" int vlp3d_adamw_flat(float *p, const float *g, float *m, float *v, const unsigned char *active, long long n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, float bias_c1, float sqrt_bias_c2,
+                                void *stream) {
+  if (!p || !g || !m || !v || !active || n < 1) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, active,
+                     n, lr, beta1, beta2, eps, weight_decay, bias_c1, sqrt_bias_c2);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

@@ -3,12 +3,110 @@
 The reference only has single-process nn.DataParallel (scripts/joint_scripts/train_3dvlp.py:124-126).
 Here every rank runs its own shard of scenes; gradients live as views into a single pre-zeroed flat
 fp32 buffer (so parameters that receive no gradient in a step — many do, SURVEY.md §5 — contribute
-zeros without any bookkeeping) and are summed with one RCCL all-reduce over xGMI (≈6 M elements =
-24 MB: latency-bound, so one bucket instead of many).  BatchNorm statistics stay per rank, exactly
+zeros without any bookkeeping) and are summed with one RCCL all-reduce over xGMI (~1.8 M elements =
+7 MB: latency-bound, so one bucket instead of many).  BatchNorm statistics stay per rank, exactly
 like the reference's DataParallel replicas.
+
+`FlatParams` additionally moves the PARAMETERS themselves into one flat buffer (same element order as the gradient
+buffer): projections that are evaluated as one merged product (q|k|v, k|v, the five ROI predictors) then read their
+concatenated weight as a VIEW (`merge_adjacent`, no torch.cat per step), and AdamW is one launch over the flat buffers
+(`FlatAdamW`, csrc/glue.hip) instead of the multi-tensor optimiser's six.
 """
+import math
+
 import torch
 import torch.distributed as dist
+from torch.autograd import Function
+
+
+def adjacency_groups(module):
+    """Parameter groups that should sit back to back in the flat buffer (each group in concatenation order)."""
+    groups = []
+    for m in module.modules():
+        name = type(m).__name__
+        if name == "ScaledDotProductAttention":
+            groups.append([m.fc_q.weight, m.fc_k.weight, m.fc_v.weight])
+            groups.append([m.fc_q.bias, m.fc_k.bias, m.fc_v.bias])
+        elif name == "StandardROIHeads":
+            heads = [m.heading_reg_predictor, m.heading_cls_predictor, m.box_predictor, m.objectness_predictor]
+            if m.num_class:
+                heads.append(m.sem_cls_predictor)
+            groups.append([h.weight for h in heads])
+            groups.append([h.bias for h in heads])
+    return groups
+
+
+def ordered_parameters(module):
+    """module.parameters() (trainable ones) reordered so that every adjacency group is contiguous."""
+    placed, out = set(), []
+    group_of = {}
+    for g in adjacency_groups(module):
+        for p in g:
+            group_of[id(p)] = g
+    for p in module.parameters():
+        if not p.requires_grad or id(p) in placed:
+            continue
+        for q in group_of.get(id(p), [p]):
+            if id(q) not in placed:
+                placed.add(id(q))
+                out.append(q)
+    return out
+
+
+class FlatParams:
+    """Re-homes the parameters of `module` (already on its device) in one flat fp32 buffer, in `ordered_parameters`
+    order; every group start is 16-byte aligned, members of an adjacency group are packed without gaps.  The
+    parameters keep their names, shapes and values (state_dict / load_state_dict work as before)."""
+
+    def __init__(self, module):
+        self.params = ordered_parameters(module)
+        starts = {id(g[0]) for g in adjacency_groups(module)}
+        members = {id(p) for g in adjacency_groups(module) for p in g}
+        offs, off = [], 0
+        for p in self.params:
+            if id(p) in starts or id(p) not in members:
+                off = (off + 3) // 4 * 4
+            offs.append(off)
+            off += p.numel()
+        self.numel = (off + 3) // 4 * 4
+        ref = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
+        self.offsets = offs
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+
+
+class _MergeAdjacent(Function):
+    """cat(tensors, 0) of tensors that ARE back to back in memory: a view forward, views of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ctx.rows = [t.shape[0] for t in ts]
+        first = ts[0]
+        shape = (sum(ctx.rows),) + tuple(first.shape[1:])
+        return first.as_strided(shape, first.stride(), first.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(torch.split(g, ctx.rows, dim=0))
+
+
+def merge_adjacent(tensors):
+    """torch.cat(tensors, 0) without a copy when the tensors are contiguous and adjacent in one storage (FlatParams
+    arranges that for the merged projections); plain torch.cat otherwise."""
+    ok = all(t.is_contiguous() and t.dtype == tensors[0].dtype for t in tensors)
+    if ok:
+        st = tensors[0].untyped_storage().data_ptr()
+        off = tensors[0].storage_offset()
+        for t in tensors:
+            if t.untyped_storage().data_ptr() != st or t.storage_offset() != off or t.shape[1:] != tensors[0].shape[1:]:
+                ok = False
+                break
+            off += t.numel()
+    return _MergeAdjacent.apply(*tensors) if ok else torch.cat(tensors, 0)
 
 
 class FlatGradBucket:
@@ -16,20 +114,26 @@ class FlatGradBucket:
 
     Autograd adds into an existing .grad with one small kernel per parameter (~300 launches per step here), so
     the gradients are left undefined during backward (autograd then just keeps the produced tensors) and are
-    gathered afterwards with one multi-tensor copy.  Parameters that received no gradient keep zeros."""
+    gathered afterwards with one multi-tensor copy.  Parameters that received no gradient keep zeros.
+    `layout`: a FlatParams whose element order the buffer follows (then flat gradient i belongs to flat parameter i)."""
 
-    def __init__(self, module, process_group=None):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, process_group=None, layout=None):
         self.group = process_group
-        n = sum(p.numel() for p in self.params)
+        if layout is not None:
+            self.params, offs, n = layout.params, layout.offsets, layout.numel
+        else:
+            self.params = [p for p in module.parameters() if p.requires_grad]
+            offs, n = [], 0
+            for p in self.params:
+                offs.append(n)
+                n += p.numel()
+        self.offsets = offs
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-            p.grad = self.views[-1]
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offs)]
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        self.touched = [True] * len(self.params)
 
     def zero(self):
         """Call before backward: zero the flat buffer and detach the .grad views from the parameters."""
@@ -62,6 +166,39 @@ class FlatGradBucket:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
+
+
+class FlatAdamW:
+    """torch.optim.AdamW over (FlatParams, FlatGradBucket with the same layout) in one launch (csrc/glue.hip)."""
+
+    def __init__(self, layout, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        assert bucket.flat.numel() == layout.flat.numel()
+        self.layout, self.bucket = layout, bucket
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(layout.flat)
+        self.v = torch.zeros_like(layout.flat)
+        self.active = torch.zeros(layout.numel, dtype=torch.uint8, device=layout.flat.device)
+        self._active_key = None
+        self.t = 0
+
+    def _set_active(self):
+        key = tuple(self.bucket.touched)
+        if key != self._active_key:  # changes only when the step's graph changes (e.g. the contrast losses switch on)
+            a = torch.zeros(self.layout.numel, dtype=torch.uint8)
+            for p, o, got in zip(self.layout.params, self.layout.offsets, self.bucket.touched):
+                if got:
+                    a[o:o + p.numel()] = 1
+            self.active.copy_(a)
+            self._active_key = key
+
+    def step(self):
+        from . import _lib as _ext
+        self._set_active()
+        self.t += 1
+        b1, b2 = self.betas
+        _ext.call("vlp3d_adamw_flat", self.layout.flat, self.bucket.flat, self.m, self.v, self.active, self.layout.numel,
+                  float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay), 1.0 - b1 ** self.t,
+                  math.sqrt(1.0 - b2 ** self.t))
 
 
 def broadcast_parameters(module, src=0, process_group=None):

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from . import glue, row_mlp
+from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
@@ -181,7 +182,7 @@ class StandardROIHeads(nn.Module):
             X = ROI_features.float().transpose(1, 2).contiguous().view(B * K, C)  # free for a point-major producer
             layers = [(self.convs[0].weight, self.convs[0].bias, self.convs[1]),
                       (self.convs[3].weight, self.convs[3].bias, self.convs[4]),
-                      (torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0), None)]
+                      (merge_adjacent([h.weight for h in heads]), merge_adjacent([h.bias for h in heads]), None)]
             if row_mlp.supported(X, layers):
                 out = row_mlp.row_stack(X, layers, keep_pad=True)              # (R, 64): the 28 predictor channels + 0
                 (heading_reg, hres, hcls, rois, obj, sem, omask, sarg) = glue.roi_split(

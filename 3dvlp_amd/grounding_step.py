@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import _lib as _ext
 from . import add_norm, losses, synth
-from .ddp import FlatGradBucket
+from .ddp import FlatAdamW, FlatGradBucket, FlatParams
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
 from .grounding import ContrastModule, MatchModule
 
@@ -135,10 +135,16 @@ class GroundingStep:
         self.device = device
         self.model = GroundingNet().to(device)
         self.model.train()
-        self.bucket = FlatGradBucket(self.model)
-        # fused: the whole AdamW update is a couple of multi-tensor launches instead of ~30 (one per foreach op and chunk)
-        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5,
-                                     fused=torch.device(device).type == "cuda")
+        if torch.device(device).type == "cuda":
+            # parameters, gradients and AdamW moments as three flat buffers with one layout: merged projections read their
+            # concatenated weights as views, the optimiser is one launch (ddp.FlatParams / FlatAdamW)
+            self.layout = FlatParams(self.model)
+            self.bucket = FlatGradBucket(self.model, layout=self.layout)
+            self.opt = FlatAdamW(self.layout, self.bucket, lr=lr, weight_decay=1e-5)
+        else:
+            self.layout = None
+            self.bucket = FlatGradBucket(self.model)
+            self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
         # bf16 for the grouped-MLP kernels only (the dense work that matters); everything else stays fp32, which

@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from . import add_norm, fused_attention
+from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 
 DEFAULT_IMPL = "hip"
@@ -51,13 +52,13 @@ class ScaledDotProductAttention(nn.Module):
             # take the column blocks as row-strided views and return one merged gradient
             aw = None if attention_weights is None else attention_weights.float()
             if queries is keys:
-                qkv = _linear(queries, torch.cat([self.fc_q.weight, self.fc_k.weight, self.fc_v.weight], 0),
-                              torch.cat([self.fc_q.bias, self.fc_k.bias, self.fc_v.bias], 0))
+                qkv = _linear(queries, merge_adjacent([self.fc_q.weight, self.fc_k.weight, self.fc_v.weight]),
+                              merge_adjacent([self.fc_q.bias, self.fc_k.bias, self.fc_v.bias]))
                 out = fused_attention.sdpa_merged(qkv, None, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
             else:
                 q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
-                kv = _linear(keys, torch.cat([self.fc_k.weight, self.fc_v.weight], 0),
-                             torch.cat([self.fc_k.bias, self.fc_v.bias], 0))
+                kv = _linear(keys, merge_adjacent([self.fc_k.weight, self.fc_v.weight]),
+                             merge_adjacent([self.fc_k.bias, self.fc_v.bias]))
                 out = fused_attention.sdpa_merged(q, kv, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
             return _linear(out, self.fc_o.weight, self.fc_o.bias), None
         q = _linear(queries, self.fc_q.weight, self.fc_q.bias)

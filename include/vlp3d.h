@@ -382,6 +382,12 @@ int vlp3d_copy_paste_map(const long long *obj_mask, int B, int K, const float *c
 int vlp3d_gather_rows(const float *x, const int *src, long long R, int D, float *out, void *stream);
 int vlp3d_scatter_rows_add(const float *g, const int *src, long long R, int D, float *dx, void *stream);
 
+/* AdamW (torch.optim.AdamW semantics) over one flat fp32 parameter / gradient / moment buffer; active (n) u8: 0 = the
+ * element's parameter received no gradient this step and is left untouched.  bias_c1 = 1 - beta1^t, sqrt_bias_c2 =
+ * sqrt(1 - beta2^t) for step t (host-computed). */
+int vlp3d_adamw_flat(float *p, const float *g, float *m, float *v, const unsigned char *active, long long n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float bias_c1, float sqrt_bias_c2, void *stream);
+
 /* ---- hardware-denominator probes (csrc/hwprobe.hip; measurement only) --------------------
  * vlp3d_probe_read: streaming 16-byte-load read of `bytes` (multiple of 16, >= 16 KiB) with `blocks` workgroups;
  * vlp3d_probe_mfma_bf16: blocks*4 waves each issue iters*4 independent v_mfma_f32_32x32x16_bf16

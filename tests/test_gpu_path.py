@@ -796,3 +796,37 @@ def test_glue_kernels_equal_torch_ops():
             w = torch.randn_like(oa)
             (oa * w).sum().backward(); (ob * w).sum().backward()
             torch.testing.assert_close(fa.grad, fb.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_flat_params_merge_views_and_flat_adamw_equal_torch():
+    """ddp.FlatParams / merge_adjacent / FlatAdamW: the merged q|k|v weight is a VIEW of the flat parameter buffer (no
+    copy), its gradient splits back into the three parameters, and three flat AdamW steps equal torch.optim.AdamW
+    (including 'no gradient -> untouched, no weight decay')."""
+    import copy
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    tr = importlib.import_module("3dvlp_amd.transformer")
+    torch.manual_seed(2)
+    net = torch.nn.ModuleDict({"att": tr.MultiHeadAttention(128, 32, 32, 4), "unused": torch.nn.Linear(8, 8)}).cuda()
+    ref = copy.deepcopy(net)
+    layout = ddp.FlatParams(net)
+    bucket = ddp.FlatGradBucket(net, layout=layout)
+    opt = ddp.FlatAdamW(layout, bucket, lr=1e-2, weight_decay=0.1)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.1)
+    a = net["att"].attention
+    w = ddp.merge_adjacent([a.fc_q.weight, a.fc_k.weight, a.fc_v.weight])
+    assert w.data_ptr() == a.fc_q.weight.data_ptr() and w.shape == (384, 128)       # a view, not a copy
+    assert torch.equal(w.detach(), torch.cat([a.fc_q.weight, a.fc_k.weight, a.fc_v.weight]).detach())
+    for n_, p in net.named_parameters():                                              # values survived the re-homing
+        assert torch.equal(p.detach(), dict(ref.named_parameters())[n_].detach()), n_
+    x = torch.randn(4, 256, 128, device="cuda")
+    for step in range(3):
+        bucket.zero()
+        net["att"](x, x, x).pow(2).mean().backward()
+        bucket.collect()
+        opt.step()
+        ropt.zero_grad(set_to_none=True)
+        ref["att"](x, x, x).pow(2).mean().backward()
+        ropt.step()
+    for (n_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p, q, rtol=2e-4, atol=2e-6, msg=n_)
+    assert net["unused"].weight.grad is None and torch.equal(net["unused"].weight, ref["unused"].weight)
