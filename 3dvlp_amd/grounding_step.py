@@ -168,6 +168,7 @@ class GroundingStep:
         self._graph = None
         self._static_batch = self._static_next = None
         self._static_loss = None
+        self._last_out = self._static_out = None
 
     def forward_loss(self, batch, geometry=None):
         d = dict(batch)
@@ -223,7 +224,10 @@ class GroundingStep:
             self._geom_tag = self._tag(nxt_batch)
             geometry = self._geom_cur
         self.bucket.zero()
-        loss, _ = self.forward_loss(batch, geometry)
+        # the step's data_dict stays referenced (self._last_out; _static_out for a captured step): its tensors are the
+        # replayed graph's outputs (losses, predictions, labels), and without the reference the caching allocator handed
+        # the block of the captured loss scalar out again — the second replay returned garbage for it
+        loss, self._last_out = self.forward_loss(batch, geometry)
         loss.backward()
         self.bucket.collect()
         add_norm.advance(self.device)  # fresh dropout masks next step (also when this is a captured graph)
@@ -256,6 +260,7 @@ class GroundingStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._static_loss = self._fwd_bwd(self._static_batch, self._static_next)
+            self._static_out = self._last_out
         else:
             # Pipelined: THREE single-stream graphs instead of one graph with a forked branch.  ROCm launches a
             # linear graph in ~0.3 ms of host time but walks a multi-stream graph node by node (16 ms for the 1300
@@ -271,7 +276,7 @@ class GroundingStep:
                 self._copy_geometry(self._geom_next, nxt)
             with torch.cuda.graph(self._gM):
                 self.bucket.zero()
-                loss, _ = self.forward_loss(self._static_batch, self._geom_cur)
+                loss, self._static_out = self.forward_loss(self._static_batch, self._geom_cur)
                 loss.backward()
                 self.bucket.collect()
                 add_norm.advance(self.device)
