@@ -26,6 +26,8 @@ SIGNATURES = {
     "vlp3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "vlp3d_ball_query_grid_workspace_bytes": [_i, _i],
+    "vlp3d_ball_query_grid": [_vp, _vp, _i, _i, _i, _f, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "vlp3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_group_points_grad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
@@ -201,16 +203,28 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+BALL_QUERY_GRID_MIN_N = 8192  # below this the all-pairs kernel (one pass over an L2-resident scene) wins
+
+
+def ball_query(new_xyz, xyz, radius, nsample, algorithm=None):
+    """algorithm: None = pick by N, "scan" (csrc/ball_query.hip) or "grid" (csrc/ball_query_grid.hip) — identical output."""
     _chk_float(new_xyz, "new_xyz")
     _chk_float(xyz, "xyz")
     _chk_dev(new_xyz, ("xyz", xyz))
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    if algorithm is None:
+        algorithm = "grid" if N >= BALL_QUERY_GRID_MIN_N else "scan"
     with torch.cuda.device(xyz.device):
-        _check(load().vlp3d_ball_query(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(idx),
-                                       _stream()), "ball_query")
+        if algorithm == "grid":
+            nbytes = int(load().vlp3d_ball_query_grid_workspace_bytes(B, N))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+            _check(load().vlp3d_ball_query_grid(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(ws), nbytes,
+                                                _p(idx), _stream()), "ball_query_grid")
+        else:
+            _check(load().vlp3d_ball_query(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(idx),
+                                           _stream()), "ball_query")
     return idx
 
 

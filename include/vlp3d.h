@@ -68,6 +68,14 @@ int vlp3d_gather_points_grad(const float *grad_out, const int *idx, int B, int C
 int vlp3d_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M, float radius, int nsample,
                      int *idx, void *stream);
 
+/* Same output as vlp3d_ball_query, bit for bit, through a uniform grid (csrc/ball_query_grid.hip): cell edge >= radius,
+ * only the 27 cells around a centre are tested, the hits are ranked by index and the nsample smallest written in
+ * ascending order with the reference's padding.  workspace: vlp3d_ball_query_grid_workspace_bytes(B,N) bytes, 16-byte
+ * aligned; five kernels + one memset on `stream`. */
+long long vlp3d_ball_query_grid_workspace_bytes(int B, int N);
+int vlp3d_ball_query_grid(const float *new_xyz, const float *xyz, int B, int N, int M, float radius, int nsample,
+                          void *workspace, long long workspace_bytes, int *idx, void *stream);
+
 /* replaces group_points — group_points.cpp:17-40. points (B,C,N), idx (B,M,S) -> out (B,C,M,S). */
 int vlp3d_group_points(const float *points, const int *idx, int B, int C, int N, int M, int S, float *out,
                        void *stream);

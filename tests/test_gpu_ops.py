@@ -296,3 +296,34 @@ def test_sa1_geometry_on_scene_with_skip_points(pu, ext):
     d2, i3 = ext.three_nn(dev(new_xyz[:, :1024]), dev(new_xyz[:, :512].copy()))
     r2, ri = orc.three_nn(new_xyz[:, :1024], new_xyz[:, :512].copy())
     assert (i3.cpu().numpy() == ri).all() and (d2.cpu().numpy() == r2).all()
+
+
+@pytest.mark.parametrize("kind,B,N,M,r,ns", [("scene", 2, 40000, 2048, 0.2, 64), ("scene", 1, 9000, 512, 0.4, 32),
+                                            ("cluster", 2, 20000, 256, 0.3, 16), ("dense", 1, 12000, 64, 0.5, 64),
+                                            ("outside", 2, 10000, 128, 0.25, 8), ("empty", 1, 8192, 64, 0.01, 16)])
+def test_ball_query_grid_equals_scan_and_oracle(ext, kind, B, N, M, r, ns):
+    """The grid kernel returns the all-pairs kernel's rows bit for bit: ascending first-nsample order, first-hit padding,
+    all-zero rows for empty balls — on scenes, on clusters denser than the hit list (fallback path), with more than
+    nsample hits per ball (rank selection), with centres outside the points' bounding box and with empty balls."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    rng = np.random.default_rng(N + M)
+    if kind == "scene":
+        xyz = np.stack([synth.make_scene(5000 + i, N)["xyz"] for i in range(B)])
+        new_xyz = xyz[:, rng.permutation(N)[:M]].copy()
+    elif kind == "cluster":   # most points inside a few tiny blobs: thousands of hits per ball
+        cen = rng.uniform(0, 4, (B, 4, 3))
+        xyz = (cen[:, rng.integers(0, 4, N)] + rng.normal(0, 0.05, (B, N, 3))).astype(np.float32)
+        new_xyz = xyz[:, :M].copy()
+    elif kind == "dense":
+        xyz = rng.uniform(0, 1.5, (B, N, 3)).astype(np.float32)
+        new_xyz = xyz[:, :M].copy()
+    elif kind == "outside":
+        xyz = rng.uniform(0, 3, (B, N, 3)).astype(np.float32)
+        new_xyz = rng.uniform(-1, 4, (B, M, 3)).astype(np.float32)
+    else:
+        xyz = rng.uniform(0, 5, (B, N, 3)).astype(np.float32)
+        new_xyz = (xyz[:, :M] + 0.5).astype(np.float32)
+    a = ext.ball_query(dev(new_xyz), dev(xyz), r, ns, "grid").cpu().numpy()
+    b = ext.ball_query(dev(new_xyz), dev(xyz), r, ns, "scan").cpu().numpy()
+    assert (a == b).all()
+    assert (a == orc.ball_query(new_xyz, xyz, r, ns)).all()
