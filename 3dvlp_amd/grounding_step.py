@@ -75,16 +75,16 @@ def grounding_loss(d, config, args=None, impl=None):
     return d["loss"]
 
 
-def batch_to_device(batch, device, mean_size_arr=None):
-    """Host batch (numpy, the reference's keys and dtypes) -> device tensors, plus the KERNEL-READY forms of pure input
-    data that the step would otherwise re-derive with a dozen small launches every iteration (this is loader work: it
-    depends on the batch only, never on the model):
+def prepare_batch(out, mean_size_arr=None):
+    """Device batch (the reference's keys and dtypes) -> the same dict plus the KERNEL-READY forms of pure input data
+    that the step would otherwise re-derive with a dozen small launches every iteration (loader work: it depends on the
+    batch only, never on the model; input_pipeline.Prefetcher runs it on the copy stream):
       k/vote_label_mask f32, k/{heading_class,size_class,sem_cls}_label i32, k/lang_num i32 — dtypes the loss kernel
       reads (lib/joint/dataset.py hands them over as int64);  k/ref_size — decoded size of the referred boxes
       (class2size, model_util_scannet.py:183-185; consumed by the DIoU loss and the contrast module);
       k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134)."""
-    out = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
-    out["istrain"] = [1]
+    device = out["point_clouds"].device
+    out.setdefault("istrain", [1])
     mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32,
                            device=device)
     out["k/vote_label_mask"] = out["vote_label_mask"].float()
@@ -94,6 +94,11 @@ def batch_to_device(batch, device, mean_size_arr=None):
     out["k/ref_size"] = (mean[out["ref_size_class_label_list"]] + out["ref_size_residual_label_list"]).float().contiguous()
     out["k/lang_kv"] = out["lang_fea"][:, 1:].contiguous()
     return out
+
+
+def batch_to_device(batch, device, mean_size_arr=None):
+    """Host batch (numpy) -> device tensors + prepare_batch (synchronous form; see input_pipeline.Prefetcher)."""
+    return prepare_batch({k: torch.from_numpy(v).to(device) for k, v in batch.items()}, mean_size_arr)
 
 
 class _deferred_bn_counters:

@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline section (profiling runs)")
     ap.add_argument("--check-replicas", action="store_true",
                     help="after the timed steps, gather a checksum of every rank's parameters into the JSON line")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="feed every step a batch that starts in (pinned) HOST memory through input_pipeline.Prefetcher: the "
+                         "PCIe-inclusive rate (never the headline `value`; reported in DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute the backbone geometry (FPS / ball query) inline instead of one batch ahead")
@@ -250,14 +253,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    feed = None
+    if args.host_batches:
+        # three distinct batches in pinned host memory (what DataLoader(pin_memory=True) hands over), cycled; two batches
+        # are on the device at any time (current + next, whose geometry the side stream prepares), a third is in flight
+        ip = importlib.import_module("3dvlp_amd.input_pipeline")
+        host = []
+        for j in range(3):
+            hb = synth.make_batch(first + 8 * j * world, B_PER_GPU, NUM_POINTS, LANG_NUM)
+            host.append({k: torch.from_numpy(v).pin_memory() for k, v in hb.items()})
+
+        def endless():
+            i = 0
+            while True:
+                yield host[i % 3]
+                i += 1
+        feed = ip.Prefetcher(endless(), device=device, prepare=gs.prepare_batch)
+
+    def one_step():
+        nonlocal cur_b, nxt_b
+        if feed is None:
+            return step.run(batch)
+        loss_ = step.run(cur_b, nxt_b)
+        cur_b, nxt_b = nxt_b, feed.next()
+        return loss_
+
+    cur_b = nxt_b = None
+    if feed is not None:
+        cur_b, nxt_b = feed.next(), feed.next()
     for _ in range(args.warmup):
-        step.run(batch)
+        one_step()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
-        loss = step.run(batch)
+        loss = one_step()
     marks[args.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
@@ -303,6 +334,8 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
                        "geometry": "inline" if args.no_pipeline else
                        "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)",
+                       "input": ("every step's batch starts in pinned host memory (PCIe-inclusive; 3 batches cycled, "
+                                 "input_pipeline.Prefetcher)" if args.host_batches else "resident in HBM before the timed region"),
                        "loss": float(loss.detach())},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
                         "how": "events on the launch stream between consecutive steps (this rank)"},
