@@ -215,7 +215,7 @@ def ball_query(new_xyz, xyz, radius, nsample, algorithm=None):
     M = new_xyz.shape[1]
     idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
     if algorithm is None:
-        algorithm = "grid" if N >= BALL_QUERY_GRID_MIN_N else "scan"
+        algorithm = os.environ.get("VLP3D_BALL_QUERY") or ("grid" if N >= BALL_QUERY_GRID_MIN_N else "scan")
     with torch.cuda.device(xyz.device):
         if algorithm == "grid":
             nbytes = int(load().vlp3d_ball_query_grid_workspace_bytes(B, N))

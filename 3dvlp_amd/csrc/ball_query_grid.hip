@@ -37,10 +37,16 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv, int n) {
 
 constexpr int BBOX_PARTS = 32;  // workgroups per scene of the bounding-box pass
 
-// partial[b][part][6] = min xyz, max xyz of this workgroup's slice of scene b
-__global__ __launch_bounds__(256) void bq_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ partial) {
+// partial[b][part][6] = min xyz, max xyz of this workgroup's slice of scene b.  The same workgroups clear the scene's cell
+// counters (MAX_CELLS / BBOX_PARTS = 4096 each) — in-stream, not a hipMemsetAsync (common.h: vlp3d_zero_words explains why).
+__global__ __launch_bounds__(256) void bq_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ partial,
+                                                      int *__restrict__ count) {
   __shared__ float red[6][4];
   const int b = blockIdx.y, part = blockIdx.x;
+  static_assert(MAX_CELLS % (BBOX_PARTS * 1024) == 0, "counter slice of a workgroup: whole int4 rounds");
+  int4 *cz = reinterpret_cast<int4 *>(count + (size_t)b * MAX_CELLS + (size_t)part * (MAX_CELLS / BBOX_PARTS));
+#pragma unroll
+  for (int j = 0; j < MAX_CELLS / BBOX_PARTS / 1024; ++j) cz[j * 256 + threadIdx.x] = make_int4(0, 0, 0, 0);
   const float *p = xyz + (size_t)b * N * 3;
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   for (int i = part * 256 + threadIdx.x; i < N; i += BBOX_PARTS * 256)
@@ -342,10 +348,8 @@ extern "C" int vlp3d_ball_query_grid(const float *new_xyz, const float *xyz, int
   int *cursor = (int *)w;
   w += (long long)B * MAX_CELLS * 4;
   float4 *sorted = (float4 *)w;
-  hipError_t e = hipMemsetAsync(count, 0, (size_t)B * MAX_CELLS * 4, s);
-  if (e != hipSuccess) return (int)e;
   const unsigned pblocks = (unsigned)(((long long)B * N + 255) / 256);
-  hipLaunchKernelGGL(bq_bbox_kernel, dim3(BBOX_PARTS, B), dim3(256), 0, s, xyz, N, partial);
+  hipLaunchKernelGGL(bq_bbox_kernel, dim3(BBOX_PARTS, B), dim3(256), 0, s, xyz, N, partial, count);
   hipLaunchKernelGGL(bq_header_kernel, dim3(B), dim3(64), 0, s, partial, radius, hdr);
   hipLaunchKernelGGL(bq_count_kernel, dim3(pblocks), dim3(256), 0, s, xyz, B, N, hdr, cell_of, count);
   hipLaunchKernelGGL(bq_scan_kernel, dim3(B), dim3(1024), 0, s, hdr, count, start, cursor);

@@ -54,3 +54,27 @@ __host__ __device__ __forceinline__ int vlp3d_cdiv(int a, int b) { return (a + b
     hipError_t e__ = hipGetLastError();              \
     if (e__ != hipSuccess) return (int)e__;          \
   } while (0)
+
+// Clear n 32-bit words from inside the stream's kernel order.  Used instead of hipMemsetAsync everywhere in this library:
+// captured into a HIP graph (ROCm 7.2), memset nodes were observed NOT to be ordered against the neighbouring kernel
+// nodes / the previous replay — an accumulate-into-zeroed-buffer kernel saw the old contents of the block on the second
+// replay (tools/memset_graph_probe.py; a ball-query counter array left uncleared that way ended in an out-of-bounds write).
+static __global__ __launch_bounds__(256) void vlp3d_zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
+  const size_t head = ((16 - ((uintptr_t)p & 15)) & 15) >> 2;  // words in front of the first 16-byte boundary
+  const size_t h = head < n ? head : n;
+  const size_t vec = (n - h) >> 2;
+  uint4 *v = reinterpret_cast<uint4 *>(p + h);
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (size_t i = tid; i < vec; i += stride) v[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < h) p[tid] = 0u;
+  const size_t tail0 = h + (vec << 2);
+  if (tid < n - tail0) p[tail0 + tid] = 0u;
+}
+
+static inline hipError_t vlp3d_zero_words(void *p, size_t n_words, hipStream_t s) {
+  if (n_words == 0) return hipSuccess;
+  size_t blocks = (n_words / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(vlp3d_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t *)p, n_words);
+  return hipGetLastError();
+}

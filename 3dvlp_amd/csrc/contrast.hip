@@ -280,7 +280,7 @@ extern "C" int vlp3d_contrast_fwd(const float *text, const float *box, const flo
   Args a = {text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, lang_num, B, L, K, D};
   if (bad_args(a) || !out2 || !lse) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(float), s);
+  hipError_t e = vlp3d_zero_words(out2, 2, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(contrast_fwd_kernel, dim3(B * (L + K)), dim3(256), sizeof(float) * (D + 8 + L), s, a, out2, lse);
   VLP3D_LAUNCH_CHECK();

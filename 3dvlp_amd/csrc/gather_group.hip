@@ -93,7 +93,7 @@ extern "C" int vlp3d_gather_points_grad(const float *grad_out, const int *idx, i
                                         float *grad_points, void *stream) {
   if (!grad_out || !idx || !grad_points || bad_dims(B, C, N, M)) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * N, s);
+  hipError_t e = vlp3d_zero_words(grad_points, (size_t)B * C * N, s);
   if (e != hipSuccess) return (int)e;
   const int gx = vlp3d_cdiv(M, 256);
   const int cpb = pick_c_per_block(C, (long long)gx * B);
@@ -120,7 +120,7 @@ extern "C" int vlp3d_group_points_grad(const float *grad_out, const int *idx, in
   if (!grad_out || !idx || !grad_points || bad_dims(B, C, N, M) || S < 1 || (long long)M * S >= (1ll << 31))
     return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * N, s);
+  hipError_t e = vlp3d_zero_words(grad_points, (size_t)B * C * N, s);
   if (e != hipSuccess) return (int)e;
   const int MS = M * S;
   const int gx = vlp3d_cdiv(MS, 256);

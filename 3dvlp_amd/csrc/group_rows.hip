@@ -127,9 +127,9 @@ extern "C" int vlp3d_group_rows_grad(const void *dout, int dout_bf16, const int 
   if (!dout || !idx || bad(B, N, M, S, C)) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipSuccess;
-  if (dfeat_pm) e = hipMemsetAsync(dfeat_pm, 0, sizeof(float) * (size_t)B * N * C, s);
-  if (e == hipSuccess && dxyz) e = hipMemsetAsync(dxyz, 0, sizeof(float) * (size_t)B * N * 3, s);
-  if (e == hipSuccess && dnew_xyz) e = hipMemsetAsync(dnew_xyz, 0, sizeof(float) * (size_t)B * M * 3, s);
+  if (dfeat_pm) e = vlp3d_zero_words(dfeat_pm, (size_t)B * N * C, s);
+  if (e == hipSuccess && dxyz) e = vlp3d_zero_words(dxyz, (size_t)B * N * 3, s);
+  if (e == hipSuccess && dnew_xyz) e = vlp3d_zero_words(dnew_xyz, (size_t)B * M * 3, s);
   if (e != hipSuccess) return (int)e;
   if (!dfeat_pm && !dxyz && !dnew_xyz) return VLP3D_OK;
   const long long total = (long long)B * M * S * (C / 4 + 1);

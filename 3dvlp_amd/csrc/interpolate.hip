@@ -172,7 +172,7 @@ extern "C" int vlp3d_three_interpolate_grad(const float *grad_out, const int *id
     VLP3D_LAUNCH_CHECK();
     return VLP3D_OK;
   }
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * m, s);
+  hipError_t e = vlp3d_zero_words(grad_points, (size_t)B * C * m, s);
   if (e != hipSuccess) return (int)e;
   const int gx = vlp3d_cdiv(n, 256);
   const int cpb = pick_c_per_block(C, (long long)gx * B);

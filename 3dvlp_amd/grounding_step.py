@@ -11,6 +11,7 @@ in the data_dict.
 reference + DIoU + OCC/OSC as run.sh:1 configures it): 3dvlp_amd/losses.py, fused in csrc/joint_loss.hip.
 """
 import importlib
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -99,6 +100,14 @@ def prepare_batch(out, mean_size_arr=None):
 def batch_to_device(batch, device, mean_size_arr=None):
     """Host batch (numpy) -> device tensors + prepare_batch (synchronous form; see input_pipeline.Prefetcher)."""
     return prepare_batch({k: torch.from_numpy(v).to(device) for k, v in batch.items()}, mean_size_arr)
+
+
+def _detached(out):
+    """The step's data_dict without its autograd graph: same storages (so the allocator keeps them), no grad_fn chain — a
+    graph kept alive across iterations keeps last iteration's AccumulateGrad nodes, bound to that iteration's stream."""
+    if os.environ.get("VLP3D_DEBUG_KEEP_AUTOGRAD") == "1":
+        return out
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
 class _deferred_bn_counters:
@@ -232,8 +241,9 @@ class GroundingStep:
         # the step's data_dict stays referenced (self._last_out; _static_out for a captured step): its tensors are the
         # replayed graph's outputs (losses, predictions, labels), and without the reference the caching allocator handed
         # the block of the captured loss scalar out again — the second replay returned garbage for it
-        loss, self._last_out = self.forward_loss(batch, geometry)
+        loss, out = self.forward_loss(batch, geometry)
         loss.backward()
+        self._last_out = _detached(out)
         self.bucket.collect()
         add_norm.advance(self.device)  # fresh dropout masks next step (also when this is a captured graph)
         if self.pipeline:
@@ -281,8 +291,9 @@ class GroundingStep:
                 self._copy_geometry(self._geom_next, nxt)
             with torch.cuda.graph(self._gM):
                 self.bucket.zero()
-                loss, self._static_out = self.forward_loss(self._static_batch, self._geom_cur)
+                loss, out = self.forward_loss(self._static_batch, self._geom_cur)
                 loss.backward()
+                self._static_out = _detached(out)
                 self.bucket.collect()
                 add_norm.advance(self.device)
                 self._static_loss = loss.detach()

@@ -327,3 +327,44 @@ def test_ball_query_grid_equals_scan_and_oracle(ext, kind, B, N, M, r, ns):
     b = ext.ball_query(dev(new_xyz), dev(xyz), r, ns, "scan").cpu().numpy()
     assert (a == b).all()
     assert (a == orc.ball_query(new_xyz, xyz, r, ns)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 128, 1024, 256), (8, 32, 40000, 2048)])
+def test_zeroing_inside_captured_graph_is_ordered(ext, shape):
+    """Accumulate-into-zeroed-buffer entries stay correct when the captured graph is replayed and the output block
+    held other data in between (hipMemsetAsync nodes did not guarantee that on ROCm 7.2: common.h vlp3d_zero_words)."""
+    B, C, N, M = shape
+    torch.manual_seed(3)
+    go = torch.randn(B, C, M, device="cuda")
+    idx = torch.randint(0, N, (B, M), device="cuda", dtype=torch.int32)
+    ref = ext.gather_points_grad(go, idx, N).clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ext.gather_points_grad(go, idx, N)
+        res = out.clone()
+        del out
+        a = torch.empty(B, C, N, device="cuda")
+        a.fill_(1.0)  # same size: takes the block `out` had
+        del a
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert (res - ref).abs().max().item() < 1e-5  # atomic accumulation order varies; a missed clear is off by 1.0
+
+
+@pytest.mark.gpu
+def test_grid_ball_query_replayed_from_a_graph(ext):
+    synth = importlib.import_module("3dvlp_amd.synth")
+    B, N, M = 4, 20000, 1024
+    xyz = torch.from_numpy(synth.make_batch(0, B, N, 2)["point_clouds"][..., :3].copy()).cuda().contiguous()
+    new_xyz = xyz[:, ::N // M][:, :M].contiguous()
+    ref = ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm="scan")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm="grid")
+        junk = torch.zeros(4 * 1024 * 1024, device="cuda") + 1.0  # lands in the freed workspace block
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
