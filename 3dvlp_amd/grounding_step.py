@@ -238,9 +238,8 @@ class GroundingStep:
             self._geom_tag = self._tag(nxt_batch)
             geometry = self._geom_cur
         self.bucket.zero()
-        # the step's data_dict stays referenced (self._last_out; _static_out for a captured step): its tensors are the
-        # replayed graph's outputs (losses, predictions, labels), and without the reference the caching allocator handed
-        # the block of the captured loss scalar out again — the second replay returned garbage for it
+        # the step's data_dict stays referenced, detached (self._last_out; _static_out for a captured step): its tensors
+        # are the replayed graph's outputs (losses, predictions, labels) that callers read after run()
         loss, out = self.forward_loss(batch, geometry)
         loss.backward()
         self._last_out = _detached(out)
