@@ -1,5 +1,5 @@
 """Summarise ONE steady-state step out of a rocprofv3 kernel_trace.csv (warm-up excluded):
-the window between the last two launches of the SA1 FPS kernel."""
+the window between the last two launches of the SA1 FPS kernel (one per step)."""
 import csv
 import glob
 import sys
@@ -9,7 +9,7 @@ path = sys.argv[1]
 f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "fps_kernel<1024" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel" in r["Kernel_Name"] or "fps_kernel<1024" in r["Kernel_Name"]]
 a, b = marks[-2], marks[-1]
 win = rows[a:b]
 t0, t1 = int(win[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
