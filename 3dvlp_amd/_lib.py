@@ -43,7 +43,8 @@ SIGNATURES = {
     "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
     "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
-                       _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
+                       _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
     "vlp3d_sa_stat_slabs": [ctypes.c_longlong],
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
@@ -61,14 +62,14 @@ SIGNATURES = {
     "vlp3d_box_decode_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_linear_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
     "vlp3d_linear_dgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
-    "vlp3d_linear_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _i, _vp],
+    "vlp3d_linear_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _i, _i, _vp],
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],
     "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_rows_slabs": [ctypes.c_longlong],
     "vlp3d_rows_fwd": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "vlp3d_rows_dgrad": [_vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp],
-    "vlp3d_rows_wgrad": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _vp],
+    "vlp3d_rows_wgrad": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "vlp3d_rows_act": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "vlp3d_rows_act_slabs": [ctypes.c_longlong],
     "vlp3d_rows_act_bwd": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
@@ -425,6 +426,70 @@ def group_rows_grad(dout, idx, B, N, C, radius, need_feat, need_xyz, need_new_xy
                                             float(radius), _opt(dfeat), _opt(dxyz), _opt(dnew), _stream()),
                "group_rows_grad")
     return dfeat, dxyz, dnew
+
+
+class SlabReduceDesc(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_slab_reduce_desc."""
+    _fields_ = [("partials", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("nblk", _i),
+                ("n_mat", _i), ("n_bias", _i), ("K", _i), ("ldo", _i), ("ncol_out", _i), ("rot", _i)]
+
+
+def wgrad_slabs(R, max_blocks):
+    """Number of slabs a weight-gradient launch over R rows writes (the formula of csrc/sa_mlp.hip)."""
+    tiles = R // 32
+    tpb = max(1, (tiles + max_blocks - 1) // max_blocks)
+    return (tiles + tpb - 1) // tpb
+
+
+class SlabReduceQueue:
+    """Weight-gradient launches issued while a queue is active (`deferred_slab_reduce`) leave their per-workgroup slabs
+    behind; `flush` sums all of them with one launch per 40 entries (vlp3d_slab_reduce_batch).  The queue holds the
+    tensors until then.  The gradients are valid only after the flush — the step driver flushes right after
+    `loss.backward()`; code that reads `.grad` inside backward hooks must not use it."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
+        self.items.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), int(ncol_out), int(rot)))
+
+    def flush(self):
+        if not self.items:
+            return
+        arr = (SlabReduceDesc * len(self.items))()
+        for d, (partials, dst, dbias, nblk, n_mat, n_bias, K, ldo, ncol_out, rot) in zip(arr, self.items):
+            d.partials, d.dst, d.dbias = partials.data_ptr(), dst.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
+            d.nblk, d.n_mat, d.n_bias, d.K, d.ldo, d.ncol_out, d.rot = nblk, n_mat, n_bias, K, ldo, ncol_out, rot
+        dev = self.items[0][0].device
+        with torch.cuda.device(dev):
+            _check(load().vlp3d_slab_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.items), _stream()),
+                   "vlp3d_slab_reduce_batch")
+        self.items = []
+
+
+_slab_queue = None  # process-wide on purpose: autograd runs backward on its own thread
+
+
+def slab_queue():
+    return _slab_queue
+
+
+class deferred_slab_reduce:
+    """Context: weight gradients produced inside are completed at exit (one batched slab sum)."""
+
+    def __enter__(self):
+        global _slab_queue
+        self._outer = _slab_queue
+        _slab_queue = SlabReduceQueue() if self._outer is None else self._outer
+        return _slab_queue
+
+    def __exit__(self, *exc):
+        global _slab_queue
+        q = _slab_queue
+        _slab_queue = self._outer
+        if self._outer is None and exc[0] is None:
+            q.flush()
+        return False
 
 
 def call(name, *args):

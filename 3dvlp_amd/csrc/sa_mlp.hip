@@ -1225,6 +1225,59 @@ __global__ __launch_bounds__(256) void wgrad_reduce_strided_kernel(const float *
   }
 }
 
+// MANY slab sums in ONE launch (vlp3d_slab_reduce_batch): the weight-gradient kernels of a backward pass leave their
+// per-workgroup slabs behind (defer_reduce != 0) and the step driver sums all of them at the end of backward — one launch
+// instead of one per layer (51 launches of 5-9 us each at cfg2).  A block sums 64 consecutive elements of one entry, as
+// wgrad_reduce; the entry table travels by value in the kernel arguments.
+constexpr int SLAB_BATCH = 40;
+struct SlabBatch {
+  vlp3d_slab_reduce_desc d[SLAB_BATCH];
+  int first_block[SLAB_BATCH + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(SlabBatch t) {
+  __shared__ float4 red[16][16];
+  int e = 0;
+  while (e + 1 < t.count && (int)blockIdx.x >= t.first_block[e + 1]) ++e;  // block-uniform
+  const vlp3d_slab_reduce_desc &d = t.d[e];
+  const int n = d.n_mat + d.n_bias;
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = ((int)blockIdx.x - t.first_block[e]) * 64 + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+#pragma unroll 4
+    for (int b = grp; b < d.nblk; b += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(d.partials + (long long)b * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[grp][q] = s;
+  __syncthreads();
+  if (grp != 0 || i >= n) return;
+  float4 a = red[0][q];
+#pragma unroll
+  for (int g = 1; g < 16; ++g) {
+    const float4 v = red[g][q];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const float v4[4] = {a.x, a.y, a.z, a.w};
+  if (i >= d.n_mat) {  // n_mat % 4 == 0: the four elements are on the same side
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d.dbias[i - d.n_mat + j] = v4[j];
+    return;
+  }
+  const int row = i / d.K, k = i - row * d.K;  // K % 4 == 0: same row
+  float *o = d.dst + (long long)row * d.ldo;
+  if (d.ncol_out > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k + j < d.ncol_out) o[(k + j + d.rot) % d.ncol_out] = v4[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[k + j] = v4[j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-channel bookkeeping of the fused layer (each replaces ~20 tiny framework kernels per BatchNorm):
 // ------------------------------------------------------------------------------------------------
@@ -1588,8 +1641,8 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
                               const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                               const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                               float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
-                              const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream) {
-  if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
+                              const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, void *stream) {
+  if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
   WgradArgs w = {};
   w.src.K = K; w.src.R = R;
   if (gather) {
@@ -1617,6 +1670,7 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
   if (bf16_io) st = gather ? launch_wgrad_t<bf16, GATHER>(cout, w, s) : launch_wgrad_t<bf16, BNRELU>(cout, w, s);
   else st = gather ? launch_wgrad_t<float, GATHER>(cout, w, s) : launch_wgrad_t<float, BNRELU>(cout, w, s);
   if (st != VLP3D_OK) return st;
+  if (defer_reduce) return VLP3D_OK;  // the slabs are summed later by vlp3d_slab_reduce_batch
   const int n = cout * K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
   VLP3D_LAUNCH_CHECK();
@@ -1759,8 +1813,8 @@ extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, 
 // with_bias != 0: dW has N*K + N elements, the last N are the bias gradient sum_r dY[r][:]; partials then holds
 // max_blocks * (N*K + N) floats.
 extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                                  int max_blocks, int with_bias, void *stream) {
-  if (!dY || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
+                                  int max_blocks, int with_bias, int defer_reduce, void *stream) {
+  if (!dY || !X || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
       ((K / 4) & (K / 4 - 1)) || (N & 31))  // K/4 a power of two: the staging row index is a shift
     return VLP3D_EINVAL;
   WgradArgs w = {};
@@ -1793,6 +1847,7 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
     }
   }
   if (st != VLP3D_OK) return st;
+  if (defer_reduce) return VLP3D_OK;
   const int n = N * K + (with_bias ? N : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
   VLP3D_LAUNCH_CHECK();
@@ -1808,13 +1863,13 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
 // partials: max_blocks * (N*K + N) floats of scratch.
 extern "C" int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
                                 const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo,
-                                float *dbias, float *partials, int max_blocks, void *stream) {
-  if (!G || !X || !dW || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 32 || (K & 31) ||
+                                float *dbias, float *partials, int max_blocks, int defer_reduce, void *stream) {
+  if (!G || !X || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 32 || (K & 31) ||
       K > 288 || (256 % (K / 4)) || ((K / 4) & (K / 4 - 1)) || N < 64 || (N & 63) || ldg < N || lda < K || ldo < K ||
       (bn5 && (!Ypre || dbias)) || (a_scale && !a_shift))
     return VLP3D_EINVAL;
   WgradArgs w = {};
-  w.colsum = dbias != nullptr;
+  w.colsum = dbias != nullptr;  // deferred: a non-NULL dbias only asks for the column sums in the slabs
   w.src.K = K; w.src.R = R; w.src.Yin = X; w.src.ldin = lda; w.src.scale = a_scale; w.src.shift = a_shift;
   w.dy.ldin = ldg;
   if (bn5) {
@@ -1837,9 +1892,35 @@ extern "C" int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, cons
   if (bn5) st = a_scale ? launch_wgrad_c<float, BNRELU, 64, BNBWD>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, BNBWD>(w, s, grid, lds);
   else st = a_scale ? launch_wgrad_c<float, BNRELU, 64, PLAIN>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds);
   if (st != VLP3D_OK) return st;
+  if (defer_reduce) return VLP3D_OK;
   const int n = N * K + (dbias ? N : 0);
   hipLaunchKernelGGL(wgrad_reduce_strided_kernel, dim3((n + 15) / 16), dim3(256), 0, s, partials, nblk, N, K, dbias ? 1 : 0, dW,
                      ldo, dbias);
   VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// Sum the per-workgroup slabs of `count` deferred weight-gradient launches (descs: HOST array, read during the call).
+extern "C" int vlp3d_slab_reduce_batch(const vlp3d_slab_reduce_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return VLP3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  for (int c0 = 0; c0 < count; c0 += SLAB_BATCH) {
+    SlabBatch t = {};
+    t.count = count - c0 < SLAB_BATCH ? count - c0 : SLAB_BATCH;
+    int blocks = 0;
+    for (int j = 0; j < t.count; ++j) {
+      const vlp3d_slab_reduce_desc &d = descs[c0 + j];
+      if (!d.partials || !d.dst || d.nblk < 1 || d.n_mat < 4 || (d.n_mat & 3) || d.n_bias < 0 || (d.n_bias & 3) ||
+          (d.n_bias && !d.dbias) || d.K < 4 || (d.K & 3) || (d.n_mat % d.K) || d.ldo < (d.ncol_out > 0 ? d.ncol_out : d.K) ||
+          d.ncol_out > d.K || d.rot < 0 || (((size_t)d.partials) & 15))
+        return VLP3D_EINVAL;
+      t.d[j] = d;
+      t.first_block[j] = blocks;
+      blocks += (d.n_mat + d.n_bias + 63) / 64;
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+    VLP3D_LAUNCH_CHECK();
+  }
   return VLP3D_OK;
 }

@@ -241,13 +241,19 @@ class GroundingStep:
         # the step's data_dict stays referenced, detached (self._last_out; _static_out for a captured step): its tensors
         # are the replayed graph's outputs (losses, predictions, labels) that callers read after run()
         loss, out = self.forward_loss(batch, geometry)
-        loss.backward()
+        self._backward(loss)
         self._last_out = _detached(out)
         self.bucket.collect()
         add_norm.advance(self.device)  # fresh dropout masks next step (also when this is a captured graph)
         if self.pipeline:
             torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()
+
+    @staticmethod
+    def _backward(loss):
+        """backward with every weight-gradient slab sum of the pass deferred into one launch (51 -> 2 at cfg2)."""
+        with _ext.deferred_slab_reduce():
+            loss.backward()
 
     def _persistent_state(self):
         """Everything a forward pass mutates besides the parameters: BatchNorm running statistics / counters and the
@@ -291,7 +297,7 @@ class GroundingStep:
             with torch.cuda.graph(self._gM):
                 self.bucket.zero()
                 loss, out = self.forward_loss(self._static_batch, self._geom_cur)
-                loss.backward()
+                self._backward(loss)
                 self._static_out = _detached(out)
                 self.bucket.collect()
                 add_norm.advance(self.device)

@@ -65,7 +65,10 @@ class _Linear(Function):
             dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy.device)
             nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
             part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
-            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db))
+            q = _ext.slab_queue()
+            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None))
+            if q is not None:
+                q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None, N if want_db else 0)
             dw = dwb[:N * K].view(N, K)
             if want_db:
                 db = dwb[N * K:]

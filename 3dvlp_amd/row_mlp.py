@@ -156,11 +156,16 @@ class _RowStack(Function):
             dbias = torch.empty((Np,), dtype=torch.float32, device=dev) if want_db else None
             ks = min(K, WGRAD_K)
             nblk = max(8, min(128, R // 64))
-            part = torch.empty((nblk, Np * ks + Np), dtype=torch.float32, device=dev)
+            q = _ext.slab_queue()
             for off in range(0, K, ks):
+                if q is not None or off == 0:  # deferred: every K-slice keeps its own slabs until the batched sum
+                    part = torch.empty((nblk, Np * ks + Np), dtype=torch.float32, device=dev)
+                db_ = dbias if off == 0 else None
                 _ext.call("vlp3d_rows_wgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, A[:, off:], lda,
                           None if pv is None else pv[0, off:], None if pv is None else pv[1, off:], R, ks, Np,
-                          dW[:, off:], K, dbias if off == 0 else None, part, nblk)
+                          dW[:, off:], K, db_, part, nblk, int(q is not None))
+                if q is not None:
+                    q.add(part, _ext.wgrad_slabs(R, nblk), dW[:, off:], Np * ks, ks, K, db_, Np if db_ is not None else 0)
             grads[4 * l] = dW[:N]
             if want_db:
                 grads[4 * l + 1] = dbias[:N]

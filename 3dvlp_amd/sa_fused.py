@@ -130,13 +130,17 @@ class FusedSAMLP(Function):
             db = torch.empty((cout[l],), dtype=torch.float32, device=dev)
             _ext.call("vlp3d_sa_bn_bwd_consts", vecs[l], gam[l], t[l], tn[l], cout[l], R, int(training), c5, dg, db)
             dparams[3 * l + 1], dparams[3 * l + 2] = dg, db
-            dW = torch.empty((cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            q = _ext.slab_queue()  # set by the step driver: all slab sums of the backward pass in one launch at its end
+            dW = torch.empty((cout[l], Ks[l]) if (l > 0 or q is None) else (cout[0], C + 3), dtype=torch.float32, device=dev)
             nblk = _wgrad_blocks(R, cout[l], Ks[l])
             part = torch.empty((nblk, cout[l], Ks[l]), dtype=torch.float32, device=dev)
+            if q is not None:
+                q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[l] * Ks[l], Ks[l], dW.shape[1],
+                      ncol_out=0 if l > 0 else C + 3, rot=0 if l > 0 else 3)
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
                           vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
-                          *(pool if G is None else (None, None, 0)), bf)
+                          *(pool if G is None else (None, None, 0)), bf, int(q is not None))
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WTs[l], cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
@@ -144,8 +148,11 @@ class FusedSAMLP(Function):
                 G = Gp
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf)
-                dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
+                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None))
+                if q is not None:  # the batched slab sum writes [xyz | features] columns directly
+                    dparams[0] = dW.view(cout[0], C + 3, 1, 1)
+                else:
+                    dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
                     kpad = WTs[0].shape[0]
                     dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dev) if need[3] else None

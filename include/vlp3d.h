@@ -167,7 +167,7 @@ int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const fl
                    const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                    float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
-                   const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream);
+                   const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, void *stream);
 
 /* per-channel bookkeeping of the fused layer (one launch each instead of ~20 framework kernels):
  * bn_fold: vec (4 x C) = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums `stats` (training) or the
@@ -200,7 +200,24 @@ int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long lon
                      void *stream);
 int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream);
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                       int max_blocks, int with_bias, void *stream);
+                       int max_blocks, int with_bias, int defer_reduce, void *stream);
+
+/* Deferred slab sums.  The three weight-gradient entries (vlp3d_sa_wgrad, vlp3d_linear_wgrad, vlp3d_rows_wgrad) write
+ * per-workgroup partial results ("slabs") and then sum them with a second launch.  With defer_reduce != 0 they stop
+ * after the slabs (dW / dbias are not touched and may be NULL) and the caller sums the slabs of MANY launches at once:
+ *   nblk   = ceil(T / ceil(T / max_blocks)), T = R / 32 — the number of slabs the launch wrote
+ *   slab   = [n_mat = N*K matrix floats | n_bias column sums (0 or N)]
+ *   dst    : element (row, k) of the matrix goes to dst[row*ldo + k]; with ncol_out > 0 only k < ncol_out is kept and
+ *            stored at column (k + rot) % ncol_out (vlp3d_sa_wgrad, gather layer: slab columns are [features | xyz | pad],
+ *            the parameter is [xyz | features]: ncol_out = C + 3, rot = 3)
+ * descs is a HOST array, consumed during the call. */
+typedef struct {
+  const float *partials;
+  float *dst;
+  float *dbias;
+  int nblk, n_mat, n_bias, K, ldo, ncol_out, rot;
+} vlp3d_slab_reduce_desc;
+int vlp3d_slab_reduce_batch(const vlp3d_slab_reduce_desc *descs, int count, void *stream);
 
 /* ---- the training loss of the grounding step (csrc/joint_loss.hip) ------------------------------------------
  * replaces lib/loss_helper/loss_joint.py:26-227 (get_joint_loss with detection + reference, run.sh:1) and what it
@@ -349,7 +366,7 @@ int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn
                      const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda, double *tstats, void *stream);
 int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
                      const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo, float *dbias,
-                     float *partials, int max_blocks, void *stream);
+                     float *partials, int max_blocks, int defer_reduce, void *stream);
 int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream);
 int vlp3d_rows_act_slabs(long long R);
 int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G, double *tstats,

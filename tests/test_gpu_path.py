@@ -832,3 +832,38 @@ def test_flat_params_merge_views_and_flat_adamw_equal_torch():
             # update is ~ lr * sign(g) there): a few 1e-5 absolute at lr = 1e-2
             torch.testing.assert_close(p, q, rtol=0, atol=1e-6 if step == 0 else 2e-4, msg=f"{n_} step {step}")
     assert net["unused"].weight.grad is None and torch.equal(net["unused"].weight, ref["unused"].weight)
+
+
+def test_deferred_slab_reduce_equals_immediate():
+    """Weight gradients with every slab sum of the backward pass batched into one launch at its end
+    (_lib.deferred_slab_reduce, vlp3d_slab_reduce_batch) equal the per-layer reduce launches: SA stacks incl. the
+    [xyz | features] column rotation of the gather layer, rows stacks with K slices and bias sums, nn.Linear [dW | db]."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    ext = importlib.import_module("3dvlp_amd._lib")
+    devc = torch.device("cuda:0")
+    batch = gs.batch_to_device(synth.make_batch(0, 2, num_points=8192, lang_num_max=2), devc)
+    batch["random"] = torch.tensor(0.25, device=devc)
+    step = gs.GroundingStep(devc)
+    _eval_dropout_train_bn(step)
+    state = [b.clone() for b in step.model.buffers()]
+    grads = []
+    for deferred in (False, False, True):  # the first two runs give the run-to-run noise of the float atomics upstream
+        for b, s0 in zip(step.model.buffers(), state):
+            b.copy_(s0)
+        step.bucket.zero()
+        loss, _ = step.forward_loss(batch, None)
+        if deferred:
+            with ext.deferred_slab_reduce() as q:
+                loss.backward()
+                assert len(q.items) > 20
+        else:
+            loss.backward()
+        step.bucket.collect()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in step.model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[2].keys()
+    for n, g0 in grads[0].items():
+        noise = _rel(grads[1][n], g0)
+        g1 = grads[2][n]
+        assert _rel(g1, g0) <= max(2e-5, 3 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)

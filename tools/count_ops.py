@@ -1,5 +1,6 @@
-"""Count ATen ops (~ kernel launches) of one eager step per phase: forward of each top-level module, loss, backward."""
-import importlib, os, sys
+"""Count ATen ops (~ kernel launches) of one eager step per phase: forward of each top-level module, loss, backward.
+With `--where` every forward op is listed with the innermost source line inside the package (and its tensor shapes)."""
+import importlib, os, sys, traceback
 from collections import Counter, defaultdict
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
@@ -15,12 +16,19 @@ SKIP = ("aten.view", "aten._unsafe_view", "aten.t.", "aten.transpose", "aten.per
         "aten.split", "aten.unbind", "aten.chunk", "aten._reshape_alias", "aten.lift_fresh", "aten.narrow", "aten.stride", "aten.size",
         "aten.sym_", "aten.is_", "aten.unfold", "aten.diagonal", "aten.new_empty.", "aten.empty_like", "aten.result_type", "aten.item", "aten._local_scalar")
 phase = ["init"]
+WHERE = "--where" in sys.argv
+where = Counter()
 counts = defaultdict(Counter)
 class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         n = str(func)
         if not n.startswith(SKIP):
             counts[phase[0]][n] += 1
+            if WHERE:
+                fr = [f for f in traceback.extract_stack() if "3dvlp_amd/" in f.filename]
+                loc = f"{os.path.basename(fr[-1].filename)}:{fr[-1].lineno}" if fr else "(autograd)"
+                shp = ",".join(str(tuple(a.shape)) for a in args if torch.is_tensor(a))[:60]
+                where[(phase[0], n, loc, shp)] += 1
         return func(*args, **(kwargs or {}))
 def pre(name):
     def f(m, a): phase[0] = "fwd:" + name
@@ -44,6 +52,9 @@ tot = 0
 for ph, c in counts.items():
     n = sum(c.values()); tot += n
     print(f"== {ph}: {n} ops")
-    for k, v in c.most_common(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
+    for k, v in c.most_common(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 12):
         print(f"     {v:4d}  {k}")
 print("total", tot)
+if WHERE:
+    for (ph, n, loc, shp), v in sorted(where.items(), key=lambda kv: (kv[0][0], kv[0][2])):
+        print(f"{v:3d} {ph:18s} {loc:28s} {n:38s} {shp}")
