@@ -45,6 +45,7 @@ SIGNATURES = {
     "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                        _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
+    "vlp3d_copy_batch": [_vp, _i, _vp],
     "vlp3d_sa_stat_slabs": [ctypes.c_longlong],
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
@@ -432,6 +433,25 @@ class SlabReduceDesc(ctypes.Structure):
     """include/vlp3d.h: vlp3d_slab_reduce_desc."""
     _fields_ = [("partials", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("nblk", _i),
                 ("n_mat", _i), ("n_bias", _i), ("K", _i), ("ldo", _i), ("ncol_out", _i), ("rot", _i)]
+
+
+class CopyDesc(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_copy_desc."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
+
+
+def copy_batch(dsts, srcs):
+    """dst[i].copy_(src[i]) for same-shape, same-dtype contiguous CUDA tensors — one launch (csrc/glue.hip)."""
+    if not dsts:
+        return
+    arr = (CopyDesc * len(dsts))()
+    for c, d, s_ in zip(arr, dsts, srcs):
+        if d.shape != s_.shape or d.dtype != s_.dtype or not (d.is_contiguous() and s_.is_contiguous()) or \
+                not (d.is_cuda and s_.is_cuda):
+            raise RuntimeError("copy_batch: same-shape, same-dtype contiguous CUDA tensors only")
+        c.src, c.dst, c.bytes = s_.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
+    with torch.cuda.device(dsts[0].device):
+        _check(load().vlp3d_copy_batch(ctypes.cast(arr, ctypes.c_void_p), len(dsts), _stream()), "vlp3d_copy_batch")
 
 
 def wgrad_slabs(R, max_blocks):

@@ -371,3 +371,55 @@ extern "C" int vlp3d_adamw_flat(float *p, const float *g, float *m, float *v, co
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
+
+// ---- copy_batch ------------------------------------------------------------------------------------------------------
+// Many small device-to-device copies in ONE launch (the hand-over of the prepared backbone geometry is 16 index /
+// coordinate tensors: torch._foreach_copy_ turned them into 16 memcpy nodes + 2 kernels per hand-over).  The table
+// travels by value in the kernel arguments; a block moves one 16 KB piece of one entry.
+namespace {
+constexpr int COPY_BATCH = 48;
+constexpr int COPY_PIECE = 16384;
+struct CopyBatch {
+  vlp3d_copy_desc d[COPY_BATCH];
+  int first_block[COPY_BATCH + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch t) {
+  int e = 0;
+  while (e + 1 < t.count && (int)blockIdx.x >= t.first_block[e + 1]) ++e;
+  const vlp3d_copy_desc &d = t.d[e];
+  const long long off = (long long)((int)blockIdx.x - t.first_block[e]) * COPY_PIECE;
+  const long long n = d.bytes - off < COPY_PIECE ? d.bytes - off : COPY_PIECE;
+  const char *s = (const char *)d.src + off;
+  char *o = (char *)d.dst + off;
+  if ((((size_t)s | (size_t)o) & 15) == 0) {
+    const long long nv = n >> 4;
+    for (long long i = threadIdx.x; i < nv; i += 256) reinterpret_cast<uint4 *>(o)[i] = reinterpret_cast<const uint4 *>(s)[i];
+    for (long long i = (nv << 4) + threadIdx.x; i < n; i += 256) o[i] = s[i];
+  } else {
+    for (long long i = threadIdx.x; i < n; i += 256) o[i] = s[i];
+  }
+}
+}  // namespace
+
+extern "C" int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return VLP3D_EINVAL;
+  for (int c0 = 0; c0 < count; c0 += COPY_BATCH) {
+    CopyBatch t = {};
+    t.count = count - c0 < COPY_BATCH ? count - c0 : COPY_BATCH;
+    long long blocks = 0;
+    for (int j = 0; j < t.count; ++j) {
+      const vlp3d_copy_desc &d = descs[c0 + j];
+      if (d.bytes < 0 || (d.bytes > 0 && (!d.src || !d.dst))) return VLP3D_EINVAL;
+      t.d[j] = d;
+      t.first_block[j] = (int)blocks;
+      blocks += (d.bytes + COPY_PIECE - 1) / COPY_PIECE;
+      if (blocks >= (1ll << 31)) return VLP3D_EINVAL;
+    }
+    t.first_block[t.count] = (int)blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(copy_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+    VLP3D_LAUNCH_CHECK();
+  }
+  return VLP3D_OK;
+}

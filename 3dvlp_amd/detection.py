@@ -67,7 +67,11 @@ class Pointnet2Backbone(nn.Module):
         return g
 
     def forward(self, data_dict):
-        xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        if "k/xyz" in data_dict and "k/feat_pm" in data_dict:
+            # the loader already split the cloud (grounding_step.prepare_batch): no 173 MB copy inside the step
+            xyz, features = data_dict["k/xyz"], data_dict["k/feat_pm"].transpose(1, 2)
+        else:
+            xyz, features = self._break_up_pc(data_dict["point_clouds"])
         geo = data_dict.get("backbone_geometry") or {}
         xyz, features, fps_inds = self.sa1(xyz, features, geometry=geo.get("sa1"))
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features

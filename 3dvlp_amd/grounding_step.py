@@ -83,7 +83,9 @@ def prepare_batch(out, mean_size_arr=None):
       k/vote_label_mask f32, k/{heading_class,size_class,sem_cls}_label i32, k/lang_num i32 — dtypes the loss kernel
       reads (lib/joint/dataset.py hands them over as int64);  k/ref_size — decoded size of the referred boxes
       (class2size, model_util_scannet.py:183-185; consumed by the DIoU loss and the contrast module);
-      k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134)."""
+      k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134);
+      k/xyz, k/feat_pm — the cloud split into coordinates and point-major features (backbone_module.py:73-80 slices
+      and copies them inside forward: 173 MB per step at cfg2)."""
     device = out["point_clouds"].device
     out.setdefault("istrain", [1])
     mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32,
@@ -94,6 +96,9 @@ def prepare_batch(out, mean_size_arr=None):
             out["k/" + k] = out[k].to(torch.int32)
     out["k/ref_size"] = (mean[out["ref_size_class_label_list"]] + out["ref_size_residual_label_list"]).float().contiguous()
     out["k/lang_kv"] = out["lang_fea"][:, 1:].contiguous()
+    pc = out["point_clouds"]
+    if pc.size(-1) > 3:
+        out["k/xyz"], out["k/feat_pm"] = pc[..., :3].contiguous(), pc[..., 3:].contiguous()
     return out
 
 
@@ -199,10 +204,14 @@ class GroundingStep:
 
     @staticmethod
     def _copy_geometry(dst, src):
-        """All index / coordinate tensors of the backbone geometry in ONE multi-tensor copy (was 16 small copies)."""
+        """All index / coordinate tensors of the backbone geometry in ONE launch (torch._foreach_copy_ issued 16 memcpy
+        nodes and two kernels for them)."""
         d = [a for k in src for a in dst[k]]
         s_ = [b for k in src for b in src[k]]
-        torch._foreach_copy_(d, s_)
+        if d[0].is_cuda and all(b.is_contiguous() for b in s_):
+            _ext.copy_batch(d, s_)
+        else:
+            torch._foreach_copy_(d, s_)
 
     @staticmethod
     def _tag(batch):

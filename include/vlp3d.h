@@ -422,6 +422,15 @@ int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, 
 int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
 
+/* count device-to-device copies in one launch (descs: HOST array, consumed during the call; overlapping entries are
+ * the caller's problem).  Replaces torch._foreach_copy_ for the hand-over of the prepared backbone geometry. */
+typedef struct {
+  const void *src;
+  void *dst;
+  long long bytes;
+} vlp3d_copy_desc;
+int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
