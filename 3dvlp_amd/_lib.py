@@ -467,11 +467,19 @@ class SlabReduceQueue:
     tensors until then.  The gradients are valid only after the flush — the step driver flushes right after
     `loss.backward()`; code that reads `.grad` inside backward hooks must not use it."""
 
+    FLUSH_BYTES = int(os.environ.get("VLP3D_SLAB_FLUSH_MB", 64)) << 20  # sum while the slabs are still cache-resident
+
     def __init__(self):
         self.items = []
+        self.pending = 0
+        self.added = 0
 
     def add(self, partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
         self.items.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), int(ncol_out), int(rot)))
+        self.added += 1
+        self.pending += 4 * int(nblk) * (int(n_mat) + int(n_bias))
+        if self.pending >= self.FLUSH_BYTES or len(self.items) >= 40:
+            self.flush()
 
     def flush(self):
         if not self.items:
@@ -485,6 +493,7 @@ class SlabReduceQueue:
             _check(load().vlp3d_slab_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.items), _stream()),
                    "vlp3d_slab_reduce_batch")
         self.items = []
+        self.pending = 0
 
 
 _slab_queue = None  # process-wide on purpose: autograd runs backward on its own thread

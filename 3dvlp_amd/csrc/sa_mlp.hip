@@ -945,6 +945,33 @@ __device__ __forceinline__ float4 load_dy4(const RowGemmArgs &a, int row, int co
   return k.apply(g, y);
 }
 
+// bf16 storage: 8 consecutive columns per staging element — ONE 16-byte load per operand (8-byte loads run at 0.54-0.70
+// of the 16-byte rate, MI355X_MICROARCH.md) — returned packed as bf16 for the LDS tile.
+template <int DYL>
+__device__ __forceinline__ uint4 load_dy8_bf(const RowGemmArgs &a, int row, int col0, const DyConsts<bf16> &klo,
+                                             const DyConsts<bf16> &khi) {
+  const uint4 yr = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
+  if (DYL == PLAIN) return yr;
+  float y[8], g[8];
+  unpack8(yr, y);
+  if (a.pool_g != nullptr) {  // kernel-uniform
+    const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+    const int sidx = row - bm * a.pool_S;
+    const long long off = (long long)bm * a.ldin + col0;
+    const float4 d0 = ld4(a.pool_g + off), d1 = ld4(a.pool_g + off + 4);
+    const uint2 sl = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
+    g[0] = (int)(sl.x & 255u) == sidx ? d0.x : 0.f;         g[1] = (int)((sl.x >> 8) & 255u) == sidx ? d0.y : 0.f;
+    g[2] = (int)((sl.x >> 16) & 255u) == sidx ? d0.z : 0.f; g[3] = (int)(sl.x >> 24) == sidx ? d0.w : 0.f;
+    g[4] = (int)(sl.y & 255u) == sidx ? d1.x : 0.f;         g[5] = (int)((sl.y >> 8) & 255u) == sidx ? d1.y : 0.f;
+    g[6] = (int)((sl.y >> 16) & 255u) == sidx ? d1.z : 0.f; g[7] = (int)(sl.y >> 24) == sidx ? d1.w : 0.f;
+  } else {
+    unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0), g);
+  }
+  const float4 lo = klo.apply(make_float4(g[0], g[1], g[2], g[3]), make_float4(y[0], y[1], y[2], y[3]));
+  const float4 hi = khi.apply(make_float4(g[4], g[5], g[6], g[7]), make_float4(y[4], y[5], y[6], y[7]));
+  return pack8(lo, hi);
+}
+
 struct WgradArgs {
   RowGemmArgs dy;   // BNBWD loader of this layer's dY (Gin, Yin, ldin = COUT, constants)
   RowGemmArgs src;  // loader of A_{l-1} (GATHER or BNRELU), K = src.K valid columns
@@ -991,6 +1018,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   // predicated — hipcc otherwise branches around each load and waits vmcnt(0) per element, serialising them.
   static_assert((32 * COUT / 4) % 256 == 0, "dY tile must split evenly over 256 threads");
   constexpr int NE_DY = 32 * COUT / 4 / 256;
+  // bf16 storage: 8-column (16-byte) staging elements for dY and for a BN+ReLU / plain A operand (the gathered operand is
+  // fp32: its 4-column elements already are 16 bytes)
+  constexpr int NE_DY8 = (32 * COUT / 8 + 255) / 256;
+  constexpr bool A8 = BF && LOADER != GATHER;
   // staging elements of the A tile per thread = 32*KP/4/256 = KP/32 = NKT <= 4*MAXT/NCT (MAXT >= NCT*NKT/4): sized by
   // the instantiation instead of the worst case 9 (five float4 of dead loads and registers at K = 128)
   constexpr int MAXE_A = (4 * MAXT / NCT) < 1 ? 1 : ((4 * MAXT / NCT) < 9 ? (4 * MAXT / NCT) : 9);
@@ -1000,18 +1031,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int kfs = (LOADER == GATHER) ? 0 : __builtin_ctz(kf4);
   auto row_of = [&](int e) -> int { return LOADER == GATHER ? e / kf4 : e >> kfs; };
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
-  float4 vdy[NE_DY], va[MAXE_A], vt;
+  float4 vdy[BF ? 1 : NE_DY], va[A8 ? 1 : MAXE_A], vt;
+  constexpr int MAXE_A8 = (MAXE_A + 1) / 2;
+  uint4 pdy[BF ? NE_DY8 : 1], pa8[A8 ? MAXE_A8 : 1];
+  const int kf8 = KF / 8, nef8 = 32 * kf8, kfs8 = A8 ? __builtin_ctz(kf8 > 0 ? kf8 : 1) : 0;
 
   // column-block mode (gridDim.y > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
   // runs as two 128-wide halves (64 instead of 144 accumulator registers: three waves per SIMD instead of one)
   const int coff = blockIdx.y * COUT;
-  DyConsts<T> dyk;
-  if (DYL == BNBWD) dyk.load(w.dy, coff + (threadIdx.x % (COUT / 4)) * 4);
-  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;
+  DyConsts<T> dyk, dyk2;
+  if (DYL == BNBWD) {
+    if (BF) {
+      dyk.load(w.dy, coff + (threadIdx.x % (COUT / 8)) * 8);
+      dyk2.load(w.dy, coff + (threadIdx.x % (COUT / 8)) * 8 + 4);
+    } else {
+      dyk.load(w.dy, coff + (threadIdx.x % (COUT / 4)) * 4);
+    }
+  }
+  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc, a_sc2 = a_sc, a_sh2 = a_sc;
   if (LOADER == BNRELU) {
-    const int k0 = (threadIdx.x % kf4) * 4;
+    const int k0 = A8 ? (threadIdx.x % kf8) * 8 : (threadIdx.x % kf4) * 4;
     a_sc = ld4(w.src.scale + k0);
     a_sh = ld4(w.src.shift + k0);
+    if (A8) {
+      a_sc2 = ld4(w.src.scale + k0 + 4);
+      a_sh2 = ld4(w.src.shift + k0 + 4);
+    }
   }
   // The gathered operand needs idx[row] before its feature row can be requested: two dependent memory latencies per
   // tile.  The indices therefore run ONE TILE FURTHER AHEAD than the data (pidx/tp hold the next tile's indices).
@@ -1043,13 +1088,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       }
     }
     const long long pbase = (long long)scene * w.src.N;
+    if constexpr (BF) {
 #pragma unroll
-    for (int j = 0; j < NE_DY; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), coff + (e % (COUT / 4)) * 4, dyk);
+      for (int j = 0; j < NE_DY8; ++j) {
+        const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
+        pdy[j] = load_dy8_bf<DYL>(w.dy, row0 + e / (COUT / 8), coff + (e % (COUT / 8)) * 8, dyk, dyk2);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE_DY; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), coff + (e % (COUT / 4)) * 4, dyk);
+      }
+    }
+    if constexpr (A8) {
+#pragma unroll
+      for (int j = 0; j < MAXE_A8; ++j) {
+        const int e = min((int)threadIdx.x + 256 * j, nef8 - 1);
+        const int row = e >> kfs8, k0 = (e - (row << kfs8)) * 8;
+        const uint4 yr = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(w.src.Yin) +
+                                                          (long long)(row0 + row) * w.src.ldin + k0);
+        if (LOADER == BNRELU) {
+          float y[8];
+          unpack8(yr, y);
+          pa8[j] = pack8(make_float4(fmaxf(0.f, y[0] * a_sc.x + a_sh.x), fmaxf(0.f, y[1] * a_sc.y + a_sh.y),
+                                     fmaxf(0.f, y[2] * a_sc.z + a_sh.z), fmaxf(0.f, y[3] * a_sc.w + a_sh.w)),
+                         make_float4(fmaxf(0.f, y[4] * a_sc2.x + a_sh2.x), fmaxf(0.f, y[5] * a_sc2.y + a_sh2.y),
+                                     fmaxf(0.f, y[6] * a_sc2.z + a_sh2.z), fmaxf(0.f, y[7] * a_sc2.w + a_sh2.w)));
+        } else {
+          pa8[j] = yr;
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < MAXE_A; ++j) {
+    for (int j = 0; j < (A8 ? 0 : MAXE_A); ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
       const int row = row_of(e), k0 = (e - row * kf4) * 4;
       const int rr = row0 + row;
@@ -1082,13 +1154,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   for (long long tile = t0; tile < t1; ++tile) {
     __syncthreads();  // the previous tile's MFMA reads are done
     if (BF) {
+      // rows of the LDS tiles are 8 (mod 16) bytes apart (bank layout of the operand reads): two 8-byte stores per element
 #pragma unroll
-      for (int j = 0; j < NE_DY; ++j) {
+      for (int j = 0; j < NE_DY8; ++j) {
         const int e = threadIdx.x + 256 * j;
-        *reinterpret_cast<uint2 *>(ldb_dy + (e / (COUT / 4)) * RSD + (e % (COUT / 4)) * 4) = pack4(vdy[j]);
+        if (e < 32 * COUT / 8) {
+          short *q = ldb_dy + (e / (COUT / 8)) * RSD + (e % (COUT / 8)) * 8;
+          *reinterpret_cast<uint2 *>(q) = make_uint2(pdy[j].x, pdy[j].y);
+          *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pdy[j].z, pdy[j].w);
+        }
+      }
+      if constexpr (A8) {
+#pragma unroll
+        for (int j = 0; j < MAXE_A8; ++j) {
+          const int e = threadIdx.x + 256 * j;
+          if (e < nef8) {
+            const int row = e >> kfs8;
+            short *q = ldb_a + row * RSA + (e - (row << kfs8)) * 8;
+            *reinterpret_cast<uint2 *>(q) = make_uint2(pa8[j].x, pa8[j].y);
+            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pa8[j].z, pa8[j].w);
+          }
+        }
       }
 #pragma unroll
-      for (int j = 0; j < MAXE_A; ++j) {
+      for (int j = 0; j < (A8 ? 0 : MAXE_A); ++j) {
         const int e = threadIdx.x + 256 * j;
         if (e < nef) {
           const int row = row_of(e);

@@ -4,6 +4,7 @@ The projections / FFNs / heads of the grounding path are 2 048..16 384-row by 12
 library runs at ~5 TFLOP/s; here they use the same exact-fp32 MFMA kernels as the grouped MLP.  `linear(x, w, b)`
 has F.linear semantics; shapes the kernels do not cover (rows not a multiple of 32, tiny widths) go to F.linear.
 """
+import os
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -13,7 +14,7 @@ from . import _lib as _ext
 _ext.load()
 
 _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
-WGRAD_BLOCKS = 256     # at most this many workgroups (= partial [dW | db] slabs)
+WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BLOCKS", 128))     # at most this many workgroups (= partial [dW | db] slabs)
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)

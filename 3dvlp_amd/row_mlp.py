@@ -10,6 +10,7 @@ VotingModule (voting_module.py:33-60) and StandardROIHeads (roi_heads.py:15-147)
 autograd backward is the same handful of kernels run in reverse (BatchNorm / ReLU backward folded into the products).
 `fp_rows` is three_interpolate + concat of the FP module on point-major features.
 """
+import os
 import torch
 from torch.autograd import Function
 
@@ -17,6 +18,7 @@ from . import _lib as _ext
 
 _ext.load()
 _ZEROS = {}
+ROWS_WGRAD_BLOCKS = int(os.environ.get("VLP3D_ROWS_WGRAD_BLOCKS", 64))
 WGRAD_K = 256  # K-slice of one weight-gradient launch (the staging of csrc/sa_mlp.hip: wgrad_kernel covers K <= 288)
 
 
@@ -155,7 +157,7 @@ class _RowStack(Function):
             want_db = (not has_bn[l]) and has_bias[l]
             dbias = torch.empty((Np,), dtype=torch.float32, device=dev) if want_db else None
             ks = min(K, WGRAD_K)
-            nblk = max(8, min(128, R // 64))
+            nblk = max(8, min(ROWS_WGRAD_BLOCKS, R // 64))
             q = _ext.slab_queue()
             for off in range(0, K, ks):
                 if q is not None or off == 0:  # deferred: every K-slice keeps its own slabs until the batched sum

@@ -15,7 +15,7 @@ from . import _lib as _ext
 
 _ext.load()
 
-WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 1024))  # most workgroups (= partial dW slabs) of the weight-gradient kernel
+WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 512))  # most workgroups (= partial dW slabs) of the weight-gradient kernel
 WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
 
 
@@ -134,13 +134,12 @@ class FusedSAMLP(Function):
             dW = torch.empty((cout[l], Ks[l]) if (l > 0 or q is None) else (cout[0], C + 3), dtype=torch.float32, device=dev)
             nblk = _wgrad_blocks(R, cout[l], Ks[l])
             part = torch.empty((nblk, cout[l], Ks[l]), dtype=torch.float32, device=dev)
-            if q is not None:
-                q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[l] * Ks[l], Ks[l], dW.shape[1],
-                      ncol_out=0 if l > 0 else C + 3, rot=0 if l > 0 else 3)
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
                           vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
                           *(pool if G is None else (None, None, 0)), bf, int(q is not None))
+                if q is not None:  # after the launch: the queue may sum right away
+                    q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[l] * Ks[l], Ks[l], Ks[l])
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WTs[l], cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
@@ -150,6 +149,7 @@ class FusedSAMLP(Function):
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
                           feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None))
                 if q is not None:  # the batched slab sum writes [xyz | features] columns directly
+                    q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[0] * Ks[0], Ks[0], C + 3, ncol_out=C + 3, rot=3)
                     dparams[0] = dW.view(cout[0], C + 3, 1, 1)
                 else:
                     dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
