@@ -46,6 +46,10 @@ SIGNATURES = {
                        _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
     "vlp3d_copy_batch": [_vp, _i, _vp],
+    "vlp3d_smallk_fwd": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
+    "vlp3d_smallk_bwd": [_vp, _vp, _i, ctypes.c_longlong, _i, _i, _vp, _vp],
+    "vlp3d_rowdot_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
+    "vlp3d_rowdot_bwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp],
     "vlp3d_sa_stat_slabs": [ctypes.c_longlong],
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
@@ -59,6 +63,7 @@ SIGNATURES = {
     "vlp3d_add_norm_blocks": [ctypes.c_longlong],
     "vlp3d_add_norm_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_add_norm_bwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "vlp3d_act_dropout": [_vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _vp, _vp, _vp],
     "vlp3d_box_decode_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_box_decode_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_linear_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
@@ -465,7 +470,9 @@ class SlabReduceQueue:
     """Weight-gradient launches issued while a queue is active (`deferred_slab_reduce`) leave their per-workgroup slabs
     behind; `flush` sums all of them with one launch per 40 entries (vlp3d_slab_reduce_batch).  The queue holds the
     tensors until then.  The gradients are valid only after the flush — the step driver flushes right after
-    `loss.backward()`; code that reads `.grad` inside backward hooks must not use it."""
+    `loss.backward()`; code that reads `.grad` inside backward hooks must not use it.  A backward function must hand
+    autograd a VIEW of `dst` (e.g. `dW.view(N, K)`), never `dst` itself: AccumulateGrad keeps a gradient tensor without
+    copying only when nothing else references it, and the queue does — the copy would be taken before the sum ran."""
 
     FLUSH_BYTES = int(os.environ.get("VLP3D_SLAB_FLUSH_MB", 64)) << 20  # sum while the slabs are still cache-resident
 
@@ -501,6 +508,17 @@ _slab_queue = None  # process-wide on purpose: autograd runs backward on its own
 
 def slab_queue():
     return _slab_queue
+
+
+def reduce_slabs(partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
+    """Sum one launch's slabs: through the active queue (deferred) or right away."""
+    q = _slab_queue
+    if q is None:
+        q = SlabReduceQueue()
+        q.add(partials, nblk, dst, n_mat, K, ldo, dbias, n_bias, ncol_out, rot)
+        q.flush()
+    else:
+        q.add(partials, nblk, dst, n_mat, K, ldo, dbias, n_bias, ncol_out, rot)
 
 
 class deferred_slab_reduce:

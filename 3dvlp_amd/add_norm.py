@@ -71,3 +71,33 @@ def add_norm(x, y, norm, p=0.0, training=True, mask_out=None):
     p = float(p) if training else 0.0
     _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
     return _AddNorm.apply(x, y, norm.weight, norm.bias, p, norm.eps, _CALLS[0], state(x.device), mask_out)
+
+
+class _ActDropout(Function):
+    @staticmethod
+    def forward(ctx, z, kind, p, call_id, seed, mask):
+        z2 = z.contiguous()
+        out = torch.empty_like(z2)
+        _ext.call("vlp3d_act_dropout", z2, None, z2.numel(), kind, float(p), seed, call_id, out, mask)
+        ctx.save_for_backward(z2, seed)
+        ctx.cfg = (kind, float(p), call_id)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z2, seed = ctx.saved_tensors
+        kind, p, call_id = ctx.cfg
+        dz = torch.empty_like(z2)
+        _ext.call("vlp3d_act_dropout", z2, dout.contiguous(), z2.numel(), kind, p, seed, call_id, dz, None)
+        return dz, None, None, None, None, None
+
+
+def act_dropout_supported(z):
+    return z.is_cuda and z.dtype == torch.float32 and z.numel() % 4 == 0 and 4 <= z.numel() < 2 ** 32
+
+
+def act_dropout(z, kind, p=0.0, training=True, mask_out=None):
+    """dropout_p(act(z)), act = "relu" | "gelu" (erf) — one launch each way (csrc/add_norm.hip), mask never stored."""
+    p = float(p) if training else 0.0
+    _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
+    return _ActDropout.apply(z, {"relu": 0, "gelu": 1}[kind], p, _CALLS[0], state(z.device), mask_out)

@@ -176,6 +176,41 @@ __global__ __launch_bounds__(256) void add_norm_slab_sum_kernel(const float *__r
 
 }  // namespace
 
+// ---- activation + dropout (attention.py:104-112 PositionwiseFeedForward: dropout(relu(.)); match_module.py:40-47:
+// Dropout(GELU(.))) as ONE element-wise kernel each way, with the same never-stored hash mask as add & norm.
+// kind 0 = ReLU, 1 = GELU (erf form, torch's default).  Backward recomputes act'(z) and the mask from z.
+__device__ __forceinline__ float act_fwd(float z, int kind) {
+  return kind == 0 ? fmaxf(z, 0.f) : 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_grad(float z, int kind) {
+  if (kind == 0) return z > 0.f ? 1.f : 0.f;
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+__global__ __launch_bounds__(256) void act_dropout_kernel(const float *__restrict__ z, const float *__restrict__ dout,
+                                                          long long n4, int kind, float p,
+                                                          const unsigned long long *__restrict__ seed, int call_id,
+                                                          float *__restrict__ out, unsigned char *__restrict__ mask) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const unsigned thresh = (unsigned)(p * 16777216.0f);
+  const unsigned mix = p > 0.f ? seed_mix_of(seed, call_id) : 0u;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  const float4 zv = reinterpret_cast<const float4 *>(z)[i];
+  float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (dout) g = reinterpret_cast<const float4 *>(dout)[i];
+  const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {g.x, g.y, g.z, g.w};
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool keep = p > 0.f ? keep_element(mix, (unsigned)(4 * i + j), thresh) : true;
+    const float v = dout ? gg[j] * act_grad(zz[j], kind) : act_fwd(zz[j], kind);
+    o[j] = keep ? v * inv_keep : 0.f;
+    if (mask) mask[4 * i + j] = keep ? 1 : 0;
+  }
+  reinterpret_cast<float4 *>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 extern "C" int vlp3d_add_norm_blocks(long long R) {  // workgroups (= partial slabs) of the backward kernel
   const long long waves = (R + 15) / 16;             // 16 rows per wave
   long long blocks = (waves + 3) / 4;
@@ -218,6 +253,18 @@ extern "C" int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const fl
   }
   hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
                      dgamma_dbeta);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// out = dropout_p(act(z)) (dout == NULL) or dz = dout * act'(z) * mask / (1-p) (dout given); n % 4 == 0, n < 2^32.
+extern "C" int vlp3d_act_dropout(const float *z, const float *dout, long long n, int kind, float p,
+                                 const unsigned long long *seed, int call_id, float *out, unsigned char *mask, void *stream) {
+  if (!z || !out || n < 4 || (n & 3) || n >= (1ll << 32) || kind < 0 || kind > 1 || p < 0.f || p >= 1.f || (p > 0.f && !seed))
+    return VLP3D_EINVAL;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(act_dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, dout, n4,
+                     kind, p, seed, call_id, out, mask);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

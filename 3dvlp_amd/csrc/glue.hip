@@ -423,3 +423,181 @@ extern "C" int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *s
   }
   return VLP3D_OK;
 }
+
+// ---- small linear layers the MFMA kernels do not cover ----------------------------------------------------------------
+// smallk: K <= 32 input columns (relation_module.py:64 bbox_embedding: Linear(27, 128) on 2048 proposals) — the BLAS
+//         library spent 10 us forward and 33 + 8 us on the weight / bias gradients.
+// rowdot: one output column (match_module.py:47: Linear(128, 1) on 16384 rows) — 10 us forward, 53 + 9 + 6 us backward.
+namespace {
+constexpr int SMALLK_KP = 32;
+
+// out[r][n] = (base ? base[r][n] : 0) + x[r][:K] . W[n][:K] + b[n];  block = 16 rows x N columns (N in {64,128,256})
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, const float *__restrict__ base,
+                                                         long long R, int K, int N, float *__restrict__ out) {
+  extern __shared__ int sm[];  // (one dynamic-LDS symbol per translation unit: declared int[] above)
+  float *Wt = reinterpret_cast<float *>(sm);  // [K][N]
+  float *xs = Wt + (size_t)K * N;             // [16][SMALLK_KP]
+  const long long r0 = (long long)blockIdx.x * 16;
+  for (int e = threadIdx.x; e < N * K; e += 256) {
+    const int n = e / K, k = e - n * K;
+    Wt[k * N + n] = W[e];
+  }
+  for (int e = threadIdx.x; e < 16 * SMALLK_KP; e += 256) {
+    const int rr = e / SMALLK_KP, k = e - rr * SMALLK_KP;
+    xs[e] = (k < K && r0 + rr < R) ? x[(r0 + rr) * ldx + k] : 0.f;
+  }
+  __syncthreads();
+  const int groups = 256 / N, rows_per = 16 / groups;  // N = 64: 4 groups x 4 rows; 128: 2 x 8; 256: 1 x 16
+  const int n = threadIdx.x % N, rg = threadIdx.x / N;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float wv = Wt[k * N + n];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < rows_per) acc[j] = __builtin_fmaf(xs[(rg * rows_per + j) * SMALLK_KP + k], wv, acc[j]);
+  }
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long long r = r0 + rg * rows_per + j;
+    if (j < rows_per && r < R) out[r * N + n] = (base ? base[r * N + n] : 0.f) + acc[j] + bv;
+  }
+}
+
+// slab[blockIdx.x] = [N x 32 partial dW (columns >= K zero) | N partial db] over this block's 64 rows
+__global__ __launch_bounds__(256) void smallk_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, int ldx,
+                                                         long long R, int K, int N, float *__restrict__ slabs) {
+  __shared__ float xs[64 * SMALLK_KP];
+  const long long r0 = (long long)blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * SMALLK_KP; e += 256) {
+    const int rr = e / SMALLK_KP, k = e - rr * SMALLK_KP;
+    xs[e] = (k < K && r0 + rr < R) ? x[(r0 + rr) * ldx + k] : 0.f;
+  }
+  __syncthreads();
+  float *slab = slabs + (size_t)blockIdx.x * ((size_t)N * SMALLK_KP + N);
+  const int per = 256 / 2;  // threads per k-half
+  const int kh = threadIdx.x / per;
+  for (int n = threadIdx.x % per; n < N; n += per) {
+    float acc[16], db = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int rr = 0; rr < 64; ++rr) {
+      const float d = r0 + rr < R ? dy[(r0 + rr) * N + n] : 0.f;
+      db += d;
+      const float4 *xp = reinterpret_cast<const float4 *>(xs + rr * SMALLK_KP + 16 * kh);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = xp[q];
+        acc[4 * q] = __builtin_fmaf(d, v.x, acc[4 * q]);
+        acc[4 * q + 1] = __builtin_fmaf(d, v.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = __builtin_fmaf(d, v.z, acc[4 * q + 2]);
+        acc[4 * q + 3] = __builtin_fmaf(d, v.w, acc[4 * q + 3]);
+      }
+    }
+    float4 *o = reinterpret_cast<float4 *>(slab + (size_t)n * SMALLK_KP + 16 * kh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (kh == 0) slab[(size_t)N * SMALLK_KP + n] = db;
+  }
+}
+
+// y[r] = x[r][:K] . w + b: half a wave per row (32 lanes x float4 = 128 columns per pass)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ b, long long R, int K,
+                                                         float *__restrict__ y) {
+  const long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int c = threadIdx.x & 31;
+  float s = 0.f;
+  if (r < R)
+    for (int k = 4 * c; k < K; k += 128) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + r * K + k), wv = *reinterpret_cast<const float4 *>(w + k);
+      s += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (r < R && c == 0) y[r] = s + (b ? b[0] : 0.f);
+}
+
+// dx[r][k] = dy[r] w[k];  slab[blockIdx.x] = [partial dw (K) | partial db, 0, 0, 0] over the block's rows (K <= 128)
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                         const float *__restrict__ w, long long R, int K, int rows_per_block,
+                                                         float *__restrict__ dx, float *__restrict__ slabs) {
+  __shared__ float4 red[8][32];
+  __shared__ float redb[8];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const bool on = 4 * c < K;
+  const float4 wv = on ? *reinterpret_cast<const float4 *>(w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float db = 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  for (int i = rg; i < rows_per_block; i += 8) {
+    const long long r = r0 + i;
+    if (r >= R) break;
+    const float d = dy[r];
+    db += d;
+    if (on) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + r * K + 4 * c);
+      acc.x = __builtin_fmaf(d, xv.x, acc.x); acc.y = __builtin_fmaf(d, xv.y, acc.y);
+      acc.z = __builtin_fmaf(d, xv.z, acc.z); acc.w = __builtin_fmaf(d, xv.w, acc.w);
+      if (dx) *reinterpret_cast<float4 *>(dx + r * K + 4 * c) = make_float4(d * wv.x, d * wv.y, d * wv.z, d * wv.w);
+    }
+  }
+  red[rg][c] = acc;
+  if (c == 0) redb[rg] = db;
+  __syncthreads();
+  if (rg == 0) {
+    float4 t = red[0][c];
+    float tb = redb[0];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+      const float4 v = red[g][c];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      tb += redb[g];
+    }
+    float *slab = slabs + (size_t)blockIdx.x * (K + 4);
+    if (on) *reinterpret_cast<float4 *>(slab + 4 * c) = t;
+    if (c == 0) *reinterpret_cast<float4 *>(slab + K) = make_float4(tb, 0.f, 0.f, 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int vlp3d_smallk_fwd(const float *x, int ldx, const float *W, const float *bias, const float *base, long long R,
+                                int K, int N, float *out, void *stream) {
+  if (!x || !W || !out || R < 1 || K < 1 || K > SMALLK_KP || ldx < K || (N != 64 && N != 128 && N != 256)) return VLP3D_EINVAL;
+  const size_t lds = ((size_t)K * N + 16 * SMALLK_KP) * sizeof(float);
+  hipLaunchKernelGGL(smallk_fwd_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, bias,
+                     base, R, K, N, out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+/* slabs: ceil(R/64) x (N*32 + N) floats; sum them with vlp3d_slab_reduce_batch {nblk = ceil(R/64), n_mat = N*32, K = 32,
+ * ldo = K_true, ncol_out = K_true, n_bias = N} */
+extern "C" int vlp3d_smallk_bwd(const float *dy, const float *x, int ldx, long long R, int K, int N, float *slabs, void *stream) {
+  if (!dy || !x || !slabs || R < 1 || K < 1 || K > SMALLK_KP || ldx < K || N < 4 || (N & 3)) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, x, ldx, R, K, N,
+                     slabs);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_rowdot_fwd(const float *x, const float *w, const float *b, long long R, int K, float *y, void *stream) {
+  if (!x || !w || !y || R < 1 || K < 4 || (K & 3)) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((unsigned)((R * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, R, K, y);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+/* slabs: nblk x (K + 4) floats, nblk = ceil(R / rows_per_block); sum with vlp3d_slab_reduce_batch {n_mat = K + 4, K = K + 4,
+ * ldo = K + 4}: [dw (K) | db, 0, 0, 0] */
+extern "C" int vlp3d_rowdot_bwd(const float *dy, const float *x, const float *w, long long R, int K, int rows_per_block,
+                                float *dx, float *slabs, void *stream) {
+  if (!dy || !x || !w || !slabs || R < 1 || K < 4 || (K & 3) || K > 128 || rows_per_block < 8) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((unsigned)((R + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+                     (hipStream_t)stream, dy, x, w, R, K, rows_per_block, dx, slabs);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

@@ -457,7 +457,11 @@ class RelationModule(nn.Module):
             else:
                 dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)
             features = features + _linear(obj_feat, self.obj_embedding[i].weight, self.obj_embedding[i].bias) * 0.1
-            features = features + self.bbox_embedding[i](manual_bbox_feat)
+            be = self.bbox_embedding[i]
+            if glue.smallk_supported(manual_bbox_feat, be.weight) and not torch.is_autocast_enabled("cuda"):
+                features = glue.small_linear(manual_bbox_feat, be.weight, be.bias, base=features)  # add folded in
+            else:
+                features = features + be(manual_bbox_feat)
             features = self.self_attn[i](features, features, features, attention_weights=dist_weights, way="add")
 
         data_dict["dist_weights"] = dist_weights

@@ -142,3 +142,84 @@ class _CopyPaste(Function):
 def copy_paste(features, obj_mask, coin):
     """match_module.py:97-121 gated by `coin < 0.5` (device scalar): features (B,K,D) fp32, obj_mask (B,K) int64."""
     return _CopyPaste.apply(features, obj_mask, coin.reshape(1).float())
+
+
+class _SmallK(Function):
+    """base + x[:, :K] @ W.T + b for K <= 32 (csrc/glue.hip: smallk); x carries no gradient (input data)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, base):
+        N, K = weight.shape
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        R = x2.shape[0]
+        out = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        b2 = None if base is None else base.reshape(R, N).contiguous()
+        _ext.call("vlp3d_smallk_fwd", x2, x2.shape[1], weight.contiguous(), bias, b2, R, K, N, out)
+        ctx.save_for_backward(x2)
+        ctx.cfg = (R, K, N, bias is not None, base is not None, None if base is None else base.shape)
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2,) = ctx.saved_tensors
+        R, K, N, has_bias, has_base, bshape = ctx.cfg
+        d2 = dout.reshape(R, N).contiguous()
+        nblk = (R + 63) // 64
+        slabs = torch.empty((nblk, N * 32 + N), dtype=torch.float32, device=dout.device)
+        _ext.call("vlp3d_smallk_bwd", d2, x2, x2.shape[1], R, K, N, slabs)
+        dW = torch.empty((N, K), dtype=torch.float32, device=dout.device)
+        db = torch.empty((N,), dtype=torch.float32, device=dout.device)
+        _ext.reduce_slabs(slabs, nblk, dW, N * 32, 32, K, db, N, ncol_out=K)
+        # VIEWS on purpose (SlabReduceQueue): the queue still references dW / db, and autograd copies — at once, before the
+        # deferred sum has run — a gradient tensor that anything else references
+        return None, dW.view(N, K), (db.view(N) if has_bias else None), (dout.reshape(bshape) if has_base else None)
+
+
+def smallk_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.shape[1] <= 32 and weight.shape[0] in (64, 128, 256)
+            and not x.requires_grad)
+
+
+def small_linear(x, weight, bias=None, base=None):
+    """base + F.linear(x, weight, bias) for weight (N, K <= 32): one launch forward, one + the batched slab sum backward."""
+    return _SmallK.apply(x, weight, bias, base)
+
+
+class _RowDot(Function):
+    """F.linear(x, weight (1,K), bias (1)) -> (R,) (csrc/glue.hip: rowdot)."""
+    ROWS_PER_BLOCK = 64
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).contiguous()
+        R = x2.shape[0]
+        w = weight.reshape(K).contiguous()
+        y = torch.empty((R,), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_rowdot_fwd", x2, w, bias, R, K, y)
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (R, K, bias is not None, x.shape, weight.shape)
+        return y.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        R, K, has_bias, xshape, wshape = ctx.cfg
+        d = dy.reshape(R).contiguous()
+        rpb = _RowDot.ROWS_PER_BLOCK
+        nblk = (R + rpb - 1) // rpb
+        slabs = torch.empty((nblk, K + 4), dtype=torch.float32, device=dy.device)
+        dx = torch.empty((R, K), dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        _ext.call("vlp3d_rowdot_bwd", d, x2, w, R, K, rpb, dx, slabs)
+        dwb = torch.empty((K + 4,), dtype=torch.float32, device=dy.device)
+        _ext.reduce_slabs(slabs, nblk, dwb, K + 4, K + 4, K + 4)
+        return (None if dx is None else dx.view(xshape)), dwb[:K].view(wshape), (dwb[K:K + 1] if has_bias else None)
+
+
+def rowdot_supported(x, weight):
+    K = x.shape[-1]
+    return x.is_cuda and x.dtype == torch.float32 and weight.shape[0] == 1 and K % 4 == 0 and 4 <= K <= 128
+
+
+def rowdot(x, weight, bias=None):
+    return _RowDot.apply(x, weight, bias)

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as _ext
-from . import glue
+from . import add_norm, glue
 from .mfma_linear import linear as _linear
 from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
 
@@ -94,8 +94,20 @@ class MatchModule(nn.Module):
 
         feature1_agg = feature1.reshape(B * L * K, -1)
         x = feature1_agg
-        for layer in self.match:  # nn.Sequential of Linear / GELU / Dropout: the Linears run on the MFMA kernels
-            x = _linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+        mods, i = list(self.match), 0
+        while i < len(mods):  # nn.Sequential of Linear / GELU / Dropout: Linears on the MFMA kernels, GELU+Dropout fused
+            layer = mods[i]
+            if isinstance(layer, nn.Linear) and glue.rowdot_supported(x, layer.weight) and not torch.is_autocast_enabled("cuda"):
+                x = glue.rowdot(x, layer.weight, layer.bias)  # Linear(128, 1): a row dot product
+            elif isinstance(layer, nn.Linear):
+                x = _linear(x, layer.weight, layer.bias)
+            elif (isinstance(layer, nn.GELU) and layer.approximate == "none" and i + 1 < len(mods)
+                  and isinstance(mods[i + 1], nn.Dropout) and add_norm.act_dropout_supported(x)):
+                x = add_norm.act_dropout(x, "gelu", mods[i + 1].p, self.training)
+                i += 1
+            else:
+                x = layer(x)
+            i += 1
         confidence = x.squeeze(1).view(B * L, K)
 
         if self.use_lang_emb:

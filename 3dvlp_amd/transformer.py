@@ -123,8 +123,12 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(p=drop_prob)
 
     def forward(self, x):
-        h = self.relu(_linear(x, self.linear1.weight, self.linear1.bias))
-        return _linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
+        z = _linear(x, self.linear1.weight, self.linear1.bias)
+        if add_norm.act_dropout_supported(z) and not torch.is_autocast_enabled("cuda"):
+            h = add_norm.act_dropout(z, "relu", self.dropout.p, self.training)  # relu + dropout: one launch each way
+        else:
+            h = self.dropout(self.relu(z))
+        return _linear(h, self.linear2.weight, self.linear2.bias)
 
 
 class CrossAttentionDecoderLayer(nn.Module):

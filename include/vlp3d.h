@@ -422,6 +422,26 @@ int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, 
 int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
 
+/* dropout_p(act(z)) and its backward in one element-wise launch each (attention.py:104-112: dropout(relu(.)) of the
+ * feed-forward block; match_module.py:40-47: Dropout(GELU(.))).  kind 0 = ReLU, 1 = GELU (erf).  The keep mask is the
+ * add & norm hash of (seed word, call_id, element) — never stored; `mask` (optional, n bytes) receives it for tests.
+ * dout == NULL: out = forward value; dout != NULL: out = dz.  n % 4 == 0, n < 2^32. */
+int vlp3d_act_dropout(const float *z, const float *dout, long long n, int kind, float p, const unsigned long long *seed,
+                      int call_id, float *out, unsigned char *mask, void *stream);
+
+/* Small linear layers outside the MFMA kernels' shapes (csrc/glue.hip):
+ * smallk: out (R,N) = base (R,N, optional) + x[:, :K] W^T + b,  K <= 32, N in {64,128,256}  (relation_module.py:64
+ *         bbox_embedding = Linear(27,128)); backward writes ceil(R/64) slabs [N x 32 | N] — sum them with
+ *         vlp3d_slab_reduce_batch {n_mat = 32 N, K = 32, ldo = ncol_out = K, n_bias = N}.
+ * rowdot: y (R) = x (R,K) w + b  (match_module.py:47 Linear(128,1)); backward writes dx (optional) and
+ *         ceil(R/rows_per_block) slabs [dw (K) | db,0,0,0] — vlp3d_slab_reduce_batch {n_mat = K = ldo = K + 4}. */
+int vlp3d_smallk_fwd(const float *x, int ldx, const float *W, const float *bias, const float *base, long long R, int K, int N,
+                     float *out, void *stream);
+int vlp3d_smallk_bwd(const float *dy, const float *x, int ldx, long long R, int K, int N, float *slabs, void *stream);
+int vlp3d_rowdot_fwd(const float *x, const float *w, const float *b, long long R, int K, float *y, void *stream);
+int vlp3d_rowdot_bwd(const float *dy, const float *x, const float *w, long long R, int K, int rows_per_block, float *dx,
+                     float *slabs, void *stream);
+
 /* count device-to-device copies in one launch (descs: HOST array, consumed during the call; overlapping entries are
  * the caller's problem).  Replaces torch._foreach_copy_ for the hand-over of the prepared backbone geometry. */
 typedef struct {

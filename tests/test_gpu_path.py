@@ -868,3 +868,72 @@ def test_deferred_slab_reduce_equals_immediate():
         noise = _rel(grads[1][n], g0)
         g1 = grads[2][n]
         assert _rel(g1, g0) <= max(2e-5, 3 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
+
+
+@pytest.mark.parametrize("kind,p", [("relu", 0.1), ("gelu", 0.5), ("gelu", 0.0)])
+def test_act_dropout_equals_torch_with_same_mask(kind, p):
+    """dropout(relu(.)) (attention.py:104-112) / Dropout(GELU(.)) (match_module.py:40-47) as one launch each way: values and
+    gradient against torch evaluating the same formula with the kernel's own keep mask; keep rate; mask redraw."""
+    an = importlib.import_module("3dvlp_amd.add_norm")
+    torch.manual_seed(4)
+    z = torch.randn(4096, 128, device="cuda", requires_grad=True)
+    mask = torch.empty(z.shape, dtype=torch.uint8, device="cuda")
+    out = an.act_dropout(z, kind, p, True, mask_out=mask)
+    g = torch.randn_like(out)
+    out.backward(g)
+    z2 = z.detach().clone().requires_grad_(True)
+    act = torch.relu(z2) if kind == "relu" else torch.nn.functional.gelu(z2)
+    ref = act * mask.float() / (1.0 - p)
+    ref.backward(g)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(z.grad, z2.grad, rtol=1e-4, atol=1e-6)
+    if p > 0:
+        assert abs(mask.float().mean().item() - (1 - p)) < 0.01
+        an.advance(z.device)
+        mask2 = torch.empty_like(mask)
+        an.act_dropout(z.detach(), kind, p, True, mask_out=mask2)
+        assert (mask2 != mask).float().mean().item() > 0.05
+    else:
+        assert bool(mask.all())
+    torch.testing.assert_close(an.act_dropout(z.detach(), kind, p, False), torch.relu(z.detach()) if kind == "relu"
+                               else torch.nn.functional.gelu(z.detach()), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_small_linears_equal_f_linear(deferred):
+    """Linear(27,128) added onto a base (relation_module.py:64,118) and Linear(128,1) (match_module.py:47) on the glue
+    kernels vs F.linear in fp64: values, input / base gradients, weight and bias gradients (immediate and queued sums)."""
+    glue = importlib.import_module("3dvlp_amd.glue")
+    ext = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(5)
+    dev = "cuda"
+    x = torch.randn(8, 256, 27, device=dev)
+    W = (torch.randn(128, 27, device=dev) * 0.2).requires_grad_(True)
+    b = torch.randn(128, device=dev).requires_grad_(True)
+    base = torch.randn(8, 256, 128, device=dev).requires_grad_(True)
+    xr = torch.randn(3000, 128, device=dev).requires_grad_(True)
+    wr = (torch.randn(1, 128, device=dev) * 0.2).requires_grad_(True)
+    br = torch.randn(1, device=dev).requires_grad_(True)
+    assert glue.smallk_supported(x, W) and glue.rowdot_supported(xr, wr)
+
+    def run():
+        o1 = glue.small_linear(x, W, b, base=base)
+        o2 = glue.rowdot(xr, wr, br)
+        return o1, o2
+    o1, o2 = run()
+    g1, g2 = torch.randn_like(o1), torch.randn_like(o2)
+    if deferred:
+        with ext.deferred_slab_reduce():
+            torch.autograd.backward([o1, o2], [g1, g2])
+    else:
+        torch.autograd.backward([o1, o2], [g1, g2])
+    got = [t.grad.clone() for t in (W, b, base, xr, wr, br)]
+    d = lambda t: t.detach().double().requires_grad_(True)
+    W64, b64, base64, xr64, wr64, br64 = (d(t) for t in (W, b, base, xr, wr, br))
+    r1 = base64 + torch.nn.functional.linear(x.double(), W64, b64)
+    r2 = torch.nn.functional.linear(xr64, wr64, br64)
+    torch.autograd.backward([r1, r2], [g1.double(), g2.double()])
+    torch.testing.assert_close(o1.double(), r1.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(o2.double(), r2.detach(), rtol=1e-5, atol=1e-5)
+    for a, r in zip(got, (W64, b64, base64, xr64, wr64, br64)):
+        assert _rel(a, r.grad) < 1e-5, _rel(a, r.grad)
