@@ -58,6 +58,7 @@ SIGNATURES = {
     "vlp3d_joint_loss_rows": [_i, _i, _i, _i],
     "vlp3d_joint_loss_fwd": [_vp] * 25 + [_i] * 8 + [_f] * 6 + [_i] + [_vp] * 6 + [_vp],
     "vlp3d_joint_loss_bwd": [_vp] * 25 + [_i] * 8 + [_f] * 6 + [_i] + [_vp] * 5 + [_vp] * 10 + [_vp],
+    "vlp3d_joint_loss_report": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_contrast_fwd": [_vp] * 9 + [_i] * 4 + [_vp, _vp, _vp],
     "vlp3d_contrast_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 7 + [_vp],
     "vlp3d_add_norm_blocks": [ctypes.c_longlong],

@@ -585,3 +585,37 @@ extern "C" int vlp3d_joint_loss_bwd(JL_ARGS, const double *sums, const int *assi
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
+
+// The reporting tensors the reference leaves in data_dict (loss_detection.py:101-108, loss_grounding.py:84-92) in the
+// dtypes its callers expect, from the kernel's compact outputs — one launch instead of eleven framework ones:
+//   object_assignment i64 (B,K) | objectness_label i64 (B,K) | objectness_mask f32 (B,K) | cluster_labels f32 (B,L,K)
+namespace {
+__global__ __launch_bounds__(256) void jl_report_kernel(const int *__restrict__ assign, const int *__restrict__ objlab,
+                                                        const int *__restrict__ rowinfo, int B, int K, int L,
+                                                        long long *__restrict__ assign64, long long *__restrict__ label64,
+                                                        float *__restrict__ mask, float *__restrict__ cluster_labels) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < (long long)B * K) {
+    assign64[t] = assign[t];
+    label64[t] = objlab[t] & 1;
+    mask[t] = (float)((objlab[t] >> 1) & 1);
+  }
+  if (t < (long long)B * L * K) {
+    const long long row = t / K;
+    const int k = (int)(t - row * K);
+    cluster_labels[t] = (rowinfo[row * 4] != 0 && rowinfo[row * 4 + 1] == k) ? 1.f : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int vlp3d_joint_loss_report(const int *assign, const int *objlab, const int *rowinfo, int B, int K, int L,
+                                       long long *assign64, long long *label64, float *mask, float *cluster_labels,
+                                       void *stream) {
+  if (!assign || !objlab || !rowinfo || !assign64 || !label64 || !mask || !cluster_labels || B < 1 || K < 1 || L < 1)
+    return VLP3D_EINVAL;
+  const long long n = (long long)B * K * (L > 1 ? L : 1);
+  hipLaunchKernelGGL(jl_report_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, assign, objlab,
+                     rowinfo, B, K, L, assign64, label64, mask, cluster_labels);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

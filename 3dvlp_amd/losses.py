@@ -316,12 +316,16 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
         for i, name in enumerate(OUT_NAMES):
             if name != "loss":
                 d[name] = comp[i]
-        d["object_assignment"] = assign.long()
-        d["objectness_label"], d["objectness_mask"] = (objlab & 1).long(), (objlab >> 1).float()
         B, L = rowinfo.shape[:2]
         K = d["cluster_ref"].shape[-1]
-        # cluster_labels (hard one-hot of the best-IoU proposal, zero rows where no proposal reaches 0.25)
-        d["cluster_labels"] = F.one_hot(rowinfo[..., 1].long(), K).float() * rowinfo[..., 0:1].float()
+        # reporting tensors in the reference's dtypes; cluster_labels = hard one-hot of the best-IoU proposal, zero rows
+        # where no proposal reaches 0.25 (one launch: csrc/joint_loss.hip jl_report)
+        a64 = torch.empty((B, K), dtype=torch.int64, device=dev)
+        l64 = torch.empty((B, K), dtype=torch.int64, device=dev)
+        msk = torch.empty((B, K), dtype=torch.float32, device=dev)
+        cl = torch.empty((B, L, K), dtype=torch.float32, device=dev)
+        _ext.call("vlp3d_joint_loss_report", assign, objlab, rowinfo, B, K, L, a64, l64, msk, cl)
+        d["object_assignment"], d["objectness_label"], d["objectness_mask"], d["cluster_labels"] = a64, l64, msk, cl
         loss = out[9]
     elif impl == "torch":
         vote_loss = compute_vote_loss(d)

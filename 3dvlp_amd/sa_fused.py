@@ -112,9 +112,15 @@ class FusedSAMLP(Function):
         # BN-backward reductions: per-workgroup slabs for layers 1-2 (written by the MASK epilogue), one zeroed
         # (2 x C) buffer for the last layer (pool_tstats adds into it)
         nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))
+        # ONE zero-filled arena per backward (one fill launch): [t3 (2 x C3 fp64) | d(features) | d(xyz) | d(new_xyz)]
+        n_t3 = 4 * cout[2]
+        n_df = B * N * C if need[3] else 0
+        n_dx = B * N * 3 if need[0] else 0
+        n_dn = B * M * 3 if need[1] else 0
+        arena = torch.zeros((n_t3 + n_df + n_dx + n_dn,), dtype=torch.float32, device=dev)
         t = [torch.empty((nslab, 2, cout[0]), dtype=torch.float64, device=dev),
              torch.empty((nslab, 2, cout[1]), dtype=torch.float64, device=dev),
-             torch.zeros((1, 2, cout[2]), dtype=torch.float64, device=dev)]
+             arena[:n_t3].view(torch.float64).view(1, 2, cout[2])]
         tn = [nslab, nslab, 1]
 
         # layer 3: the masked gradient lives only at the selected sample of each ball — it is synthesised inside the
@@ -155,9 +161,10 @@ class FusedSAMLP(Function):
                     dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
                 if need[0] or need[1] or need[3]:
                     kpad = WTs[0].shape[0]
-                    dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dev) if need[3] else None
-                    dxyz = torch.zeros((B, N, 3), dtype=torch.float32, device=dev) if need[0] else None
-                    dnew = torch.zeros((B, M, 3), dtype=torch.float32, device=dev) if need[1] else None
+                    o = n_t3
+                    dfeat = arena[o:o + n_df].view(B, N, C) if need[3] else None
+                    dxyz = arena[o + n_df:o + n_df + n_dx].view(B, N, 3) if need[0] else None
+                    dnew = arena[o + n_df + n_dx:].view(B, M, 3) if need[1] else None
                     _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
                               dxyz, dnew, bf)
         return (dxyz, dnew, None, dfeat, None, None, None, None, *dparams)

@@ -422,6 +422,12 @@ int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, 
 int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
 
+/* data_dict's reporting tensors from vlp3d_joint_loss_fwd's compact outputs, in the reference's dtypes: object_assignment
+ * i64 (B,K), objectness_label i64 (B,K), objectness_mask f32 (B,K) (loss_detection.py:101-108), cluster_labels f32 (B,L,K)
+ * (hard one-hot of the best-IoU proposal, zero rows below IoU 0.25; loss_grounding.py:84-92). */
+int vlp3d_joint_loss_report(const int *assign, const int *objlab, const int *rowinfo, int B, int K, int L,
+                            long long *assign64, long long *label64, float *mask, float *cluster_labels, void *stream);
+
 /* dropout_p(act(z)) and its backward in one element-wise launch each (attention.py:104-112: dropout(relu(.)) of the
  * feed-forward block; match_module.py:40-47: Dropout(GELU(.))).  kind 0 = ReLU, 1 = GELU (erf).  The keep mask is the
  * add & norm hash of (seed word, call_id, element) — never stored; `mask` (optional, n bytes) receives it for tests.
