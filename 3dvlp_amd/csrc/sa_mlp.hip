@@ -325,6 +325,47 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   if (EPI == STORE || EPI == MASK) block_stats_to_slab<COUT>(s1, s2, (EPI == STORE) ? a.stats : a.tstats, r, half, wave);
 }
 
+// Plain linear layer, fp32 in memory, bf16 MFMA operands (rounded in registers), fp32 accumulation: the timing-
+// configuration form of row_gemm<float, 32, PLAIN, BIAS / BIAS_WT> (64 exact-fp32 MFMA steps per 32 x 32 x 128 tile -> 8).
+// A wave owns one 32 x 32 output tile; grid = (row tiles / 4, N / 32).
+template <bool WT>
+__global__ __launch_bounds__(256) void linear_bf16_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
+                                                          int K, int ldw, const float *__restrict__ bias, long long R,
+                                                          float *__restrict__ Y, int ldy) {
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ntiles = R / 32;
+  const int c0 = blockIdx.y * 32;
+  const float bv = bias ? bias[c0 + r] : 0.f;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const float *xr = X + (tile * 32 + r) * ldx + 8 * half;
+    const float *wr = WT ? W + (long long)(8 * half) * ldw + c0 + r : W + (long long)(c0 + r) * K + 8 * half;
+    f32x16 acc = zero16();
+    const int ng = K / 16;
+#pragma unroll 4
+    for (int g = 0; g < ng; ++g) {
+      const float4 a0 = ld4(xr + 16 * g), a1 = ld4(xr + 16 * g + 4);
+      float4 b0, b1;
+      if (WT) {
+        const float *wp = wr + (long long)(16 * g) * ldw;
+        b0 = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+        b1 = make_float4(wp[4 * ldw], wp[5 * ldw], wp[6 * ldw], wp[7 * ldw]);
+      } else {
+        b0 = ld4(wr + 16 * g);
+        b1 = ld4(wr + 16 * g + 4);
+      }
+      bf16x8 av, bw;
+      av[0] = bf16_bits(a0.x); av[1] = bf16_bits(a0.y); av[2] = bf16_bits(a0.z); av[3] = bf16_bits(a0.w);
+      av[4] = bf16_bits(a1.x); av[5] = bf16_bits(a1.y); av[6] = bf16_bits(a1.z); av[7] = bf16_bits(a1.w);
+      bw[0] = bf16_bits(b0.x); bw[1] = bf16_bits(b0.y); bw[2] = bf16_bits(b0.z); bw[3] = bf16_bits(b0.w);
+      bw[4] = bf16_bits(b1.x); bw[5] = bf16_bits(b1.y); bw[6] = bf16_bits(b1.z); bw[7] = bf16_bits(b1.w);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y[(tile * 32 + acc_row(i, half)) * ldy + c0 + r] = acc[i] + bv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // row_gemm_lds (bf16): same products, loaders and epilogues as row_gemm, but the operands reach the matrix
 // cores through LDS so that every global access is a full, coalesced row segment:
@@ -981,14 +1022,17 @@ struct WgradArgs {
   int colsum;       // fp32 only: also reduce the columns of dY (the bias gradient of a linear layer) into slab[COUT*K..]
 };
 
-template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD>  // MAXT = output tiles per wave
+// BFM (fp32 storage only): stage the fp32 tiles as bf16 and contract with the bf16 MFMA — the timing configuration of the
+// plain linear layers (same operand rounding as the bf16 grouped MLPs; accumulation stays fp32).
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>  // MAXT = output tiles per wave
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KP = w.KP, K = w.src.K, NKT = KP / 32, NT = NCT * NKT;
-  constexpr bool BF = sizeof(T) == 2;  // bf16 storage: both tiles are staged as bf16 and contracted with the bf16 MFMA
+  constexpr bool BF = sizeof(T) == 2 || BFM;  // both tiles are staged as bf16 and contracted with the bf16 MFMA
+  constexpr bool ST16 = sizeof(T) == 2;       // bf16 STORAGE: 8-column (16-byte) staging elements
   float *lds_dy = lds;               // fp32: [32][COUT]
   float *lds_a = lds + 32 * COUT;    // fp32: [32][KP]
   // bf16: [32][COUT + 4] and [32][KP + 4] shorts — row strides of 8 (mod 16) bytes put the two lane halves (rows +8)
@@ -1021,7 +1065,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   // bf16 storage: 8-column (16-byte) staging elements for dY and for a BN+ReLU / plain A operand (the gathered operand is
   // fp32: its 4-column elements already are 16 bytes)
   constexpr int NE_DY8 = (32 * COUT / 8 + 255) / 256;
-  constexpr bool A8 = BF && LOADER != GATHER;
+  constexpr bool A8 = ST16 && LOADER != GATHER;
   // staging elements of the A tile per thread = 32*KP/4/256 = KP/32 = NKT <= 4*MAXT/NCT (MAXT >= NCT*NKT/4): sized by
   // the instantiation instead of the worst case 9 (five float4 of dead loads and registers at K = 128)
   constexpr int MAXE_A = (4 * MAXT / NCT) < 1 ? 1 : ((4 * MAXT / NCT) < 9 ? (4 * MAXT / NCT) : 9);
@@ -1031,9 +1075,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int kfs = (LOADER == GATHER) ? 0 : __builtin_ctz(kf4);
   auto row_of = [&](int e) -> int { return LOADER == GATHER ? e / kf4 : e >> kfs; };
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
-  float4 vdy[BF ? 1 : NE_DY], va[A8 ? 1 : MAXE_A], vt;
+  float4 vdy[ST16 ? 1 : NE_DY], va[A8 ? 1 : MAXE_A], vt;
   constexpr int MAXE_A8 = (MAXE_A + 1) / 2;
-  uint4 pdy[BF ? NE_DY8 : 1], pa8[A8 ? MAXE_A8 : 1];
+  uint4 pdy[ST16 ? NE_DY8 : 1], pa8[A8 ? MAXE_A8 : 1];
   const int kf8 = KF / 8, nef8 = 32 * kf8, kfs8 = A8 ? __builtin_ctz(kf8 > 0 ? kf8 : 1) : 0;
 
   // column-block mode (gridDim.y > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
@@ -1041,7 +1085,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const int coff = blockIdx.y * COUT;
   DyConsts<T> dyk, dyk2;
   if (DYL == BNBWD) {
-    if (BF) {
+    if (ST16) {
       dyk.load(w.dy, coff + (threadIdx.x % (COUT / 8)) * 8);
       dyk2.load(w.dy, coff + (threadIdx.x % (COUT / 8)) * 8 + 4);
     } else {
@@ -1088,7 +1132,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       }
     }
     const long long pbase = (long long)scene * w.src.N;
-    if constexpr (BF) {
+    if constexpr (ST16) {
 #pragma unroll
       for (int j = 0; j < NE_DY8; ++j) {
         const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
@@ -1155,13 +1199,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
     __syncthreads();  // the previous tile's MFMA reads are done
     if (BF) {
       // rows of the LDS tiles are 8 (mod 16) bytes apart (bank layout of the operand reads): two 8-byte stores per element
+      if constexpr (ST16) {
 #pragma unroll
-      for (int j = 0; j < NE_DY8; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        if (e < 32 * COUT / 8) {
-          short *q = ldb_dy + (e / (COUT / 8)) * RSD + (e % (COUT / 8)) * 8;
-          *reinterpret_cast<uint2 *>(q) = make_uint2(pdy[j].x, pdy[j].y);
-          *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pdy[j].z, pdy[j].w);
+        for (int j = 0; j < NE_DY8; ++j) {
+          const int e = threadIdx.x + 256 * j;
+          if (e < 32 * COUT / 8) {
+            short *q = ldb_dy + (e / (COUT / 8)) * RSD + (e % (COUT / 8)) * 8;
+            *reinterpret_cast<uint2 *>(q) = make_uint2(pdy[j].x, pdy[j].y);
+            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pdy[j].z, pdy[j].w);
+          }
+        }
+      } else {  // fp32 storage, bf16 MFMA: 4-column (16-byte) elements rounded here
+#pragma unroll
+        for (int j = 0; j < NE_DY; ++j) {
+          const int e = threadIdx.x + 256 * j;
+          *reinterpret_cast<uint2 *>(ldb_dy + (e / (COUT / 4)) * RSD + (e % (COUT / 4)) * 4) = pack4(vdy[j]);
         }
       }
       if constexpr (A8) {
@@ -1209,9 +1261,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
       fetch(tile + 1);
       fetch_idx(min(tile + 2, t1 - 1));
     }
-    if (!BF && w.colsum && (int)threadIdx.x < COUT) {
+    if (!ST16 && w.colsum && (int)threadIdx.x < COUT) {
+      if (BFM) {  // the staged tile is bf16: the bias gradient sums the rounded values
 #pragma unroll 8
-      for (int row = 0; row < 32; ++row) csum += lds_dy[row * COUT + threadIdx.x];
+        for (int row = 0; row < 32; ++row)
+          csum += __uint_as_float(((unsigned)(unsigned short)ldb_dy[row * RSD + threadIdx.x]) << 16);
+      } else {
+#pragma unroll 8
+        for (int row = 0; row < 32; ++row) csum += lds_dy[row * COUT + threadIdx.x];
+      }
     }
     if (BF) {
       // contraction over the 32 rows in two 16-row steps; lane (col, half) gathers its column's 8 rows
@@ -1248,7 +1306,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   const long long ntot = (long long)COUT * gridDim.y;
   float *slab0 = w.partials + (long long)blockIdx.x * (ntot * K + (w.colsum ? ntot : 0));
   float *slab = slab0 + (long long)coff * K;
-  if (!BF && w.colsum && (int)threadIdx.x < COUT) slab0[ntot * K + coff + threadIdx.x] = csum;
+  if (!ST16 && w.colsum && (int)threadIdx.x < COUT) slab0[ntot * K + coff + threadIdx.x] = csum;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = wave + 4 * i;
@@ -1575,16 +1633,16 @@ int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStre
   return VLP3D_EINVAL;
 }
 
-template <typename T, int LOADER, int COUT, int DYL = BNBWD>
+template <typename T, int LOADER, int COUT, int DYL = BNBWD, bool BFM = false>
 int launch_wgrad_c(const WgradArgs &w, hipStream_t s, dim3 grid, size_t lds) {
   const int per_wave = ((COUT / 32) * (w.KP / 32) + 3) / 4;
   const dim3 block(256);
   // fewer accumulator registers -> more resident workgroups -> more loads in flight (the kernel is latency bound)
-  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1, DYL>), grid, block, lds, s, w);
-  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3, DYL>), grid, block, lds, s, w);
-  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4, DYL>), grid, block, lds, s, w);
-  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6, DYL>), grid, block, lds, s, w);
-  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9, DYL>), grid, block, lds, s, w);
+  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1, DYL, BFM>), grid, block, lds, s, w);
+  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3, DYL, BFM>), grid, block, lds, s, w);
+  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4, DYL, BFM>), grid, block, lds, s, w);
+  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6, DYL, BFM>), grid, block, lds, s, w);
+  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9, DYL, BFM>), grid, block, lds, s, w);
   else return VLP3D_EINVAL;
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
@@ -1814,8 +1872,14 @@ extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const flo
 // Y (R x N) = X (R x K) W^T + bias;  W (N x K) row-major, bias (N) or NULL.  R % 32 == 0, K % 8 == 0,
 // N in {32, 64, 128, 160, 256, 288}.
 extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
-                                void *stream) {
+                                int bf16_mma, void *stream) {
   if (!X || !W || !Y || R < 32 || (R & 31) || K < 8 || (K & 7)) return VLP3D_EINVAL;
+  if (bf16_mma && R <= 65536 && N % 32 == 0 && N >= 32 && K % 16 == 0) {
+    hipLaunchKernelGGL((linear_bf16_kernel<false>), dim3(grid_tiles(R), N / 32), dim3(256), 0, (hipStream_t)stream, X, K, W, K, 0,
+                       bias, R, Y, N);
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  }
   RowGemmArgs a = {};
   a.Yin = X; a.ldin = K; a.W = W; a.K = K; a.R = R; a.Yout = Y; a.ldout = N; a.scale = bias;
   if (R <= 65536 && N % 32 == 0 && N >= 64 && N <= 1024) {
@@ -1888,8 +1952,15 @@ extern "C" int vlp3d_sa_prep_weights(const float *W1, const float *W2, const flo
 }
 
 // dX (R x K) = dY (R x N) * W, W (N x K) row-major as stored by nn.Linear — no transposed copy of the weight.
-extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream) {
+extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, int bf16_mma,
+                                  void *stream) {
   if (!dY || !W || !dX || R < 32 || (R & 31) || N < 8 || (N & 7) || K < 32 || (K & 31)) return VLP3D_EINVAL;
+  if (bf16_mma && N % 16 == 0) {
+    hipLaunchKernelGGL((linear_bf16_kernel<true>), dim3(grid_tiles(R), K / 32), dim3(256), 0, (hipStream_t)stream, dY, N, W, N, K,
+                       nullptr, R, dX, K);
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  }
   RowGemmArgs a = {};
   a.Yin = dY; a.ldin = N; a.W = W; a.K = N; a.ldw = K; a.R = R; a.Yout = dX; a.ldout = K;
   hipLaunchKernelGGL((row_gemm_kernel<float, 32, PLAIN, BIAS_WT>), dim3(grid_tiles(R), K / 32), dim3(256), 0,
@@ -1902,7 +1973,7 @@ extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, 
 // with_bias != 0: dW has N*K + N elements, the last N are the bias gradient sum_r dY[r][:]; partials then holds
 // max_blocks * (N*K + N) floats.
 extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                                  int max_blocks, int with_bias, int defer_reduce, void *stream) {
+                                  int max_blocks, int with_bias, int defer_reduce, int bf16_mma, void *stream) {
   if (!dY || !X || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
       ((K / 4) & (K / 4 - 1)) || (N & 31))  // K/4 a power of two: the staging row index is a shift
     return VLP3D_EINVAL;
@@ -1920,18 +1991,22 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nblk);
   int st;
+  const size_t esz = bf16_mma ? 2 : 4;  // staged element size
+  const int pad = bf16_mma ? 8 : 0;     // the bf16 tiles carry 4 shorts of row padding each
   if ((N > 256 || (N / 32) * (w.KP / 32) > 36) && N % 128 == 0 && N <= 1024) {
     // wide layers (merged q/k/v) or more than 9 output tiles per wave: 128-column workgroup blocks
-    const size_t lds128 = (size_t)32 * (128 + w.KP) * sizeof(float);
+    const size_t lds128 = (size_t)32 * (128 + w.KP + pad) * esz;
     if (lds128 > 64 * 1024) return VLP3D_EINVAL;
-    st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, dim3((unsigned)nblk, N / 128), lds128);
+    const dim3 g2((unsigned)nblk, N / 128);
+    st = bf16_mma ? launch_wgrad_c<float, PLAIN, 128, PLAIN, true>(w, s, g2, lds128)
+                  : launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, g2, lds128);
   } else {
-    const size_t lds = (size_t)32 * (N + w.KP) * sizeof(float);
+    const size_t lds = (size_t)32 * (N + w.KP + pad) * esz;
     if (lds > 64 * 1024) return VLP3D_EINVAL;
     switch (N) {
-      case 64: st = launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds); break;
-      case 128: st = launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, grid, lds); break;
-      case 256: st = launch_wgrad_c<float, PLAIN, 256, PLAIN>(w, s, grid, lds); break;
+      case 64: st = bf16_mma ? launch_wgrad_c<float, PLAIN, 64, PLAIN, true>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds); break;
+      case 128: st = bf16_mma ? launch_wgrad_c<float, PLAIN, 128, PLAIN, true>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 128, PLAIN>(w, s, grid, lds); break;
+      case 256: st = bf16_mma ? launch_wgrad_c<float, PLAIN, 256, PLAIN, true>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 256, PLAIN>(w, s, grid, lds); break;
       default: return VLP3D_EINVAL;
     }
   }

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as _ext
+from . import mfma_linear
 from . import add_norm, losses, synth
 from .ddp import FlatAdamW, FlatGradBucket, FlatParams
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
@@ -166,6 +167,7 @@ class GroundingStep:
             self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
+        self.sa_dtype = sa_dtype
         # bf16 for the grouped-MLP kernels only (the dense work that matters); everything else stays fp32, which
         # removes the ~350 per-step cast kernels autocast would launch around the many small layers
         for m in self.model.modules():
@@ -194,7 +196,8 @@ class GroundingStep:
         d["epoch"] = self.epoch
         if geometry is not None:
             d["backbone_geometry"] = geometry
-        with _deferred_bn_counters(self.model):  # 26 one-element `add_(1)` launches -> one multi-tensor add
+        # 26 one-element `add_(1)` launches -> one multi-tensor add; plain linear layers follow the grouped MLPs' dtype
+        with _deferred_bn_counters(self.model), mfma_linear.bf16_mma(self.sa_dtype == torch.bfloat16):
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                     d = self.model(d)

@@ -13,6 +13,7 @@ from . import _lib as _ext
 
 _ext.load()
 
+BF16_MMA = False       # timing configuration (set by the step driver together with the bf16 grouped MLPs): bf16 MFMA operands
 _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
 WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BLOCKS", 128))     # at most this many workgroups (= partial [dW | db] slabs)
 _FWD_N = (32, 64, 128, 160, 256, 288)
@@ -34,13 +35,14 @@ def supported(x, weight):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bf16_mma):
+        ctx.bf = int(bool(bf16_mma))
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         R, K = x2.shape
         N = weight.shape[0]
         w = weight.contiguous()
         y = torch.empty((R, N), dtype=torch.float32, device=x.device)
-        _ext.call("vlp3d_linear_fwd", x2, w, bias, R, K, N, y)
+        _ext.call("vlp3d_linear_fwd", x2, w, bias, R, K, N, y, ctx.bf)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
@@ -56,9 +58,9 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, K), dtype=torch.float32, device=dy.device)
             if K % 32 == 0:
-                _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx)  # reads W (N,K) as stored: no transposed copy
+                _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx, ctx.bf)  # reads W (N,K) as stored: no transposed copy
             else:
-                _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx)
+                _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx, ctx.bf)
             dx = dx.view(ctx.xshape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -67,7 +69,7 @@ class _Linear(Function):
             nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
             part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
             q = _ext.slab_queue()
-            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None))
+            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None), ctx.bf)
             if q is not None:
                 q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None, N if want_db else 0)
             dw = dwb[:N * K].view(N, K)
@@ -75,10 +77,27 @@ class _Linear(Function):
                 db = dwb[N * K:]
         elif want_db:
             db = dy2.sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
+class bf16_mma:
+    """Context: linear() calls inside use bf16 MFMA operands (forward; each call's backward follows its forward)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global BF16_MMA
+        self._old, BF16_MMA = BF16_MMA, self.enabled
+
+    def __exit__(self, *exc):
+        global BF16_MMA
+        BF16_MMA = self._old
+        return False
+
+
+def linear(x, weight, bias=None, bf16_mma=None):
+    """F.linear on the MFMA kernels.  bf16_mma=None: the module default BF16_MMA."""
     if supported(x, weight) and not torch.is_autocast_enabled("cuda"):
-        return _Linear.apply(x, weight, bias)
+        return _Linear.apply(x, weight, bias, BF16_MMA if bf16_mma is None else bf16_mma)
     return F.linear(x, weight, bias)

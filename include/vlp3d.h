@@ -196,11 +196,14 @@ int vlp3d_sa_prep_weights(const float *W1, const float *W2, const float *W3, int
  * vlp3d_linear_dgrad: dX (R,K) = dY (R,N) W with W (N,K) as nn.Linear stores it (no transposed copy); K % 32 == 0.
  * vlp3d_linear_wgrad: dW (N,K) = dY^T X; with_bias != 0 appends the bias gradient: dW then has N*K + N floats and
  * `partials` max_blocks * (N*K + N). */
+/* bf16_mma != 0 (the timing configuration, together with the bf16 grouped MLPs): operands are rounded to bf16 in
+ * registers / LDS and contracted with v_mfma_f32_32x32x16_bf16; memory I/O and accumulation stay fp32 (K % 16 == 0,
+ * R <= 65536 for fwd; otherwise the exact-fp32 form runs). */
 int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
-                     void *stream);
-int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, void *stream);
+                     int bf16_mma, void *stream);
+int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, int bf16_mma, void *stream);
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
-                       int max_blocks, int with_bias, int defer_reduce, void *stream);
+                       int max_blocks, int with_bias, int defer_reduce, int bf16_mma, void *stream);
 
 /* Deferred slab sums.  The three weight-gradient entries (vlp3d_sa_wgrad, vlp3d_linear_wgrad, vlp3d_rows_wgrad) write
  * per-workgroup partial results ("slabs") and then sum them with a second launch.  With defer_reduce != 0 they stop

@@ -439,6 +439,36 @@ def test_mfma_linear_equals_f_linear(R, K, N):
         assert (a.double() - e.double()).abs().max().item() < 1e-4 * e.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("R,K,N", [(16384, 128, 128), (2048, 128, 256), (2048, 256, 128), (16384, 128, 384), (64, 64, 64)])
+def test_mfma_linear_bf16_mma_close_to_fp64(R, K, N):
+    """The timing-configuration form (bf16 MFMA operands, fp32 I/O and accumulation): within bf16 operand rounding of the
+    fp64 result — norm-wise 2^-8 — and EQUAL to the exact kernels evaluated on bf16-rounded operands (same products)."""
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    torch.manual_seed(R + K)
+    x = torch.randn(R // 32, 32, K, device="cuda", requires_grad=True)
+    w = (torch.randn(N, K, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(N, device="cuda", requires_grad=True)
+    with ml.bf16_mma(True):
+        y = ml.linear(x, w, b)
+    assert not ml.BF16_MMA
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, [x, w, b], g)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    exp = torch.autograd.grad(ref, [x, w, b], g.double())
+    assert _rel(y, ref) < 4e-3
+    for a, e in zip(got, exp):
+        assert _rel(a, e) < 4e-3, _rel(a, e)
+    # same products on pre-rounded operands through the exact-fp32 kernels
+    r = lambda t: t.detach().bfloat16().float()
+    y2 = torch.nn.functional.linear(r(x).double(), r(w).double(), b.double())
+    assert _rel(y, y2) < 1e-5
+    dx2 = r(g).double().reshape(-1, N) @ r(w).double()
+    assert _rel(got[0].reshape(-1, K), dx2) < 1e-5
+    dw2 = r(g).double().reshape(-1, N).t() @ r(x).double().reshape(-1, K)
+    assert _rel(got[1], dw2) < 1e-5
+    assert _rel(got[2], r(g).double().reshape(-1, N).sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("NH", [1, 12])
 def test_box_decode_fused_equals_op_sequence(NH):
     """csrc/box_decode.hip vs the op-by-op restatement of decode_pred_box + get_3d_box_batch: same values (fp32
