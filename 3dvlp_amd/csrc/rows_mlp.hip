@@ -15,6 +15,8 @@
 //           MASK    G = relu'(Yprev*p_scale + p_shift) * acc, column sums of G and G * yhat_prev -> slab
 // The weight is (N x K) row-major, or K-major (wt = 1: (K x ldw), i.e. the SAME buffer read as the transposed operand of
 // the input-gradient product — no transposed copies).
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,7 @@ struct RowsArgs {
   const float *bn5;                // BNBWD: [rstd | -mean*rstd | gamma*rstd | mean(g) | mean(g*yhat)], each of length K
   const float *W;
   int ldw, wt;
+  int bfm;  // bf16 MFMA operands (rounded in registers), fp32 I/O and accumulation: the timing configuration
   int K, N;
   long long R;
   float *Y;
@@ -69,7 +72,29 @@ __device__ __forceinline__ void w_load(const RowsArgs &a, int col, int kbase, in
   }
 }
 
-__device__ __forceinline__ void w_mma(const float *sa, int kbase, int half, const WChunk &c, f32x16 &acc) {
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short bf16x8_t;
+__device__ __forceinline__ short bf16_bits_(float v) {
+  __hip_bfloat16 h = __float2bfloat16(v);
+  return *reinterpret_cast<short *>(&h);
+}
+__device__ __forceinline__ bf16x8_t pack_bf16x8(const float4 &a, const float4 &b) {
+  bf16x8_t v;
+  v[0] = bf16_bits_(a.x); v[1] = bf16_bits_(a.y); v[2] = bf16_bits_(a.z); v[3] = bf16_bits_(a.w);
+  v[4] = bf16_bits_(b.x); v[5] = bf16_bits_(b.y); v[6] = bf16_bits_(b.z); v[7] = bf16_bits_(b.w);
+  return v;
+}
+
+__device__ __forceinline__ void w_mma(const float *sa, int kbase, int half, const WChunk &c, f32x16 &acc, int bfm) {
+  if (bfm) {  // two 32x32x16 bf16 steps per 32 columns of K: step j contracts the k's of chunks 2j and 2j+1 (any pairing of
+              // the summation index works as long as both operands use the same one)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(sa + kbase + 16 * j + 4 * half);
+      const float4 a1 = *reinterpret_cast<const float4 *>(sa + kbase + 16 * j + 8 + 4 * half);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_bf16x8(a0, a1), pack_bf16x8(c.w[2 * j], c.w[2 * j + 1]), acc, 0, 0, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const float4 av = *reinterpret_cast<const float4 *>(sa + kbase + 8 * s + 4 * half);
@@ -142,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
       const float *sa = sA + r * lds_ld;
       for (int kb = 0; kb < a.K; kb += 64) {
         if (kb + 32 < a.K) w_load(a, col, kb + 32, half, wb);
-        w_mma(sa, kb, half, wa, acc);
+        w_mma(sa, kb, half, wa, acc, a.bfm);
         if (kb + 32 >= a.K) break;
         if (kb + 64 < a.K) w_load(a, col, kb + 64, half, wa);
-        w_mma(sa, kb + 32, half, wb, acc);
+        w_mma(sa, kb + 32, half, wb, acc, a.bfm);
       }
       // acc[i] = element (row row0 + acc_row(i, half), column col)
       if (EPI == STORE) {
@@ -324,9 +349,10 @@ extern "C" int vlp3d_rows_slabs(long long R) { return R < 32 ? 0 : (int)rows_blo
 // each of length K: the `vec` of vlp3d_sa_bn_fold).  stats != NULL: no bias, per-column sums of Y -> slabs
 // [vlp3d_rows_slabs(R)][2][N] for vlp3d_sa_bn_fold.  W (N x K) row-major.  R % 32 == 0, K % 32 == 0, N % 32 == 0.
 extern "C" int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W,
-                              const float *bias, int N, float *Y, int ldy, double *stats, void *stream) {
+                              const float *bias, int N, float *Y, int ldy, double *stats, int bf16_mma, void *stream) {
   if (bad_gemm(X, W, Y, R, K, N, ldx, K, ldy) || (stats && bias) || (a_vec && (256 % (K / 4)))) return VLP3D_EINVAL;
   RowsArgs a = {};
+  a.bfm = bf16_mma != 0;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = K; a.K = K; a.N = N; a.R = R; a.Y = Y; a.ldy = ldy; a.bias = bias; a.stats = stats;
   if (a_vec) { a.a_scale = a_vec; a.a_shift = a_vec + K; }
   hipStream_t s = (hipStream_t)stream;
@@ -341,11 +367,12 @@ extern "C" int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const
 // input gradient).  K % 32 == 0, N % 32 == 0.
 extern "C" int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R,
                                 int N, int K, const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda,
-                                double *tstats, void *stream) {
+                                double *tstats, int bf16_mma, void *stream) {
   if (bad_gemm(G, W, dA, R, N, K, ldg, K, lda) || (bn5 && (!Ypre || (256 % (N / 4)))) ||
       (p_vec && (!Yprev || !tstats || ldprev < K)))
     return VLP3D_EINVAL;
   RowsArgs a = {};
+  a.bfm = bf16_mma != 0;
   a.ldx = ldg; a.W = W; a.ldw = K; a.wt = 1; a.K = N; a.N = K; a.R = R; a.Y = dA; a.ldy = lda;
   if (bn5) { a.X = Ypre; a.G = G; a.bn5 = bn5; } else { a.X = G; }
   a.Yprev = Yprev; a.ldprev = ldprev; a.p_vec = p_vec; a.stats = tstats;

@@ -2027,7 +2027,7 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
 // partials: max_blocks * (N*K + N) floats of scratch.
 extern "C" int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
                                 const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo,
-                                float *dbias, float *partials, int max_blocks, int defer_reduce, void *stream) {
+                                float *dbias, float *partials, int max_blocks, int defer_reduce, int bf16_mma, void *stream) {
   if (!G || !X || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 32 || (K & 31) ||
       K > 288 || (256 % (K / 4)) || ((K / 4) & (K / 4 - 1)) || N < 64 || (N & 63) || ldg < N || lda < K || ldo < K ||
       (bn5 && (!Ypre || dbias)) || (a_scale && !a_shift))
@@ -2051,10 +2051,15 @@ extern "C" int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, cons
   const int nblk = (int)((ntiles + tpb - 1) / tpb);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nblk, N / 64);
-  const size_t lds = (size_t)32 * (64 + K) * sizeof(float);
+  const size_t lds = bf16_mma ? (size_t)32 * (64 + K + 8) * 2 : (size_t)32 * (64 + K) * sizeof(float);
   int st;
-  if (bn5) st = a_scale ? launch_wgrad_c<float, BNRELU, 64, BNBWD>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, BNBWD>(w, s, grid, lds);
-  else st = a_scale ? launch_wgrad_c<float, BNRELU, 64, PLAIN>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds);
+  if (bf16_mma) {
+    if (bn5) st = a_scale ? launch_wgrad_c<float, BNRELU, 64, BNBWD, true>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, BNBWD, true>(w, s, grid, lds);
+    else st = a_scale ? launch_wgrad_c<float, BNRELU, 64, PLAIN, true>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN, true>(w, s, grid, lds);
+  } else {
+    if (bn5) st = a_scale ? launch_wgrad_c<float, BNRELU, 64, BNBWD>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, BNBWD>(w, s, grid, lds);
+    else st = a_scale ? launch_wgrad_c<float, BNRELU, 64, PLAIN>(w, s, grid, lds) : launch_wgrad_c<float, PLAIN, 64, PLAIN>(w, s, grid, lds);
+  }
   if (st != VLP3D_OK) return st;
   if (defer_reduce) return VLP3D_OK;
   const int n = N * K + (dbias ? N : 0);

@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as _ext
+from . import mfma_linear
 
 _ext.load()
 _ZEROS = {}
@@ -59,6 +60,7 @@ class _RowStack(Function):
         R, dev = x.shape[0], x.device
         x = x.contiguous()
         lib = _ext.load()
+        bf = int(mfma_linear.BF16_MMA)  # bf16 MFMA operands: the step driver's timing configuration (mfma_linear.bf16_mma)
         nslab = int(lib.vlp3d_rows_slabs(R))
         Ys, vecs, Wp = [], [], []
         A, lda, a_vec = x, x.shape[1], None
@@ -75,13 +77,13 @@ class _RowStack(Function):
             y = torch.empty((R, Np), dtype=torch.float32, device=dev)
             bn = bns[l]
             if bn is None:
-                _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None)
+                _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None, bf)
                 vec = None
             else:
                 vec = torch.empty((4, Np), dtype=torch.float32, device=dev)
                 if training[l]:
                     st = torch.empty((nslab, 2, Np), dtype=torch.float64, device=dev)
-                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, None, Np, y, Np, st)
+                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, None, Np, y, Np, st, bf)
                     track = bn.track_running_stats and bn.training
                     if track:
                         if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once
@@ -94,7 +96,7 @@ class _RowStack(Function):
                     if track and b is not None:  # the bias shifts the batch mean (and nothing else)
                         bn.running_mean.add_(b.detach(), alpha=mom)
                 else:  # eval: y includes the bias, the running statistics normalise it
-                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None)
+                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None, bf)
                     _ext.call("vlp3d_sa_bn_fold", None, 1, gam[l], bet[l], bn.running_mean, bn.running_var, Np, R,
                               float(bn.eps), 0.0, 0, vec)
             Ys.append(y)
@@ -107,12 +109,12 @@ class _RowStack(Function):
             out = Ys[-1] if keep_pad else Ys[-1][:, :W[-1].shape[0]]
         ctx.save_for_backward(x, *Ys, *[v for v in vecs if v is not None], *Wp, *[g for g in gam if g is not None])
         ctx.meta = (L, [v is not None for v in vecs], training, [b is not None for b in bias],
-                    [tuple(w.shape) for w in W])
+                    [tuple(w.shape) for w in W], bf)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        L, has_bn, training, has_bias, wshapes = ctx.meta
+        L, has_bn, training, has_bias, wshapes, bf = ctx.meta
         sv = list(ctx.saved_tensors)
         x, Ys = sv[0], sv[1:1 + L]
         nbn = sum(has_bn)
@@ -165,7 +167,7 @@ class _RowStack(Function):
                 db_ = dbias if off == 0 else None
                 _ext.call("vlp3d_rows_wgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, A[:, off:], lda,
                           None if pv is None else pv[0, off:], None if pv is None else pv[1, off:], R, ks, Np,
-                          dW[:, off:], K, db_, part, nblk, int(q is not None))
+                          dW[:, off:], K, db_, part, nblk, int(q is not None), bf)
                 if q is not None:
                     q.add(part, _ext.wgrad_slabs(R, nblk), dW[:, off:], Np * ks, ks, K, db_, Np if db_ is not None else 0)
             grads[4 * l] = dW[:N]
@@ -175,12 +177,12 @@ class _RowStack(Function):
                 Gp = torch.empty((R, K), dtype=torch.float32, device=dev)
                 tp = torch.empty((nslab, 2, K), dtype=torch.float64, device=dev)
                 _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, Ys[l - 1], K,
-                          vecs[l - 1], Gp, K, tp)
+                          vecs[l - 1], Gp, K, tp, bf)
                 G, t, tn = Gp, tp, nslab
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty((R, K), dtype=torch.float32, device=dev)
                 _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, None, 0, None,
-                          dx, K, None)
+                          dx, K, None, bf)
         return (dx, None, None, *grads)
 
 

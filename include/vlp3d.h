@@ -362,14 +362,16 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
  *             vlp3d_rows_act_slabs(R)).
  * fp_rows / fp_rows_grad: X = [three_interpolate(known) | unknown] on point-major features (pointnet2_modules.py:393-411,
  *             blend order of interpolate_gpu.cu:103-104) and the adjoint w.r.t. known (m <= 1024). */
+/* bf16_mma != 0: bf16 MFMA operands rounded in registers / LDS (timing configuration), fp32 I/O, statistics, accumulation */
 int vlp3d_rows_slabs(long long R);
 int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W, const float *bias, int N,
-                   float *Y, int ldy, double *stats, void *stream);
+                   float *Y, int ldy, double *stats, int bf16_mma, void *stream);
 int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R, int N, int K,
-                     const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda, double *tstats, void *stream);
+                     const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda, double *tstats, int bf16_mma,
+                     void *stream);
 int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
                      const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo, float *dbias,
-                     float *partials, int max_blocks, int defer_reduce, void *stream);
+                     float *partials, int max_blocks, int defer_reduce, int bf16_mma, void *stream);
 int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream);
 int vlp3d_rows_act_slabs(long long R);
 int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G, double *tstats,

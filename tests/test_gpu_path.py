@@ -967,3 +967,32 @@ def test_small_linears_equal_f_linear(deferred):
     torch.testing.assert_close(o2.double(), r2.detach(), rtol=1e-5, atol=1e-5)
     for a, r in zip(got, (W64, b64, base64, xr64, wr64, br64)):
         assert _rel(a, r.grad) < 1e-5, _rel(a, r.grad)
+
+
+@pytest.mark.parametrize("R,dims,last_plain", [(4096, [512, 256, 256], False), (2048, [128, 128, 128, 28], True)])
+def test_row_stack_bf16_mma_close_to_fp32(R, dims, last_plain):
+    """The timing-configuration form of the rows stacks (bf16 MFMA operands, fp32 I/O / statistics / accumulation) stays
+    within bf16 operand rounding of the exact-fp32 form: the output norm-wise at 1e-2; gradients at 0.12 — on random
+    Gaussian rows the BatchNorm backward subtracts two nearly equal column means, which amplifies the operand rounding
+    (the bf16 grouped MLPs show the same against their autocast yardstick, test_sa_module_mfma_bf16_close_to_fp32)."""
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    torch.manual_seed(R)
+    L = len(dims) - 1
+    Ws = [torch.randn(dims[i + 1], dims[i], device="cuda") * 0.1 for i in range(L)]
+    bs = [torch.randn(dims[i + 1], device="cuda") * 0.1 for i in range(L)]
+    x0, go = torch.randn(R, dims[0], device="cuda"), torch.randn(R, dims[-1], device="cuda")
+    res = []
+    for bf in (False, True):
+        torch.manual_seed(1)
+        bns = [None if (last_plain and i == L - 1) else torch.nn.BatchNorm1d(dims[i + 1]).cuda().train() for i in range(L)]
+        x = x0.clone().requires_grad_(True)
+        W = [w.clone().requires_grad_(True) for w in Ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        with ml.bf16_mma(bf):
+            y = rm.row_stack(x, [(W[i], b[i], bns[i]) for i in range(L)])
+        (y * go).sum().backward()
+        res.append([y.detach(), x.grad] + [w.grad for w in W] + [bn.weight.grad for bn in bns if bn is not None])
+    assert 1e-5 < _rel(res[1][0], res[0][0]) < 1e-2  # close, and the switch did something
+    for a_, e_ in zip(res[1][1:], res[0][1:]):
+        assert _rel(a_, e_) < 0.12, _rel(a_, e_)

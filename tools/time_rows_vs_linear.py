@@ -13,7 +13,7 @@ for R, K, N in [(16384, 128, 128), (16384, 128, 384), (16384, 128, 256), (16384,
     y1 = torch.empty(R, N, device="cuda"); y2 = torch.empty(R, N, device="cuda")
     dy = torch.randn(R, N, device="cuda"); dx1 = torch.empty(R, K, device="cuda"); dx2 = torch.empty(R, K, device="cuda")
     a = t(lambda: ext.call("vlp3d_linear_fwd", x, w, b, R, K, N, y1, 0))
-    c = t(lambda: ext.call("vlp3d_rows_fwd", x, K, R, K, None, w, b, N, y2, N, None))
+    c = t(lambda: ext.call("vlp3d_rows_fwd", x, K, R, K, None, w, b, N, y2, N, None, 0))
     d = t(lambda: ext.call("vlp3d_linear_dgrad", dy, w, R, N, K, dx1, 0))
-    e = t(lambda: ext.call("vlp3d_rows_dgrad", dy, None, N, None, w, R, N, K, None, 0, None, dx2, K, None))
+    e = t(lambda: ext.call("vlp3d_rows_dgrad", dy, None, N, None, w, R, N, K, None, 0, None, dx2, K, None, 0))
     print(f"R={R} K={K} N={N}: fwd linear {a:.1f} us rows {c:.1f} us (maxdiff {(y1-y2).abs().max().item():.1e}) | dgrad linear {d:.1f} rows {e:.1f} ({(dx1-dx2).abs().max().item():.1e})")
