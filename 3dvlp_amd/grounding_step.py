@@ -197,7 +197,7 @@ class GroundingStep:
         if geometry is not None:
             d["backbone_geometry"] = geometry
         # 26 one-element `add_(1)` launches -> one multi-tensor add; plain linear layers follow the grouped MLPs' dtype
-        with _deferred_bn_counters(self.model), mfma_linear.bf16_mma(self.sa_dtype == torch.bfloat16):
+        with _deferred_bn_counters(self.model), mfma_linear.bf16_mma(self.sa_dtype == torch.bfloat16 and os.environ.get("VLP3D_LINEAR_BF16", "1") != "0"):
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                     d = self.model(d)
