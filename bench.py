@@ -138,11 +138,11 @@ def kernel_rooflines(args, batch, ext):
         ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
         d = {"kernel": kernel, "bound": bound, "achieved": round(ach, 4), "peak": round(peak, 4), "unit": unit,
              "frac": round(ach / peak, 4), "traffic": None, "ms": round(ms, 4)}
-        for name, v in table.items():
-            if key and key in name:
-                d["traffic"] = v["hbm_bytes_corrected"]
-                d["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE bytes/launch, profiles/r02_pmc_traffic.json"
-                break
+        keys = () if not key else ((key,) if isinstance(key, str) else tuple(key))
+        hits = [v["hbm_bytes_corrected"] for name, v in table.items() if any(k in name for k in keys)]
+        if hits:  # a tuple of keys = a multi-kernel entry (the grid ball query): its launches' traffic summed
+            d["traffic"] = sum(hits) if len(keys) > 1 else hits[0]
+            d["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE bytes/launch, profiles/r02_pmc_traffic.json"
         d.update(extra)
         return d
 
@@ -189,13 +189,14 @@ def kernel_rooflines(args, batch, ext):
                         "executes only the updates its bounding-box test cannot rule out (DESIGN.md §4.1)",
               hbm_algorithmic_GBs=round(B * (12 * n + 4 * m) / (fps_ms * 1e-3) / 1e9, 3),
               streaming_equiv_GBs=round(B * m * n * 20.0 / (fps_ms * 1e-3) / 1e9, 1)),
-        entry("ball_query_kernel SA1 r=0.2 ns=64", "ball_query", "hbm", bq_bytes, PEAK_HBM_GBS, "GB/s", bq_ms,
+        entry("grid ball query SA1 r=0.2 ns=64 (bq_bbox/header/count/scan/scatter/query: six launches, side stream)",
+              ("bq_bbox", "bq_header", "bq_count", "bq_scan", "bq_scatter", "bq_query"), "hbm", bq_bytes, PEAK_HBM_GBS, "GB/s", bq_ms,
               tests_per_s_T=round(B * m * n / (bq_ms * 1e-3) / 1e12, 3)),
         entry(("sdpa_fwd_lds_kernel (bf16 MFMA)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
               " match self-attention 64x(256x256) h4 d32", "sdpa_fwd", "hbm", att_bytes, PEAK_HBM_GBS, "GB/s", att_ms,
               mfma_TFLOPs=round(4.0 * BL * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
         entry(("sdpa_fwd_lds_kernel (bf16 MFMA)" if bf else "sdpa_fwd_kernel<fp32 MFMA>") +
-              " match cross-attention 64x(256x49) h4 d32", None, "hbm", xat_bytes, PEAK_HBM_GBS, "GB/s", xat_ms,
+              " match cross-attention 64x(256x49) h4 d32", "sdpa_fwd_cross", "hbm", xat_bytes, PEAK_HBM_GBS, "GB/s", xat_ms,
               mfma_TFLOPs=round(4.0 * BL * 256 * NUM_TOKENS * 128 / (xat_ms * 1e-3) / 1e12, 2)),
     ]
     return head, others

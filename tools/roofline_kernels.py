@@ -31,7 +31,12 @@ for bf in (1, 0):
     for _ in range(3):
         ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf)
 q = torch.randn(64, 256, 128, device=dev)
+kc = torch.randn(64, 49, 128, device=dev)
+mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
 for bf in (True, False):
     for _ in range(3):
-        fa.sdpa(q, q, q, 4, bf16_mma=bf)
+        if mode == "cross":
+            fa.sdpa(q, kc, kc, 4, bf16_mma=bf)
+        else:
+            fa.sdpa(q, q, q, 4, bf16_mma=bf)
 torch.cuda.synchronize()

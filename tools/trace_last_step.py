@@ -10,7 +10,8 @@ f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel" in r["Kernel_Name"] or "fps_kernel<1024" in r["Kernel_Name"]]
-a, b = marks[-2], marks[-1]
+pairs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if marks[i + 1] - marks[i] > 200]
+a, b = pairs[-1]  # the last FULL step (bench.py launches the FPS kernel alone again in its per-kernel section)
 win = rows[a:b]
 t0, t1 = int(win[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
 agg = defaultdict(lambda: [0, 0])
