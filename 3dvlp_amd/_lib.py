@@ -77,9 +77,9 @@ SIGNATURES = {
     "vlp3d_rows_fwd": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "vlp3d_rows_dgrad": [_vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp],
     "vlp3d_rows_wgrad": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
-    "vlp3d_rows_act": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
+    "vlp3d_rows_act": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_rows_act_slabs": [ctypes.c_longlong],
-    "vlp3d_rows_act_bwd": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_rows_act_bwd": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_fp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_fp_rows_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_roi_split": [_vp, _i, ctypes.c_longlong, _i, _i, _f] + [_vp] * 8 + [_vp],

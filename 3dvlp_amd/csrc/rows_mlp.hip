@@ -216,27 +216,34 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
   }
 }
 
-// out = relu(Y * scale + shift): the activation of the LAST BatchNorm layer of a stack, 4 columns per thread
+// out = act(Y * scale + shift): the activation of the LAST BatchNorm layer of a stack, 4 columns per thread.
+// act = ReLU, or PReLU with the per-channel slope vector when `slope` is given (relation_module.py:47: Conv1d -> BatchNorm1d
+// -> PReLU(C)).
 __global__ __launch_bounds__(256) void rows_act_kernel(const float *__restrict__ Y, long long n4, int C,
-                                                       const float *__restrict__ vec, float *__restrict__ out) {
+                                                       const float *__restrict__ vec, const float *__restrict__ slope,
+                                                       float *__restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i * 4) % C);
   const float4 y = ld4(Y + i * 4), sc = ld4(vec + c), sh = ld4(vec + C + c);
+  const float4 sl = slope ? ld4(slope + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float v0 = y.x * sc.x + sh.x, v1 = y.y * sc.y + sh.y, v2 = y.z * sc.z + sh.z, v3 = y.w * sc.w + sh.w;
   *reinterpret_cast<float4 *>(out + i * 4) =
-      make_float4(fmaxf(0.f, y.x * sc.x + sh.x), fmaxf(0.f, y.y * sc.y + sh.y), fmaxf(0.f, y.z * sc.z + sh.z),
-                  fmaxf(0.f, y.w * sc.w + sh.w));
+      make_float4(v0 > 0.f ? v0 : sl.x * v0, v1 > 0.f ? v1 : sl.y * v1, v2 > 0.f ? v2 : sl.z * v2, v3 > 0.f ? v3 : sl.w * v3);
 }
 
-// G = dOut * [Y*scale + shift > 0], per-workgroup column sums of G and G*yhat -> slab [blockIdx.x][2][C]; thread = column
+// G = dOut * act'(Y*scale + shift), per-workgroup column sums of G and G*yhat -> slab [blockIdx.x][2][C]; with a PReLU slope
+// also sum(dOut * min(v, 0)) -> dslope slab [blockIdx.x][C]; thread = column
 __global__ __launch_bounds__(256) void rows_act_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ Y,
                                                            long long R, int C, const float *__restrict__ vec,
-                                                           long long rows_per_block, float *__restrict__ G,
-                                                           double *__restrict__ slabs) {
+                                                           const float *__restrict__ slope, long long rows_per_block,
+                                                           float *__restrict__ G, double *__restrict__ slabs,
+                                                           double *__restrict__ dslope) {
   const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
   for (int c = threadIdx.x; c < C; c += 256) {
     const float sc = vec[c], sh = vec[C + c], rs = vec[2 * C + c], nm = vec[3 * C + c];
-    double s1 = 0.0, s2 = 0.0;
+    const float al = slope ? slope[c] : 0.f;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     long long r = r0;
     for (; r + 4 <= r1; r += 4) {  // four rows in flight
       float y[4], d[4];
@@ -247,21 +254,26 @@ __global__ __launch_bounds__(256) void rows_act_bwd_kernel(const float *__restri
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float g = (y[u] * sc + sh > 0.f) ? d[u] : 0.f;
+        const float v = y[u] * sc + sh;
+        const float g = v > 0.f ? d[u] : al * d[u];
         G[(r + u) * C + c] = g;
         s1 += g;
         s2 += g * (y[u] * rs + nm);
+        s3 += v > 0.f ? 0.f : d[u] * v;
       }
     }
     for (; r < r1; ++r) {
-      const float y = Y[r * C + c];
-      const float g = (y * sc + sh > 0.f) ? dOut[r * C + c] : 0.f;
+      const float y = Y[r * C + c], d = dOut[r * C + c];
+      const float v = y * sc + sh;
+      const float g = v > 0.f ? d : al * d;
       G[r * C + c] = g;
       s1 += g;
       s2 += g * (y * rs + nm);
+      s3 += v > 0.f ? 0.f : d * v;
     }
     slabs[((size_t)blockIdx.x * 2) * C + c] = s1;
     slabs[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
+    if (dslope) dslope[(size_t)blockIdx.x * C + c] = s3;
   }
 }
 
@@ -382,10 +394,12 @@ extern "C" int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, cons
 }
 
 // out (R x C) = relu(Y * scale + shift), vec = [scale | shift | ..] of length C each.  C % 4 == 0.
-extern "C" int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream) {
+extern "C" int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, const float *slope, float *out,
+                              void *stream) {
   if (!Y || !vec || !out || R < 1 || C < 4 || (C & 3)) return VLP3D_EINVAL;
   const long long n4 = R * C / 4;
-  hipLaunchKernelGGL(rows_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Y, n4, C, vec, out);
+  hipLaunchKernelGGL(rows_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Y, n4, C, vec, slope,
+                     out);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
@@ -396,12 +410,13 @@ extern "C" int vlp3d_rows_act_slabs(long long R) {
   const long long n = (R + 63) / 64;
   return (int)(n < 256 ? n : 256);
 }
-extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G,
-                                  double *tstats, void *stream) {
-  if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 1) return VLP3D_EINVAL;
+extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, const float *slope,
+                                  float *G, double *tstats, double *dslope_slabs, void *stream) {
+  if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 1 || (slope && !dslope_slabs)) return VLP3D_EINVAL;
   const int nslab = vlp3d_rows_act_slabs(R);
   const long long rpb = (R + nslab - 1) / nslab;
-  hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, rpb, G, tstats);
+  hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G, tstats,
+                     slope ? dslope_slabs : nullptr);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

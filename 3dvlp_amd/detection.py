@@ -416,7 +416,17 @@ class RelationModule(nn.Module):
         self.obj_embedding = nn.ModuleList(nn.Linear(128, hidden_size) for _ in range(depth))
 
     def forward(self, data_dict):
-        features = self.features_concat(data_dict["pred_bbox_feature"].permute(0, 2, 1)).permute(0, 2, 1)
+        pf = data_dict["pred_bbox_feature"]  # (B, K, det_channel) point-major
+        fc = self.features_concat
+        layers = [(fc[0].weight, fc[0].bias, fc[1])]
+        if (self.fused_bias and pf.is_cuda and pf.dtype == torch.float32 and fc[2].weight.numel() == fc[1].num_features
+                and fc[1].num_features % 64 == 0 and row_mlp.supported(pf.reshape(-1, pf.shape[-1]), layers)):
+            # Conv1d -> BatchNorm1d -> PReLU on the rows kernels (the slope rides on the final activation), then the second
+            # 1x1 convolution as a linear layer: no NCHW round trips, no MIOpen / BLAS launches
+            h = row_mlp.row_stack(pf.reshape(-1, pf.shape[-1]), layers, final_slope=fc[2].weight)
+            features = _linear(h, fc[3].weight.reshape(fc[3].weight.shape[0], -1), fc[3].bias).view(pf.shape[0], pf.shape[1], -1)
+        else:
+            features = fc(pf.permute(0, 2, 1)).permute(0, 2, 1)
         B, K = features.shape[:2]
         corners = data_dict["pred_bbox_corner"]
 

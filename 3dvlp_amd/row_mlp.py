@@ -54,7 +54,7 @@ def supported(x, layers):
 
 class _RowStack(Function):
     @staticmethod
-    def forward(ctx, x, bns, keep_pad, *params):
+    def forward(ctx, x, bns, keep_pad, slope, *params):
         L = len(bns)
         W, bias, gam, bet = params[0::4], params[1::4], params[2::4], params[3::4]
         R, dev = x.shape[0], x.device
@@ -104,18 +104,23 @@ class _RowStack(Function):
             A, lda, a_vec = y, Np, vec
         if bns[-1] is not None:
             out = torch.empty_like(Ys[-1])
-            _ext.call("vlp3d_rows_act", Ys[-1], R, Ys[-1].shape[1], vecs[-1], out)
+            if slope is not None and slope.numel() != Ys[-1].shape[1]:
+                raise ValueError("final PReLU slope needs one value per (64-aligned) output channel")
+            _ext.call("vlp3d_rows_act", Ys[-1], R, Ys[-1].shape[1], vecs[-1], slope, out)
         else:
             out = Ys[-1] if keep_pad else Ys[-1][:, :W[-1].shape[0]]
-        ctx.save_for_backward(x, *Ys, *[v for v in vecs if v is not None], *Wp, *[g for g in gam if g is not None])
+        ctx.save_for_backward(x, *Ys, *[v for v in vecs if v is not None], *Wp, *[g for g in gam if g is not None],
+                              *([slope] if slope is not None else []))
         ctx.meta = (L, [v is not None for v in vecs], training, [b is not None for b in bias],
-                    [tuple(w.shape) for w in W], bf)
+                    [tuple(w.shape) for w in W], bf, slope is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        L, has_bn, training, has_bias, wshapes, bf = ctx.meta
+        L, has_bn, training, has_bias, wshapes, bf, has_slope = ctx.meta
         sv = list(ctx.saved_tensors)
+        slope = sv.pop() if has_slope else None
+        dslope = None
         x, Ys = sv[0], sv[1:1 + L]
         nbn = sum(has_bn)
         vlist, Wp, glist = sv[1 + L:1 + L + nbn], sv[1 + L + nbn:1 + 2 * L + nbn], sv[1 + 2 * L + nbn:]
@@ -133,7 +138,10 @@ class _RowStack(Function):
             G = torch.empty((R, Np), dtype=torch.float32, device=dev)
             tn = int(lib.vlp3d_rows_act_slabs(R))
             t = torch.empty((tn, 2, Np), dtype=torch.float64, device=dev)
-            _ext.call("vlp3d_rows_act_bwd", dout.contiguous(), Ys[last], R, Np, vecs[last], G, t)
+            ds = torch.empty((tn, Np), dtype=torch.float64, device=dev) if has_slope else None
+            _ext.call("vlp3d_rows_act_bwd", dout.contiguous(), Ys[last], R, Np, vecs[last], slope, G, t, ds)
+            if has_slope:
+                dslope = ds.sum(0).float()
         else:
             N = wshapes[last][0]
             G = dout if dout.shape[1] == Np else torch.nn.functional.pad(dout, (0, Np - N))
@@ -183,18 +191,19 @@ class _RowStack(Function):
                 dx = torch.empty((R, K), dtype=torch.float32, device=dev)
                 _ext.call("vlp3d_rows_dgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, Wp[l], R, Np, K, None, 0, None,
                           dx, K, None, bf)
-        return (dx, None, None, *grads)
+        return (dx, None, None, dslope, *grads)
 
 
-def row_stack(x, layers, keep_pad=False):
+def row_stack(x, layers, keep_pad=False, final_slope=None):
     """x (R, K0) fp32 CUDA; layers = [(weight (N,K[,1[,1]]), bias or None, bn module or None), ...] -> (R, N_last).
+    final_slope: per-channel PReLU weight (N_last,) replacing the ReLU after the LAST BatchNorm layer.
     keep_pad: return the final plain layer's full 64-aligned buffer (R, round_up(N, 64)); the columns past N are zero
     and take no gradient — lets a consumer kernel address column blocks without a slice copy either way."""
     bns = [bn for _, _, bn in layers]
     params = []
     for w, b, bn in layers:
         params += [w.reshape(w.shape[0], w.shape[1]), b, None if bn is None else bn.weight, None if bn is None else bn.bias]
-    return _RowStack.apply(x, bns, bool(keep_pad), *params)
+    return _RowStack.apply(x, bns, bool(keep_pad), final_slope, *params)
 
 
 class _FPRows(Function):

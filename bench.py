@@ -183,7 +183,7 @@ def kernel_rooflines(args, batch, ext):
                  PEAK_HBM_GBS, "GB/s", g_ms, mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2),
                  algorithmic_bytes=g_bytes)
     others = [
-        entry("fps_pruned_kernel SA1 40000->2048 (side stream; bit-exact bounding-box pruned FPS)", "fps_pruned_kernel",
+        entry("fps_pruned_kernel SA1 40000->2048 (side stream; bounding-box pruned FPS, same indices as the dense kernel)", "fps_pruned_kernel",
               "valu", fps_flops, fps_peak, "TFLOP/s", fps_ms, cus_used=B,
               numerator="ALGORITHMIC: the dense algorithm's B*(m-1)*n distance-update-compares x 11 flop; the kernel "
                         "executes only the updates its bounding-box test cannot rule out (DESIGN.md §4.1)",

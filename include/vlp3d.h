@@ -359,7 +359,8 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
  *             sums to tstats slabs [vlp3d_rows_slabs(R)][2][K].  K % 32 == 0, N % 32 == 0.
  * rows_wgrad: dW[:, 0:K] (stride ldo) = dY^T A (+ dbias = column sums of G when bn5 == NULL); see csrc/sa_mlp.hip.
  * rows_act / rows_act_bwd: the activation of the last BatchNorm layer and its backward (+ column sums, nslab =
- *             vlp3d_rows_act_slabs(R)).
+ *             vlp3d_rows_act_slabs(R)).  slope == NULL: ReLU; else PReLU with that per-channel slope (C floats), and
+ *             dslope_slabs [nslab][C] fp64 receives the partial sums of its gradient.
  * fp_rows / fp_rows_grad: X = [three_interpolate(known) | unknown] on point-major features (pointnet2_modules.py:393-411,
  *             blend order of interpolate_gpu.cu:103-104) and the adjoint w.r.t. known (m <= 1024). */
 /* bf16_mma != 0: bf16 MFMA operands rounded in registers / LDS (timing configuration), fp32 I/O, statistics, accumulation */
@@ -372,10 +373,10 @@ int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn
 int vlp3d_rows_wgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *X, int lda,
                      const float *a_scale, const float *a_shift, long long R, int K, int N, float *dW, int ldo, float *dbias,
                      float *partials, int max_blocks, int defer_reduce, int bf16_mma, void *stream);
-int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, float *out, void *stream);
+int vlp3d_rows_act(const float *Y, long long R, int C, const float *vec, const float *slope, float *out, void *stream);
 int vlp3d_rows_act_slabs(long long R);
-int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, float *G, double *tstats,
-                       void *stream);
+int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, const float *slope, float *G,
+                       double *tstats, double *dslope_slabs, void *stream);
 int vlp3d_fp_rows(const float *known, const float *unknown, const int *idx, const float *weight, int B, int n, int m, int C1,
                   int C2, float *X, void *stream);
 int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *weight, int B, int n, int m, int C1, int ld,

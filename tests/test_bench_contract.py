@@ -34,7 +34,7 @@ def test_bench_json_line_contract():
     rs = d["roofline_step"]
     assert rs["flops_per_step"] > 3e11 and 0 < rs["frac_mfma"] < 1 and 0 < rs["frac_hbm"] < 1
     names = " ".join(k["kernel"] for k in d["roofline_kernels"])
-    assert "fps" in names and "ball_query" in names and "cross-attention" in names
+    assert "fps" in names and "ball query" in names and "cross-attention" in names
     hw = d["hw"]
     assert 2000 < hw["hbm_read_GBs"] < 9000 and 500 < hw["bf16_mfma_TFLOPs"] < 3000 and 50 < hw["fp32_fma_TFLOPs"] < 200
 

@@ -996,3 +996,33 @@ def test_row_stack_bf16_mma_close_to_fp32(R, dims, last_plain):
     assert 1e-5 < _rel(res[1][0], res[0][0]) < 1e-2  # close, and the switch did something
     for a_, e_ in zip(res[1][1:], res[0][1:]):
         assert _rel(a_, e_) < 0.12, _rel(a_, e_)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_row_stack_final_prelu_equals_fp64_formula(training):
+    """Conv1d -> BatchNorm1d -> PReLU(C) (relation_module.py:47, features_concat) on the rows kernels: output, input gradient,
+    weight / bias / BatchNorm / slope gradients against the same chain in fp64."""
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    torch.manual_seed(11)
+    R, K, N = 2048, 128, 128
+    x0 = torch.randn(R, K, device="cuda")
+    W0, b0 = torch.randn(N, K, device="cuda") * 0.1, torch.randn(N, device="cuda") * 0.1
+    a0 = torch.rand(N, device="cuda") * 0.5
+    bn = torch.nn.BatchNorm1d(N).cuda().train(training)
+    _randomise_bn(bn)
+    go = torch.randn(R, N, device="cuda")
+    x, W, b, a = (t.clone().requires_grad_(True) for t in (x0, W0, b0, a0))
+    y = rm.row_stack(x, [(W, b, bn)], final_slope=a)
+    (y * go).sum().backward()
+    xd, Wd, bd, ad = (t.double().requires_grad_(True) for t in (x0, W0, b0, a0))
+    gd, ed = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    h = xd @ Wd.t() + bd
+    mean, var = (h.mean(0), h.var(0, unbiased=False)) if training else (bn.running_mean.double(), bn.running_var.double())
+    v = (h - mean) / torch.sqrt(var + bn.eps) * gd + ed
+    ref = torch.where(v > 0, v, ad * v)
+    (ref * go.double()).sum().backward()
+    assert _rel(y, ref) < 1e-5
+    for got, exp in ((x.grad, xd.grad), (W.grad, Wd.grad), (bn.weight.grad, gd.grad), (bn.bias.grad, ed.grad), (a.grad, ad.grad)):
+        assert _rel(got, exp) < 2e-4, _rel(got, exp)
+    if not training:
+        assert _rel(b.grad, bd.grad) < 2e-4
