@@ -575,6 +575,136 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward 2, bf16-MFMA form with the head's Q and dO shared through LDS: every wave of the one-wave form streamed all
+// queries of its head from L2 (64 KB per wave, eight key-tile waves per head re-reading the same rows, plus 32 strided
+// dword loads per tile for the column-layout copies).  A workgroup = up to four key tiles of one (b,h); Q and dO are
+// converted to bf16 ONCE while staging, row-major (S = Q K^T, dP = dO V^T: a lane's operand = two ds_read_b128) and
+// transposed (dV^T += dO^T P, dK^T += Q^T dS: four ds_read_b64 in the accumulator's row order); lse / delta as fp32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
+    const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nqp, int nk, int ldq, int ldk,
+    int ldv, float scale, float *__restrict__ dk, float *__restrict__ dv) {
+  extern __shared__ __attribute__((aligned(16))) short sm_q[];
+  constexpr int KS = D + 8;
+  const int TS = nqp + 4;
+  short *sQ = sm_q;                  // [nqp][KS]
+  short *sDO = sQ + nqp * KS;        // [nqp][KS]
+  short *sQt = sDO + nqp * KS;       // [D][TS]
+  short *sDOt = sQt + D * TS;        // [D][TS]
+  float *sL = reinterpret_cast<float *>(sDOt + D * TS);  // [nqp] lse, then [nqp] delta (offset is a multiple of 16 bytes)
+  float *sDl = sL + nqp;
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * D, nthr = blockDim.x;
+  for (int c = threadIdx.x; c < nqp * (D / 4); c += nthr) {
+    const int qi = c / (D / 4), d4 = (c - qi * (D / 4)) * 4;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv4 = qv;
+    if (qi < nq) {
+      const long long qrow = (long long)b * nq + qi;
+      qv = *reinterpret_cast<const float4 *>(q + qrow * ldq + h * D + d4);
+      dv4 = *reinterpret_cast<const float4 *>(dout + qrow * HD + h * D + d4);
+    }
+    short4 qb, db;
+    qb.x = bf16_bits(qv.x); qb.y = bf16_bits(qv.y); qb.z = bf16_bits(qv.z); qb.w = bf16_bits(qv.w);
+    db.x = bf16_bits(dv4.x); db.y = bf16_bits(dv4.y); db.z = bf16_bits(dv4.z); db.w = bf16_bits(dv4.w);
+    *reinterpret_cast<short4 *>(sQ + qi * KS + d4) = qb;
+    *reinterpret_cast<short4 *>(sDO + qi * KS + d4) = db;
+    sQt[(d4 + 0) * TS + qi] = qb.x; sQt[(d4 + 1) * TS + qi] = qb.y; sQt[(d4 + 2) * TS + qi] = qb.z; sQt[(d4 + 3) * TS + qi] = qb.w;
+    sDOt[(d4 + 0) * TS + qi] = db.x; sDOt[(d4 + 1) * TS + qi] = db.y; sDOt[(d4 + 2) * TS + qi] = db.z; sDOt[(d4 + 3) * TS + qi] = db.w;
+  }
+  for (int c = threadIdx.x; c < nqp; c += nthr) {
+    const long long stat = ((long long)b * H + h) * nq + min(c, nq - 1);
+    sL[c] = lse[stat];
+    sDl[c] = delta[stat];
+  }
+  __syncthreads();
+  const int k0 = (blockIdx.x * (nthr >> 6) + wave) * 32;
+  if (k0 >= nk) return;
+  const int ki = min(k0 + r, nk - 1);
+  const long long krow = (long long)b * nk + ki;
+  const bool k_ok = k0 + r < nk;
+  const bool masked = mask != nullptr && mask[(long long)b * nk + ki] == 0.f;
+  float kreg[16], vreg[16];
+  load_half_row(k, krow, ldk, h, half, kreg);
+  load_half_row(v, krow, ldv, h, half, vreg);
+  bf16x8 kb[2], vb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      kb[t][j] = bf16_bits(kreg[8 * t + j]);
+      vb[t][j] = bf16_bits(vreg[8 * t + j]);
+    }
+  const long long stat0 = ((long long)b * H + h) * nq;
+  f32x16 dka = zero16(), dva = zero16();
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    f32x16 s = zero16(), dp = zero16();
+    const short *qr = sQ + (q0 + r) * KS + 16 * half, *dr = sDO + (q0 + r) * KS + 16 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // S[query][key], dP[query][key]: lane = key
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(qr + 8 * t), kb[t], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(dr + 8 * t), vb[t], dp, 0, 0, 0);
+    }
+    f32x16 p;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4 *>(sL + q0 + 8 * g + 4 * half);
+      const float4 d4 = *reinterpret_cast<const float4 *>(sDl + q0 + 8 * g + 4 * half);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        const int qq = q0 + acc_row(i, half);
+        float pv = 0.f, ds = 0.f;
+        if (qq < nq && k_ok) {
+          const float raw = s[i] * scale;
+          float x = apply_bias(raw, bias_mode, bias, (stat0 + qq) * nk + ki);
+          if (masked) x = -10000.f;
+          pv = __expf(x - lv[e]);
+          ds = masked ? 0.f : pv * (dp[i] - dl[e]);
+          if (bias_mode == 2) ds *= bias[(stat0 + qq) * nk + ki];
+        }
+        p[i] = pv;
+        s[i] = ds;
+      }
+    }
+    // dV^T[dim][key] += dO^T[dim][query] P[query][key];  dK^T[dim][key] += Q^T[dim][query] dS[query][key]
+    const short *dot = sDOt + r * TS + q0 + 4 * half, *qt = sQt + r * TS + q0 + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 da, qa, pb, sb;
+      const short4 a0 = *reinterpret_cast<const short4 *>(dot + 16 * t), a1 = *reinterpret_cast<const short4 *>(dot + 16 * t + 8);
+      const short4 c0 = *reinterpret_cast<const short4 *>(qt + 16 * t), c1 = *reinterpret_cast<const short4 *>(qt + 16 * t + 8);
+      da[0] = a0.x; da[1] = a0.y; da[2] = a0.z; da[3] = a0.w; da[4] = a1.x; da[5] = a1.y; da[6] = a1.z; da[7] = a1.w;
+      qa[0] = c0.x; qa[1] = c0.y; qa[2] = c0.z; qa[3] = c0.w; qa[4] = c1.x; qa[5] = c1.y; qa[6] = c1.z; qa[7] = c1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[j] = bf16_bits(p[8 * t + j]);
+        sb[j] = bf16_bits(s[8 * t + j]);
+      }
+      dva = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, pb, dva, 0, 0, 0);
+      dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sb, dka, 0, 0, 0);
+    }
+  }
+  if (k_ok) {
+    float *__restrict__ rk = dk + krow * ldk + h * D;
+    float *__restrict__ rv = dv + krow * ldv + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 a, c;
+      a.x = dka[4 * g + 0] * scale; a.y = dka[4 * g + 1] * scale; a.z = dka[4 * g + 2] * scale;
+      a.w = dka[4 * g + 3] * scale;
+      c.x = dva[4 * g + 0]; c.y = dva[4 * g + 1]; c.z = dva[4 * g + 2]; c.w = dva[4 * g + 3];
+      *reinterpret_cast<float4 *>(rk + 8 * g + 4 * half) = a;
+      *reinterpret_cast<float4 *>(rv + 8 * g + 4 * half) = c;
+    }
+  }
+}
+
 // row strides (floats) of q / k / v (and of dq / dk / dv): >= H*D and a multiple of 4 (16-byte row slices)
 bool bad_ld(int ldq, int ldk, int ldv, int H) {
   return ldq < H * D || ldk < H * D || ldv < H * D || ((ldq | ldk | ldv) & 3);
@@ -630,8 +760,20 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
     } else
       hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
                          nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
-    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
-                       H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
+    const int nqp = (nq + 31) & ~31;
+    const size_t lds_kv = ((size_t)2 * nqp * (D + 8) + (size_t)2 * D * (nqp + 4)) * sizeof(short) + (size_t)2 * nqp * sizeof(float);
+    if (nq <= 512 && lds_kv <= 150 * 1024) {  // Q, dO (+ transposes) of a head staged once per workgroup of up to 4 key tiles
+      const int tiles = vlp3d_cdiv(nk, 32), wpb = tiles < 4 ? tiles : 4;
+      if (lds_kv > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb), lds_kv, s, q, k, v, bias,
+                         bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv);
+    } else
+      hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
+                         H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
   } else {
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel<false>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
                        nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
