@@ -300,6 +300,26 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def three_interpolate_grad_asshipped(grad_out, idx, weight, m):
+    """What the reference's three_interpolate_grad EXECUTES (interpolate.cpp:77-104 calls the forward wrapper with
+    m := n, n := m, points := grad_out): a forward blend of grad_out with a wrong batch stride, no scatter.  Only for
+    like-for-like comparisons with a run of the reference; the default backward is the true adjoint."""
+    _chk_float(grad_out, "grad_out")
+    _chk_int(idx, "idx")
+    _chk_float(weight, "weight")
+    _chk_dev(grad_out, ("idx", idx), ("weight", weight))
+    B, C, n = grad_out.shape
+    m = int(m)
+    if m > n:
+        raise RuntimeError("three_interpolate_grad_asshipped: m > n would read idx / weight out of bounds "
+                           "(the reference does, too)")
+    out = torch.empty((B, C, m), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _check(load().vlp3d_three_interpolate(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(out), _stream()),
+               "three_interpolate (as-shipped gradient)")
+    return out
+
+
 # ---- fused ops ----
 def nn_distance(pc1, pc2, mode, delta):
     _chk_float(pc1, "pc1")

@@ -68,6 +68,11 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+# False (default): the backward of three_interpolate is its true adjoint.  True: reproduce what the reference executes
+# (the host bug of interpolate.cpp:95, see _lib.three_interpolate_grad_asshipped) for like-for-like training comparisons.
+THREE_INTERPOLATE_GRAD_AS_SHIPPED = False
+
+
 class ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features, idx, weight):
@@ -78,6 +83,8 @@ class ThreeInterpolate(Function):
     @staticmethod
     def backward(ctx, grad_out):
         idx, weight, m = ctx.three_interpolate_for_backward
+        if THREE_INTERPOLATE_GRAD_AS_SHIPPED:
+            return _ext.three_interpolate_grad_asshipped(grad_out.contiguous(), idx, weight, m), None, None
         return _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, m), None, None
 
 

@@ -13,7 +13,7 @@ Pinned here (SURVEY.md §8c list): nn_distance; ScaledDotProductAttention /
 MultiHeadAttention (plain, additive bias, multiplicative weights, mask);
 CrossAttentionDecoderLayer x2; MatchModule (eval, istrain=0); RelationModule
 (eval); VotingModule (train+eval); SharedMLP (train+eval);
-box3d_diou_batch_tensor; StandardROIHeads (eval); get_3d_box_batch; SoftmaxRankingLoss.
+box3d_diou_batch_tensor; StandardROIHeads (eval); get_3d_box_batch; SoftmaxRankingLoss; AnswerModule (eval).
 
 NOT pinnable (documented in DESIGN.md): the nine pointnet2._ext CUDA ops and
 pytorch3d box3d_overlap.
@@ -300,9 +300,26 @@ def gen_ranking_loss():
     save("ranking_loss", **d)
 
 
+def gen_answer():
+    """models/answer_module/answer_module.py:10-114 (QA head as shipped: AttFlat over cross_box_feature -> answer_cls), eval."""
+    from models.answer_module.answer_module import AnswerModule
+    rng = np.random.default_rng(1000)
+    m = AnswerModule(num_answers=24, hidden_size=128).eval()
+    d = pack(quantize_module_(m, rng))
+    xq, x = qrand(rng, (6, 32, 128), 32)
+    d.update({"in/cross_box_feature": xq, "in/cross_box_feature#scale": np.float32(32)})
+    with torch.no_grad():
+        out = m({"cross_box_feature": torch.from_numpy(x)})
+    d["out/answer_scores"] = t2n(out["answer_scores"])
+    save("answer_module", **d)
+
+
 if __name__ == "__main__":
     if "--only-ranking" in sys.argv:
         gen_ranking_loss()
+        sys.exit(0)
+    if "--only-answer" in sys.argv:
+        gen_answer()
         sys.exit(0)
     gen_nn_distance()
     gen_attention()
@@ -314,3 +331,4 @@ if __name__ == "__main__":
     gen_boxes()
     gen_roi_heads()
     gen_ranking_loss()
+    gen_answer()

@@ -208,6 +208,25 @@ def test_three_interpolate_forward_backward(pu, B, C, m, n):
     np.testing.assert_allclose(ft.grad.cpu().numpy(), orc.three_interpolate_grad(g, idx, w, m), rtol=1e-5, atol=1e-5)
 
 
+def test_three_interpolate_grad_as_shipped_switch(pu, monkeypatch):
+    """THREE_INTERPOLATE_GRAD_AS_SHIPPED reproduces what the reference executes (interpolate.cpp:95: the forward wrapper on
+    grad_out) — bit-equal to the oracle's restatement of that bug; the default stays the true adjoint."""
+    rng = np.random.default_rng(13)
+    B, C, m, n = 4, 64, 256, 512
+    feats = rng.normal(size=(B, C, m)).astype(np.float32)
+    idx = rng.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    w = rng.random((B, n, 3)).astype(np.float32)
+    g = rng.normal(size=(B, C, n)).astype(np.float32)
+    monkeypatch.setattr(pu, "THREE_INTERPOLATE_GRAD_AS_SHIPPED", True)
+    ft = dev(feats).requires_grad_(True)
+    pu.three_interpolate(ft, dev(idx), dev(w)).backward(dev(g))
+    assert (ft.grad.cpu().numpy() == orc.three_interpolate_grad_asshipped(g, idx, w, m)).all()
+    monkeypatch.setattr(pu, "THREE_INTERPOLATE_GRAD_AS_SHIPPED", False)
+    ft = dev(feats).requires_grad_(True)
+    pu.three_interpolate(ft, dev(idx), dev(w)).backward(dev(g))
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), orc.three_interpolate_grad(g, idx, w, m), rtol=1e-5, atol=1e-5)
+
+
 def test_nn_distance_golden_and_hot_path_shapes(golden):
     nnd = importlib.import_module("3dvlp_amd.nn_distance")
     g = golden("nn_distance")

@@ -254,3 +254,52 @@ def test_copy_paste_device_formulation_equals_reference_loop():
             else:
                 feature0[i, om[:total_len - obj_lens[i]], :] = obj_features[j:j + total_len - obj_lens[i], :]
         assert torch.equal(got, feature0), trial
+
+
+@pytest.mark.parametrize("env", DEVICES, indirect=True)
+def test_answer_module(env, golden):
+    """QA head (answer_module.py:10-114, AttFlat of mcan_module.py:74-112): strict state-dict key contract + outputs."""
+    ans = importlib.import_module("3dvlp_amd.answer")
+    g = golden("answer_module")
+    m = ans.AnswerModule(num_answers=24, hidden_size=128)
+    sd = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in g.weights("w/").items()}
+    m.load_state_dict(sd, strict=True)  # every reference key present, nothing extra
+    m = m.to(env).eval()
+    with torch.no_grad():
+        d = m({"cross_box_feature": T(g["in/cross_box_feature"], env)})
+    np.testing.assert_allclose(d["answer_scores"].cpu().numpy(), g["out/answer_scores"], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_answer_module_train_backward_vs_torch_ops():
+    """Train mode (hash dropout off: p = 0 set on the modules) on the MFMA kernels vs the same module on plain torch ops
+    (CPU, fp64): every parameter gradient the head uses."""
+    ans = importlib.import_module("3dvlp_amd.answer")
+    torch.manual_seed(3)
+    m = ans.AnswerModule(num_answers=24, hidden_size=128)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, ans.FC):
+            mod.pdrop = 0.0
+    ref = ans.AnswerModule(num_answers=24, hidden_size=128).double()
+    ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, ans.FC):
+            mod.pdrop = 0.0
+    x = torch.randn(64, 256, 128)
+    g = torch.randn(64, 24)
+    m = m.cuda().train()
+    out = m({"cross_box_feature": x.cuda()})["answer_scores"]
+    (out * g.cuda()).sum().backward()
+    out_r = ref.train()({"cross_box_feature": x.double()})["answer_scores"]
+    (out_r * g.double()).sum().backward()
+    assert float((out.cpu().double() - out_r).norm() / out_r.norm()) < 1e-5
+    for (n, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None, n
+            continue
+        # (the score bias has an exactly zero gradient — softmax is shift invariant — hence the absolute floor)
+        assert float((p.grad.cpu().double() - pr.grad).norm()) < 1e-4 * float(pr.grad.norm()) + 1e-6, n
