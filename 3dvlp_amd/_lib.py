@@ -163,7 +163,7 @@ def _chk_dev(ref, *others):
 
 # ---- the nine _ext functions (same names / argument order as bindings.cpp:12-23) ----
 FPS_PRUNED_MIN_N = 8192   # below this the all-register dense kernel wins (no sort pre-pass)
-FPS_PRUNED_MAX_N = 65536  # 64 slots per wave
+FPS_PRUNED_MAX_N = 131072  # 64 slots per wave and lane-slot, two lane-slots above 65536 points
 
 
 def furthest_point_sampling(points, nsamples, algorithm=None):

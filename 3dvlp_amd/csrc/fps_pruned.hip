@@ -183,6 +183,8 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// NS = slots per lane: a wave holds 64 * NS slots of 64 points, i.e. N <= 65536 * NS (NS = 2: cfg5's 80 000-point scenes).
+template <int NS>
 __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restrict__ xyz_all, float4 *__restrict__ pts_all,
                                                            const int *__restrict__ perm_all, int *__restrict__ idx_all,
                                                            int N, int m, int log2P, int L, int m_lds) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   float4 *__restrict__ pts = pts_all + (size_t)b * N;
   const int *__restrict__ perm = perm_all + (size_t)b * N;
   int *__restrict__ idx = idx_all + (size_t)b * m;
-  const int nslots = (N + 1023) / 1024;  // <= 64: lane i of a wave holds the state of the wave's slot i
+  const int nslots = (N + 1023) / 1024;  // <= 64 NS: lane i of a wave holds the state of the wave's slots i, i + 64, ..
   const unsigned Pm1 = (1u << log2P) - 1u;
 
   // larger = preferred by the reference's reduction tree among equal values (see fps.hip)
@@ -215,10 +217,16 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     return __builtin_ctzll(__ballot(v == vmax && tk == tmax));
   };
 
-  float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};
-  unsigned sval = 0u;
-  int swl = 0;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
+  float blo[NS][3], bhi[NS][3];
+  unsigned sval[NS];
+  int swl[NS];
+  float sx[NS], sy[NS], sz[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    sval[q] = 0u; swl[q] = 0; sx[q] = sy[q] = sz[q] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) blo[q][a] = bhi[q][a] = 0.f;
+  }
   for (int i = 0; i < nslots; ++i) {
     const int pos = i * 1024 + wave * 64 + lane;
     const bool valid = pos < N;
@@ -237,14 +245,16 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     int wl = 0;
     if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
     const float wx = readlane_f32(p.x, wl), wy = readlane_f32(p.y, wl), wz = readlane_f32(p.z, wl);
-    if (lane == i) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        blo[a] = lo[a];
-        bhi[a] = hi[a];
+    for (int q = 0; q < NS; ++q)
+      if (lane + 64 * q == i) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          blo[q][a] = lo[a];
+          bhi[q][a] = hi[a];
+        }
+        sval[q] = vmax; swl[q] = wl; sx[q] = wx; sy[q] = wy; sz[q] = wz;
       }
-      sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz;
-    }
   }
   if (tid == 0) idx[0] = 0;
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
@@ -252,63 +262,79 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   __syncthreads();
 
   for (int j = 1; j < m; ++j) {
-    const float ex = fmaxf(0.f, fmaxf(blo[0] - x1, x1 - bhi[0]));
-    const float ey = fmaxf(0.f, fmaxf(blo[1] - y1, y1 - bhi[1]));
-    const float ez = fmaxf(0.f, fmaxf(blo[2] - z1, z1 - bhi[2]));
-    const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
-    const bool active = (lane < nslots) && (sval != 0u) && (lb2 < __uint_as_float(sval - 1u));
-    unsigned long long todo = __ballot(active);
-    while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time
-      int si[4];
-      float4 p[4];
-      int nb = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        si[u] = -1;
-        if (todo != 0ull) {  // uniform
-          si[u] = __builtin_ctzll(todo);
-          todo &= todo - 1ull;
-          nb = u + 1;
-          if (si[u] < L) {
-            p[u] = lpts[si[u] * 1024 + tid];
-          } else {
-            // the barrier below does not wait for global stores any more: order this read after the wave's own
-            // older temp stores to the slot (they were issued iterations ago; the wait is free in practice)
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) only (gfx9 encoding: expcnt/lgkmcnt fields left at max)
+    for (int q = 0; q < NS; ++q) {
+      const float ex = fmaxf(0.f, fmaxf(blo[q][0] - x1, x1 - bhi[q][0]));
+      const float ey = fmaxf(0.f, fmaxf(blo[q][1] - y1, y1 - bhi[q][1]));
+      const float ez = fmaxf(0.f, fmaxf(blo[q][2] - z1, z1 - bhi[q][2]));
+      const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
+      const bool active = (lane + 64 * q < nslots) && (sval[q] != 0u) && (lb2 < __uint_as_float(sval[q] - 1u));
+      unsigned long long todo = __ballot(active);
+      while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time
+        int si[4];
+        float4 p[4];
+        int nb = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          si[u] = -1;
+          if (todo != 0ull) {  // uniform
+            si[u] = __builtin_ctzll(todo) + 64 * q;
+            todo &= todo - 1ull;
+            nb = u + 1;
+            if (si[u] < L) {
+              p[u] = lpts[si[u] * 1024 + tid];
+            } else {
+              // the barrier below does not wait for global stores any more: order this read after the wave's own
+              // older temp stores to the slot (they were issued iterations ago; the wait is free in practice)
+              __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) only (gfx9 encoding: expcnt/lgkmcnt fields left at max)
+              const int pos = si[u] * 1024 + wave * 64 + lane;
+              p[u] = pts[pos < N ? pos : N - 1];
+              if (pos >= N) p[u].w = -1.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < nb) {  // uniform
             const int pos = si[u] * 1024 + wave * 64 + lane;
-            p[u] = pts[pos < N ? pos : N - 1];
-            if (pos >= N) p[u].w = -1.f;
+            const bool valid = pos < N;
+            const float d = vlp3d_sumsq3(p[u].x - x1, p[u].y - y1, p[u].z - z1);
+            const float t = vmin(d, p[u].w);
+            if (si[u] < L) lpts[si[u] * 1024 + tid].w = t;
+            else if (valid) pts[pos].w = t;
+            const unsigned v = value_of(t, valid);
+            const unsigned vmax = wave_max_u32(v);
+            int wl = 0;
+            if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
+            const float wx = readlane_f32(p[u].x, wl), wy = readlane_f32(p[u].y, wl), wz = readlane_f32(p[u].z, wl);
+            if (lane + 64 * q == si[u]) { sval[q] = vmax; swl[q] = wl; sx[q] = wx; sy[q] = wy; sz[q] = wz; }
           }
         }
       }
+    }
+    // this lane's better slot (NS = 2): larger value; an exact tie is decided by the reference's order of the two winners
+    unsigned lv = sval[0];
+    int lsl = lane, lwl = swl[0];
+    float lx = sx[0], ly = sy[0], lz = sz[0];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u < nb) {  // uniform
-          const int pos = si[u] * 1024 + wave * 64 + lane;
-          const bool valid = pos < N;
-          const float d = vlp3d_sumsq3(p[u].x - x1, p[u].y - y1, p[u].z - z1);
-          const float t = vmin(d, p[u].w);
-          if (si[u] < L) lpts[si[u] * 1024 + tid].w = t;
-          else if (valid) pts[pos].w = t;
-          const unsigned v = value_of(t, valid);
-          const unsigned vmax = wave_max_u32(v);
-          int wl = 0;
-          if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
-          const float wx = readlane_f32(p[u].x, wl), wy = readlane_f32(p[u].y, wl), wz = readlane_f32(p[u].z, wl);
-          if (lane == si[u]) { sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz; }
-        }
+    for (int q = 1; q < NS; ++q) {
+      bool take = sval[q] > lv;
+      if (sval[q] == lv && lv != 0u && lane + 64 * q < nslots) {
+        const int pa = min(lsl * 1024 + wave * 64 + lwl, N - 1), pb = min((lane + 64 * q) * 1024 + wave * 64 + swl[q], N - 1);
+        take = tiekey(perm[pb]) > tiekey(perm[pa]);
       }
+      if (take) { lv = sval[q]; lsl = lane + 64 * q; lwl = swl[q]; lx = sx[q]; ly = sy[q]; lz = sz[q]; }
     }
     // wave candidate = best slot (ties between slots by the reference's order of their winners)
-    const unsigned mine = lane < nslots ? sval : 0u;
+    const unsigned mine = lsl < nslots ? lv : 0u;
     const unsigned vw = wave_max_u32(mine);
     int cl = 0;
-    if (vw != 0u) cl = winner_lane(mine, vw, min(lane * 1024 + wave * 64 + swl, N - 1));
-    const int cwl = __builtin_amdgcn_readlane(swl, cl);
-    const float cx = readlane_f32(sx, cl), cy = readlane_f32(sy, cl), cz = readlane_f32(sz, cl);
+    if (vw != 0u) cl = winner_lane(mine, vw, min(lsl * 1024 + wave * 64 + lwl, N - 1));
+    const int cwl = __builtin_amdgcn_readlane(lwl, cl), csl = __builtin_amdgcn_readlane(lsl, cl);
+    const float cx = readlane_f32(lx, cl), cy = readlane_f32(ly, cl), cz = readlane_f32(lz, cl);
     if (lane == 0) {
       s_val[par][wave] = vw;
-      s_pos[par][wave] = (unsigned)(cl * 1024 + wave * 64 + cwl);
+      s_pos[par][wave] = (unsigned)(csl * 1024 + wave * 64 + cwl);
       s_xyz[par][wave][0] = cx; s_xyz[par][wave][1] = cy; s_xyz[par][wave][2] = cz;
     }
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait ~1 us for the acknowledgement of the
@@ -358,10 +384,11 @@ extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
 }
 
 // Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
-// Requires N <= 65536 (64 slots per wave); same output as vlp3d_furthest_point_sampling.
+// Requires N <= 131072 (64 slots per wave and lane-slot; two lane-slots above 65536); same output as
+// vlp3d_furthest_point_sampling.
 extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
                                                     long long workspace_bytes, int *idx, void *stream) {
-  if (!xyz || !workspace || !idx || B < 1 || N < 1 || N > 65536 || m < 0 ||
+  if (!xyz || !workspace || !idx || B < 1 || N < 1 || N > 131072 || m < 0 ||
       workspace_bytes < vlp3d_fps_workspace_bytes(B, N))
     return VLP3D_EINVAL;
   if (m == 0) return VLP3D_OK;
@@ -387,13 +414,19 @@ extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int
   const size_t lds = (size_t)L * 1024 * sizeof(float4) + (size_t)m_lds * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)fps_pruned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       9 * 1024 * (int)sizeof(float4) + 2048 * (int)sizeof(int));
+    const int max_lds = 9 * 1024 * (int)sizeof(float4) + 2048 * (int)sizeof(int);
+    hipError_t e = hipFuncSetAttribute((const void *)fps_pruned_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)fps_pruned_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(fps_pruned_kernel, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N),
-                     L, m_lds);
+  if (nslots <= 64)
+    hipLaunchKernelGGL(fps_pruned_kernel<1>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N), L,
+                       m_lds);
+  else
+    hipLaunchKernelGGL(fps_pruned_kernel<2>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N), L,
+                       m_lds);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -49,7 +49,7 @@ int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *
 
 /* Same output as vlp3d_furthest_point_sampling, computed with distance-bound pruning (csrc/fps_pruned.hip):
  * points are Morton-sorted into 64-point slots and a slot whose bounding box is farther from the new sample than
- * its current maximum is skipped.  workspace: vlp3d_fps_workspace_bytes(B,N) bytes of scratch.  N <= 65536. */
+ * its current maximum is skipped.  workspace: vlp3d_fps_workspace_bytes(B,N) bytes of scratch.  N <= 131072. */
 long long vlp3d_fps_workspace_bytes(int B, int N);
 int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
                                          long long workspace_bytes, int *idx, void *stream);

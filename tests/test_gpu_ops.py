@@ -58,7 +58,8 @@ def test_fps_ties_and_skip_rule(pu, N):
     assert (got == orc.furthest_point_sampling(xyz, m)).all()
 
 
-@pytest.mark.parametrize("B,N,m", [(2, 9000, 300), (2, 20000, 512), (1, 40000, 700), (1, 65536, 64), (3, 5000, 5000)])
+@pytest.mark.parametrize("B,N,m", [(2, 9000, 300), (2, 20000, 512), (1, 40000, 700), (1, 65536, 64), (3, 5000, 5000),
+                                   (2, 80000, 300), (1, 131072, 96), (1, 65537, 128)])
 def test_fps_pruned_equals_dense_and_oracle(ext, B, N, m):
     """Distance-bound pruning must not change a single index (random surfaces-like data)."""
     synth = importlib.import_module("3dvlp_amd.synth")
@@ -70,7 +71,7 @@ def test_fps_pruned_equals_dense_and_oracle(ext, B, N, m):
     assert (pruned == orc.furthest_point_sampling(xyz, m)).all()
 
 
-@pytest.mark.parametrize("N", [1500, 9000, 36000])
+@pytest.mark.parametrize("N", [1500, 9000, 36000, 70000])
 def test_fps_pruned_ties_and_skip_rule(ext, N):
     rng = np.random.default_rng(N + 1)
     xyz = rng.integers(1, 4, size=(3, N, 3)).astype(np.float32)  # massive exact ties
