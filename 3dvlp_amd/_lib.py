@@ -68,7 +68,7 @@ SIGNATURES = {
     "vlp3d_box_decode_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_box_decode_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_linear_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp],
-    "vlp3d_linear_dgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp],
+    "vlp3d_linear_dgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_linear_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],

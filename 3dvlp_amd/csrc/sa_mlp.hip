@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
 // A wave owns one 32 x 32 output tile; grid = (row tiles / 4, N / 32).
 template <bool WT>
 __global__ __launch_bounds__(256) void linear_bf16_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
-                                                          int K, int ldw, const float *__restrict__ bias, long long R,
+                                                          int K, int ldw, const float *__restrict__ bias,
+                                                          const float *__restrict__ base, long long R,
                                                           float *__restrict__ Y, int ldy) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -361,8 +362,16 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(const float *__restric
       bw[4] = bf16_bits(b1.x); bw[5] = bf16_bits(b1.y); bw[6] = bf16_bits(b1.z); bw[7] = bf16_bits(b1.w);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc, 0, 0, 0);
     }
+    if (base) {  // + a same-shape tensor (the gradient arriving through a residual connection beside the layer)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Y[(tile * 32 + acc_row(i, half)) * ldy + c0 + r] = acc[i] + bv;
+      for (int i = 0; i < 16; ++i) {
+        const long long o = (tile * 32 + acc_row(i, half)) * ldy + c0 + r;
+        Y[o] = acc[i] + bv + base[o];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Y[(tile * 32 + acc_row(i, half)) * ldy + c0 + r] = acc[i] + bv;
+    }
   }
 }
 
@@ -1876,7 +1885,7 @@ extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bia
   if (!X || !W || !Y || R < 32 || (R & 31) || K < 8 || (K & 7)) return VLP3D_EINVAL;
   if (bf16_mma && R <= 65536 && N % 32 == 0 && N >= 32 && K % 16 == 0) {
     hipLaunchKernelGGL((linear_bf16_kernel<false>), dim3(grid_tiles(R), N / 32), dim3(256), 0, (hipStream_t)stream, X, K, W, K, 0,
-                       bias, R, Y, N);
+                       bias, nullptr, R, Y, N);
     VLP3D_LAUNCH_CHECK();
     return VLP3D_OK;
   }
@@ -1952,12 +1961,13 @@ extern "C" int vlp3d_sa_prep_weights(const float *W1, const float *W2, const flo
 }
 
 // dX (R x K) = dY (R x N) * W, W (N x K) row-major as stored by nn.Linear — no transposed copy of the weight.
-extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, int bf16_mma,
-                                  void *stream) {
+extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, const float *base,
+                                  int bf16_mma, void *stream) {
   if (!dY || !W || !dX || R < 32 || (R & 31) || N < 8 || (N & 7) || K < 32 || (K & 31)) return VLP3D_EINVAL;
+  if (base && !(bf16_mma && N % 16 == 0)) return VLP3D_EINVAL;  // the exact-fp32 form has no fused add: add it yourself
   if (bf16_mma && N % 16 == 0) {
     hipLaunchKernelGGL((linear_bf16_kernel<true>), dim3(grid_tiles(R), K / 32), dim3(256), 0, (hipStream_t)stream, dY, N, W, N, K,
-                       nullptr, R, dX, K);
+                       nullptr, base, R, dX, K);
     VLP3D_LAUNCH_CHECK();
     return VLP3D_OK;
   }

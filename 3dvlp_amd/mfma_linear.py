@@ -35,8 +35,9 @@ def supported(x, weight):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bf16_mma):
+    def forward(ctx, x, weight, bias, bf16_mma, with_residual=False):
         ctx.bf = int(bool(bf16_mma))
+        ctx.with_residual = bool(with_residual)
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         R, K = x2.shape
         N = weight.shape[0]
@@ -46,10 +47,13 @@ class _Linear(Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
+        if with_residual:  # x handed back as a second output: the caller routes its residual connection through it, and
+            # backward receives both gradients of x together (the add is then fused into the dX kernel)
+            return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x2, w = ctx.saved_tensors
         R, K = x2.shape
         N = w.shape[0]
@@ -57,11 +61,18 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, K), dtype=torch.float32, device=dy.device)
+            base = None
+            if dres is not None and ctx.bf and K % 32 == 0 and N % 16 == 0:
+                base = dres.reshape(R, K).contiguous()
             if K % 32 == 0:
-                _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx, ctx.bf)  # reads W (N,K) as stored: no transposed copy
+                _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx, base, ctx.bf)  # reads W (N,K) as stored: no transposed copy
             else:
                 _ext.call("vlp3d_linear_fwd", dy2, w.t().contiguous(), None, R, N, K, dx, ctx.bf)
             dx = dx.view(ctx.xshape)
+            if dres is not None and base is None:
+                dx = dx + dres
+        elif dres is not None:
+            dx = dres
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
@@ -77,7 +88,7 @@ class _Linear(Function):
                 db = dwb[N * K:]
         elif want_db:
             db = dy2.sum(0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class bf16_mma:
@@ -96,8 +107,12 @@ class bf16_mma:
         return False
 
 
-def linear(x, weight, bias=None, bf16_mma=None):
-    """F.linear on the MFMA kernels.  bf16_mma=None: the module default BF16_MMA."""
+def linear(x, weight, bias=None, bf16_mma=None, with_residual=False):
+    """F.linear on the MFMA kernels.  bf16_mma=None: the module default BF16_MMA.
+    with_residual=True returns (y, x_res): x_res is x, to be used for the residual connection around the layer — backward
+    then receives both gradients of x in one place and adds them inside the dX kernel (bf16 configuration)."""
     if supported(x, weight) and not torch.is_autocast_enabled("cuda"):
-        return _Linear.apply(x, weight, bias, BF16_MMA if bf16_mma is None else bf16_mma)
+        return _Linear.apply(x, weight, bias, BF16_MMA if bf16_mma is None else bf16_mma, with_residual)
+    if with_residual:
+        return F.linear(x, weight, bias), x
     return F.linear(x, weight, bias)

@@ -36,10 +36,18 @@ class ScaledDotProductAttention(nn.Module):
             nn.init.constant_(fc.bias, 0)
 
     def forward(self, queries, keys, values, attention_mask=None, attention_weights=None, way="add",
-                need_att=True):
+                need_att=True, with_residual=False):
         """queries (b,nq,d_model), keys/values (b,nk,d_model); attention_mask broadcastable to
         (b,h,nq,nk) with 0 = masked (filled with -10000); attention_weights (b,h,nq,nk).
-        Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran)."""
+        Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran).
+        with_residual: returns (out, att, q_res) — q_res is `queries` routed through the query projection's autograd
+        node (mfma_linear.linear(with_residual=True)), for the residual connection of the caller."""
+        if with_residual:
+            res = self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, True)
+            return res if len(res) == 3 else (res[0], res[1], queries)
+        return self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, False)
+
+    def _forward(self, queries, keys, values, attention_mask, attention_weights, way, need_att, wr):
         b_s, nq = queries.shape[:2]
         nk = keys.shape[1]
         if way not in ("add", "mul"):
@@ -51,16 +59,22 @@ class ScaledDotProductAttention(nn.Module):
             # keep the reference's names): q|k|v for self-attention, k|v for cross-attention; the attention kernels
             # take the column blocks as row-strided views and return one merged gradient
             aw = None if attention_weights is None else attention_weights.float()
+            q_res = None
             if queries is keys:
                 qkv = _linear(queries, merge_adjacent([self.fc_q.weight, self.fc_k.weight, self.fc_v.weight]),
-                              merge_adjacent([self.fc_q.bias, self.fc_k.bias, self.fc_v.bias]))
+                              merge_adjacent([self.fc_q.bias, self.fc_k.bias, self.fc_v.bias]), with_residual=wr)
+                if wr:
+                    qkv, q_res = qkv
                 out = fused_attention.sdpa_merged(qkv, None, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
             else:
-                q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
+                q = _linear(queries, self.fc_q.weight, self.fc_q.bias, with_residual=wr)
+                if wr:
+                    q, q_res = q
                 kv = _linear(keys, merge_adjacent([self.fc_k.weight, self.fc_v.weight]),
                              merge_adjacent([self.fc_k.bias, self.fc_v.bias]))
                 out = fused_attention.sdpa_merged(q, kv, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
-            return _linear(out, self.fc_o.weight, self.fc_o.bias), None
+            o = _linear(out, self.fc_o.weight, self.fc_o.bias)
+            return (o, None, q_res) if wr else (o, None)
         q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
         k = _linear(keys, self.fc_k.weight, self.fc_k.bias)
         v = _linear(values, self.fc_v.weight, self.fc_v.bias)
@@ -105,12 +119,12 @@ class MultiHeadAttention(nn.Module):
                                       need_att=output_attn)
             out = queries + self.dropout(torch.relu(out))
         else:
-            out, att = self.attention(queries, keys, values, attention_mask, attention_weights, way,
-                                      need_att=output_attn)
+            out, att, q_res = self.attention(queries, keys, values, attention_mask, attention_weights, way,
+                                             need_att=output_attn, with_residual=True)
             if self.fused_norm and add_norm.supported(queries, out, self.layer_norm):
-                out = add_norm.add_norm(queries, out, self.layer_norm, self.dropout.p, self.training)
+                out = add_norm.add_norm(q_res, out, self.layer_norm, self.dropout.p, self.training)
             else:
-                out = self.layer_norm(queries + self.dropout(out))
+                out = self.layer_norm(q_res + self.dropout(out))
         return (out, att) if output_attn else out
 
 
@@ -122,13 +136,17 @@ class PositionwiseFeedForward(nn.Module):
         self.relu = nn.ReLU()
         self.dropout = nn.Dropout(p=drop_prob)
 
-    def forward(self, x):
-        z = _linear(x, self.linear1.weight, self.linear1.bias)
+    def forward(self, x, with_residual=False):
+        """with_residual: returns (y, x_res) — x routed through linear1's autograd node for the caller's residual add."""
+        z = _linear(x, self.linear1.weight, self.linear1.bias, with_residual=with_residual)
+        if with_residual:
+            z, x_res = z
         if add_norm.act_dropout_supported(z) and not torch.is_autocast_enabled("cuda"):
             h = add_norm.act_dropout(z, "relu", self.dropout.p, self.training)  # relu + dropout: one launch each way
         else:
             h = self.dropout(self.relu(z))
-        return _linear(h, self.linear2.weight, self.linear2.bias)
+        y = _linear(h, self.linear2.weight, self.linear2.bias)
+        return (y, x_res) if with_residual else y
 
 
 class CrossAttentionDecoderLayer(nn.Module):
@@ -148,7 +166,7 @@ class CrossAttentionDecoderLayer(nn.Module):
     def forward(self, query, key, value, src_mask=None, src_trg_mask=None):
         x = self.self_attention(query, query, query, attention_mask=src_mask)
         x = self.enc_dec_attention(x, key, value, attention_mask=src_trg_mask)
-        f = self.ffn(x)
+        f, x_res = self.ffn(x, with_residual=True)
         if self.fused_norm and add_norm.supported(x, f, self.norm):
-            return add_norm.add_norm(x, f, self.norm, self.dropout.p, self.training)
-        return self.norm(self.dropout(f) + x)
+            return add_norm.add_norm(x_res, f, self.norm, self.dropout.p, self.training)
+        return self.norm(self.dropout(f) + x_res)

@@ -201,7 +201,9 @@ int vlp3d_sa_prep_weights(const float *W1, const float *W2, const float *W3, int
  * R <= 65536 for fwd; otherwise the exact-fp32 form runs). */
 int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
                      int bf16_mma, void *stream);
-int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, int bf16_mma, void *stream);
+int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, int N, int K, float *dX, const float *base, int bf16_mma,
+                       void *stream); /* base (R,K, optional, bf16_mma only): dX = dY W + base — the gradient that arrives
+                                         through a residual connection beside the layer, added in the epilogue */
 int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, int K, int N, float *dW, float *partials,
                        int max_blocks, int with_bias, int defer_reduce, int bf16_mma, void *stream);
 
