@@ -44,17 +44,23 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def time_kernel(fn, reps, inner=8):
-    """Mean duration (ms) of `fn` (one hand-written kernel launch): event pairs on the launch stream around `inner`
-    back-to-back launches (the kernels serialise on the stream; a pair around a single 30 us kernel would mostly
-    measure the launch path), averaged over `reps` such groups."""
+    """Mean duration (ms) of `fn` (one hand-written kernel launch, or the few launches of one entry point): `inner`
+    back-to-back launches are captured into a HIP graph — the way the step itself issues them — and event pairs on the
+    launch stream bracket each replay; averaged over `reps` replays.  (Issued from Python one by one, a 20 us kernel is
+    host-bound: the pair would mostly measure the launch path.)"""
     fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     total = 0.0
     for _ in range(reps):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(inner):
-            fn()
+        g.replay()
         e.record()
         e.synchronize()
         total += s.elapsed_time(e)
