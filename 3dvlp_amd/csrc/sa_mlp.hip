@@ -213,6 +213,90 @@ __device__ __forceinline__ void block_stats_to_slab(const double (&s1)[COUT / 32
   }
 }
 
+// SCATTER epilogue of the gather layer's backward: acc[ct][i] = element (row trow0 + acc_row(i, half), column 32 ct + r) of
+// the input-gradient tile; columns [0,C) -> d(features), [C,C+3) -> d(xyz) / -d(new_xyz), the rest is padding.
+// Ball query pads a ball with copies of its FIRST neighbour, so most rows of a ball add into the same point row (SA2 at
+// cfg2: 5.7 distinct neighbours of 32), and ALL rows of a ball add into the same centre: those rows are summed inside the
+// wave first (16 registers + one cross-half exchange) and leave as ONE atomic per column — 5x fewer memory-side atomics
+// at SA2, no 32-way contention on d(new_xyz).  Needs S a power of two >= 16 and whole balls / whole tiles aligned
+// (M*S % 32 == 0); other shapes take the row-by-row form.
+template <int NCT>
+__device__ __forceinline__ void scatter_rows(const RowGemmArgs &a, const f32x16 (&acc)[NCT], int trow0, int r, int half) {
+  const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
+  int pr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pr[i] = a.idx[trow0 + acc_row(i, half)];
+  const bool merge = a.S_shift >= 4 && tscene >= 0;
+  if (merge) {
+    const int groups = a.S >= 32 ? 1 : 2;  // balls per 32-row tile (S = 16: rows 0-15 / 16-31 = registers 0-7 / 8-15)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (g >= groups) break;
+      const int i0 = groups == 1 ? 0 : 8 * g, i1 = groups == 1 ? 16 : 8 * g + 8;
+      const int bm = (trow0 + 16 * g * (groups - 1)) >> a.S_shift;
+      const int p0 = a.idx[(long long)bm << a.S_shift];  // the ball's first neighbour = the padding value
+      const long long pn0 = (long long)tscene * a.N + p0;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 32 * ct + r;
+        float dup = 0.f, all = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < i0 || i >= i1) continue;
+          const float v = acc[ct][i];
+          all += v;
+          if (pr[i] == p0) dup += v;
+        }
+        dup += __shfl_xor(dup, 32);
+        all += __shfl_xor(all, 32);
+        if (half == 0) {
+          if (col < a.C) {
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn0 * a.C + col, dup);
+          } else if (col < a.C + 3) {
+            if (a.dxyz) atomicAdd(a.dxyz + pn0 * 3 + (col - a.C), dup / a.radius);
+            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -(all / a.radius));
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < i0 || i >= i1 || pr[i] == p0) continue;
+        const long long pn = (long long)tscene * a.N + pr[i];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int col = 32 * ct + r;
+          const float v = acc[ct][i];
+          if (col < a.C) {
+            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
+          } else if (col < a.C + 3) {
+            if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), v / a.radius);
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rr = trow0 + acc_row(i, half);
+    const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+    const int b = tscene >= 0 ? tscene : bm / a.M;
+    const long long pn = (long long)b * a.N + pr[i];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int col = 32 * ct + r;
+      const float v = acc[ct][i];
+      if (col < a.C) {
+        if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
+      } else if (col < a.C + 3) {
+        const float gv = v / a.radius;
+        if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
+        if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
+      }
+    }
+  }
+}
+
 template <typename T, int COUT, int LOADER, int EPI>
 __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   constexpr int NCT = COUT / 32;
@@ -292,33 +376,8 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
         for (int i = 0; i < 16; ++i)
           st1(Y + (tile * 32 + acc_row(i, half)) * a.ldout + 32 * ct + r, acc[ct][i] + bv);
       }
-    } else {  // SCATTER: columns [0,C) -> d(features), [C,C+3) -> d(xyz), the rest is padding
-      // 32-bit index math, the scene index once per tile when a tile cannot straddle scenes: the 64-bit divisions per
-      // accumulator row were 32 multi-instruction sequences per lane and tile
-      const int trow0 = (int)(tile * 32);
-      const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
-      int pr[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pr[i] = a.idx[trow0 + acc_row(i, half)];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rr = trow0 + acc_row(i, half);
-        const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
-        const int b = tscene >= 0 ? tscene : bm / a.M;
-        const long long pn = (long long)b * a.N + pr[i];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int col = 32 * ct + r;
-          const float v = acc[ct][i];
-          if (col < a.C) {
-            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
-          } else if (col < a.C + 3) {
-            const float gv = v / a.radius;
-            if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
-            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
-          }
-        }
-      }
+    } else {  // SCATTER
+      scatter_rows<NCT>(a, acc, (int)(tile * 32), r, half);
     }
   }
 
@@ -811,32 +870,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         *reinterpret_cast<uint4 *>(G + (long long)row * a.ldout + ch * 8) = *reinterpret_cast<const uint4 *>(sA + row * lde + ch * 8);
       }
     } else {
-      // 32-bit index math, the scene index once per tile when a tile cannot straddle scenes: the 64-bit divisions per
-      // accumulator row were 32 multi-instruction sequences per lane and tile
-      const int trow0 = (int)(tile * 32);
-      const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
-      int pr[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pr[i] = a.idx[trow0 + acc_row(i, half)];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rr = trow0 + acc_row(i, half);
-        const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
-        const int b = tscene >= 0 ? tscene : bm / a.M;
-        const long long pn = (long long)b * a.N + pr[i];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int col = 32 * ct + r;
-          const float v = acc[ct][i];
-          if (col < a.C) {
-            if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
-          } else if (col < a.C + 3) {
-            const float gv = v / a.radius;
-            if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
-            if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
-          }
-        }
-      }
+      scatter_rows<NCT>(a, acc, (int)(tile * 32), r, half);
     }
   }
 
