@@ -34,6 +34,7 @@ struct RowsArgs {
   const float *W;
   int ldw, wt;
   int bfm;  // bf16 MFMA operands (rounded in registers), fp32 I/O and accumulation: the timing configuration
+  int wlds; // bfm && !wt: the workgroup's 128 x K weight block is staged ONCE in LDS as bf16 (set by launch() when it fits)
   int K, N;
   long long R;
   float *Y;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void w_mma(const float *sa, int kbase, int half, cons
 
 template <int LOADER, int EPI>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sA[];  // [32][K + 4]
+  extern __shared__ __attribute__((aligned(16))) float sA[];  // [32][K + 4]; then, with a.wlds, bf16 sW[128][K + 4]
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c0 = blockIdx.y * 128 + 32 * wave, col = c0 + r;  // this wave's 32 output columns
@@ -127,11 +128,28 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
     k_a = ld4(a.bn5 + scol); k_b = ld4(a.bn5 + a.K + scol); k_c = ld4(a.bn5 + 2 * a.K + scol);
     k_d = ld4(a.bn5 + 3 * a.K + scol); k_e = ld4(a.bn5 + 4 * a.K + scol);
   }
+  // A row-major weight has every lane of a fragment load on a different row (32 cache lines per instruction: the forward
+  // product ran 11 us where the K-major dX product of the same size ran 6); staged through LDS the global reads are
+  // coalesced row segments, read once per workgroup instead of once per tile, and the fragments are two ds_read_b64.
+  const int wld = a.K + 4;  // shorts per staged weight row
+  short *sW = reinterpret_cast<short *>(sA + 32 * lds_ld);
+  if (a.wlds) {
+    const int k4n = a.K / 4;
+    for (int c = threadIdx.x; c < 128 * k4n; c += 256) {
+      const int n = c / k4n, k4 = c - n * k4n;
+      const int gcol = blockIdx.y * 128 + n;
+      const float4 wv = gcol < a.N ? ld4(a.W + (long long)gcol * a.ldw + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      short4 pk;
+      pk.x = bf16_bits_(wv.x); pk.y = bf16_bits_(wv.y); pk.z = bf16_bits_(wv.z); pk.w = bf16_bits_(wv.w);
+      *reinterpret_cast<short4 *>(sW + n * wld + 4 * k4) = pk;
+    }
+    // visible after the first __syncthreads() of the tile loop below
+  }
   double s1 = 0.0, s2 = 0.0;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long row0 = tile * 32;
     WChunk wa, wb;
-    if (active) w_load(a, col, 0, half, wa);
+    if (active && !a.wlds) w_load(a, col, 0, half, wa);
     // ---- stage the A tile: 8 chunks (+ 8 of G) per thread in flight, then transform and write to LDS
     for (int e0 = threadIdx.x; e0 < nch; e0 += 256 * 8) {
       float4 x[8], g[8];
@@ -163,7 +181,18 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (active) {
+    if (active && a.wlds) {
+      const float *sa = sA + r * lds_ld;
+      const short *sw = sW + (32 * wave + r) * wld + 4 * half;
+      for (int kb = 0; kb < a.K; kb += 16) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(sa + kb + 4 * half);
+        const float4 a1 = *reinterpret_cast<const float4 *>(sa + kb + 8 + 4 * half);
+        const short4 w0 = *reinterpret_cast<const short4 *>(sw + kb), w1 = *reinterpret_cast<const short4 *>(sw + kb + 8);
+        bf16x8_t bw;
+        bw[0] = w0.x; bw[1] = w0.y; bw[2] = w0.z; bw[3] = w0.w; bw[4] = w1.x; bw[5] = w1.y; bw[6] = w1.z; bw[7] = w1.w;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_bf16x8(a0, a1), bw, acc, 0, 0, 0);
+      }
+    } else if (active) {
       const float *sa = sA + r * lds_ld;
       for (int kb = 0; kb < a.K; kb += 64) {
         if (kb + 32 < a.K) w_load(a, col, kb + 32, half, wb);
@@ -172,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
         if (kb + 64 < a.K) w_load(a, col, kb + 64, half, wa);
         w_mma(sa, kb + 32, half, wb, acc, a.bfm);
       }
+    }
+    if (active) {
       // acc[i] = element (row row0 + acc_row(i, half), column col)
       if (EPI == STORE) {
         float ps = 0.f, pq = 0.f;
@@ -335,14 +366,18 @@ unsigned rows_blocks(long long R) {
 template <int LOADER, int EPI>
 int launch(const RowsArgs &a, hipStream_t s) {
   const dim3 grid(rows_blocks(a.R), (a.N + 127) / 128);
-  const size_t lds = (size_t)32 * (a.K + 4) * sizeof(float);
+  size_t lds = (size_t)32 * (a.K + 4) * sizeof(float);
+  RowsArgs b = a;
+  const size_t wbytes = (size_t)128 * (a.K + 4) * sizeof(short);
+  b.wlds = a.bfm && !a.wt && a.K % 16 == 0 && lds + wbytes <= 100 * 1024;
+  if (b.wlds) lds += wbytes;
   auto kern = rows_gemm_kernel<LOADER, EPI>;
   if (lds > 64 * 1024) {
     if (lds > 150 * 1024) return VLP3D_EINVAL;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -402,24 +402,35 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(const float *__restric
     const float *wr = WT ? W + (long long)(8 * half) * ldw + c0 + r : W + (long long)(c0 + r) * K + 8 * half;
     f32x16 acc = zero16();
     const int ng = K / 16;
-#pragma unroll 4
-    for (int g = 0; g < ng; ++g) {
-      const float4 a0 = ld4(xr + 16 * g), a1 = ld4(xr + 16 * g + 4);
-      float4 b0, b1;
-      if (WT) {
-        const float *wp = wr + (long long)(16 * g) * ldw;
-        b0 = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
-        b1 = make_float4(wp[4 * ldw], wp[5 * ldw], wp[6 * ldw], wp[7 * ldw]);
-      } else {
-        b0 = ld4(wr + 16 * g);
-        b1 = ld4(wr + 16 * g + 4);
+    // eight K-groups (128 columns) per round: ALL their loads are issued before the first product, so a wave pays one
+    // memory latency per 128 columns instead of one per 16 (the rolled loop was 8 dependent round trips at K = 128)
+    for (int g0 = 0; g0 < ng; g0 += 8) {
+      float4 a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int g = min(g0 + u, ng - 1);  // clamped: unconditional loads (the extra groups of a short tail are not used)
+        a0[u] = ld4(xr + 16 * g);
+        a1[u] = ld4(xr + 16 * g + 4);
+        if (WT) {
+          const float *wp = wr + (long long)(16 * g) * ldw;
+          b0[u] = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+          b1[u] = make_float4(wp[4 * ldw], wp[5 * ldw], wp[6 * ldw], wp[7 * ldw]);
+        } else {
+          b0[u] = ld4(wr + 16 * g);
+          b1[u] = ld4(wr + 16 * g + 4);
+        }
       }
-      bf16x8 av, bw;
-      av[0] = bf16_bits(a0.x); av[1] = bf16_bits(a0.y); av[2] = bf16_bits(a0.z); av[3] = bf16_bits(a0.w);
-      av[4] = bf16_bits(a1.x); av[5] = bf16_bits(a1.y); av[6] = bf16_bits(a1.z); av[7] = bf16_bits(a1.w);
-      bw[0] = bf16_bits(b0.x); bw[1] = bf16_bits(b0.y); bw[2] = bf16_bits(b0.z); bw[3] = bf16_bits(b0.w);
-      bw[4] = bf16_bits(b1.x); bw[5] = bf16_bits(b1.y); bw[6] = bf16_bits(b1.z); bw[7] = bf16_bits(b1.w);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads above the products (the scheduler otherwise re-serialises them)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (g0 + u >= ng) a0[u] = a1[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // branch-free tail: a zero operand adds nothing
+        bf16x8 av, bw;
+        av[0] = bf16_bits(a0[u].x); av[1] = bf16_bits(a0[u].y); av[2] = bf16_bits(a0[u].z); av[3] = bf16_bits(a0[u].w);
+        av[4] = bf16_bits(a1[u].x); av[5] = bf16_bits(a1[u].y); av[6] = bf16_bits(a1[u].z); av[7] = bf16_bits(a1[u].w);
+        bw[0] = bf16_bits(b0[u].x); bw[1] = bf16_bits(b0[u].y); bw[2] = bf16_bits(b0[u].z); bw[3] = bf16_bits(b0[u].w);
+        bw[4] = bf16_bits(b1[u].x); bw[5] = bf16_bits(b1[u].y); bw[6] = bf16_bits(b1[u].z); bw[7] = bf16_bits(b1[u].w);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc, 0, 0, 0);
+      }
     }
     if (base) {  // + a same-shape tensor (the gradient arriving through a residual connection beside the layer)
 #pragma unroll

@@ -17,6 +17,6 @@ for R, K, N in ((16384, 128, 128), (16384, 128, 256), (16384, 256, 128), (2048, 
     y = torch.empty(R, N, device=dev); dy = torch.randn(R, N, device=dev); dx = torch.empty(R, K, device=dev)
     nblk = max(16, min(256, R // 64)); dwb = torch.empty(N * K + N, device=dev); part = torch.empty(nblk, N * K + N, device=dev)
     f = t(lambda: ext.call("vlp3d_linear_fwd", x, w, b, R, K, N, y, BF))
-    g = t(lambda: ext.call("vlp3d_linear_dgrad", dy, w, R, N, K, dx, BF))
+    g = t(lambda: ext.call("vlp3d_linear_dgrad", dy, w, R, N, K, dx, None, BF))
     h = t(lambda: ext.call("vlp3d_linear_wgrad", dy, x, R, K, N, dwb, part, nblk, 1, 0, BF))
     print(f"R={R} K={K} N={N}: fwd {f:6.1f} us  dgrad {g:6.1f} us  wgrad+reduce {h:6.1f} us")
