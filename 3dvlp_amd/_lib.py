@@ -36,14 +36,15 @@ SIGNATURES = {
     "vlp3d_nn_distance": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_group_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vlp3d_group_rows_grad": [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
-    "vlp3d_sa_fwd_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp, _i, _vp],
-    "vlp3d_sa_fwd_layer": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],
-    "vlp3d_sa_pool": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "vlp3d_sa_compact": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_sa_fwd_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_fwd_layer": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_pool": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "vlp3d_sa_pool_grad": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp],
-    "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
+    "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
-                       _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+                       _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
     "vlp3d_copy_batch": [_vp, _i, _vp],
     "vlp3d_smallk_fwd": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
@@ -298,6 +299,18 @@ def three_interpolate_grad(grad_out, idx, weight, m):
         _check(load().vlp3d_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, int(m), _p(out),
                                                    _stream()), "three_interpolate_grad")
     return out
+
+
+def sa_compact(idx, N):
+    """Compact row map of a grouped MLP from the ball-query indices (csrc/sa_compact.hip): idx (B,M,S) i32, N = points per
+    scene -> rowptr (B*M + 1) i32 with the number of distinct rows in the last entry, crow (B*M*S, 4) i32."""
+    _chk_int(idx, "idx")
+    B, M, S = idx.shape
+    rowptr = torch.empty((B * M + 1,), dtype=torch.int32, device=idx.device)
+    crow = torch.empty((B * M * S, 4), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(load().vlp3d_sa_compact(_p(idx), B, int(N), M, S, _p(rowptr), _p(crow), _stream()), "sa_compact")
+    return rowptr, crow
 
 
 def three_interpolate_grad_asshipped(grad_out, idx, weight, m):

@@ -1,0 +1,101 @@
+// Compact row map of a grouped MLP (csrc/sa_mlp.hip, bf16 configuration).
+//
+// ball_query pads a ball that holds fewer than nsample points with copies of its FIRST neighbour
+// (ball_query_gpu.cu:14-49), and the reference pushes the padded (B, C, npoint, nsample) tensor through the whole
+// SharedMLP.  Every copy of a row yields the same pre-activations; BatchNorm sees the copies only through their
+// multiplicity in the batch sums and max-pooling not at all.  The stack is therefore evaluated on the DISTINCT rows:
+//   * batch sums  sum_r f(y_r)             = sum_u w_u f(y_u)      (w_u = multiplicity: 1, or nsample - cnt + 1 for the
+//                                                                 ball's first neighbour)
+//   * BatchNorm backward of one copy        dy = k1 (g - k2 - yhat k3); summed over the copies of u:
+//                                           dY_u = k1 (G_u - w_u (k2 + yhat_u k3)),  G_u = sum of the copies' g
+//   * everything downstream of dY (dX = dY W^T, dW = dY^T A, ReLU masks, the scatter) is linear in it.
+// At cfg2 39 % of SA1's and 18 % of SA2's rows are distinct (tools/dup_fraction.py).
+//
+// The map is computed once per batch next to the ball query (side stream): rowptr[bm] = first compact row of ball bm
+// (rowptr[B*M] = number of compact rows P), crow[r'] = (global point row b*N + idx, (bm << 8) | s, float bits of w, 0);
+// rows P .. roundup32(P)-1 are dummies (point 0, s = 255, w = 0) so that the kernels can work on whole 32-row tiles.
+#include "common.h"
+
+namespace {
+
+// cnt[bm] = number of distinct neighbours = position of the first repeat of idx[bm][0] (S if there is none)
+__global__ __launch_bounds__(256) void sa_cnt_kernel(const int *__restrict__ idx, int nb, int S, int *__restrict__ cnt) {
+  const int bm = blockIdx.x * 256 + threadIdx.x;
+  if (bm >= nb) return;
+  const int *p = idx + (long long)bm * S;
+  const int first = p[0];
+  int c = S;
+  for (int s = 1; s < S; ++s)
+    if (p[s] == first) { c = s; break; }
+  cnt[bm] = c;
+}
+
+// in-place exclusive scan of v[0..n) by ONE workgroup; v[n] = total
+__global__ __launch_bounds__(1024) void sa_scan_kernel(int *__restrict__ v, int n) {
+  __shared__ int wtot[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const int mine = i < n ? v[i] : 0;
+    int inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int w = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int t = __shfl_up(w, off);
+      if (lane >= off) w += t;
+    }
+    const int before = wave > 0 ? __shfl(w, wave - 1) : 0, all = __shfl(w, 15);
+    if (i < n) v[i] = carry_s + before + inc - mine;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) v[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void sa_fill_kernel(const int *__restrict__ idx, int B, int N, int M, int S,
+                                                      const int *__restrict__ rowptr, int4 *__restrict__ crow) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long R = (long long)B * M * S;
+  const int nb = B * M;
+  if (t < 32) {  // dummy rows that complete the last tile
+    const int P = rowptr[nb];
+    const int r = P + (int)t;
+    if (r < ((P + 31) & ~31)) crow[r] = make_int4(0, 255, __float_as_int(0.f), 0);
+  }
+  if (t >= R) return;
+  const int bm = (int)(t / S), s = (int)(t - (long long)bm * S);
+  const int r0 = rowptr[bm], cnt = rowptr[bm + 1] - r0;
+  if (s >= cnt) return;
+  const int b = bm / M;
+  const float w = s == 0 ? (float)(S - cnt + 1) : 1.f;
+  crow[r0 + s] = make_int4(b * N + idx[t], (bm << 8) | s, __float_as_int(w), 0);
+}
+
+}  // namespace
+
+// rowptr: (B*M + 1) ints; crow: (B*M*S) int4 (worst case: every row distinct).  S <= 255, B*M < 2^23, B*N < 2^31.
+extern "C" int vlp3d_sa_compact(const int *idx, int B, int N, int M, int S, int *rowptr, void *crow, void *stream) {
+  if (!idx || !rowptr || !crow || B < 1 || N < 1 || M < 1 || S < 1 || S > 255 || (long long)B * M >= (1ll << 23) ||
+      (long long)B * N >= (1ll << 31) || (long long)B * M * S >= (1ll << 31))
+    return VLP3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = B * M;
+  hipLaunchKernelGGL(sa_cnt_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, idx, nb, S, rowptr);
+  hipLaunchKernelGGL(sa_scan_kernel, dim3(1), dim3(1024), 0, s, rowptr, nb);
+  const long long R = (long long)nb * S;
+  hipLaunchKernelGGL(sa_fill_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, idx, B, N, M, S, rowptr,
+                     (int4 *)crow);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}

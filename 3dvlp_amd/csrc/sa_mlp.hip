@@ -97,7 +97,32 @@ struct RowGemmArgs {
   int S_shift;             // GATHER: log2(S) when S is a power of two, else -1
   int tile_scene;          // GATHER in row_gemm_lds: 1 when M*S % 32 == 0 (a 32-row tile never straddles two scenes)
   int ldw;                 // BIAS_WT: the weight is given K-major, (K x ldw) row-major (dX = dY W without a transpose)
+  // Compact row map (csrc/sa_compact.hip; bf16 LDS kernels only).  crow == NULL: dense rows r = (b*M + m)*S + s.
+  // Otherwise the matrices hold the DISTINCT rows of every ball back to back: crow[r] = (global point row, (ball << 8) |
+  // position in the ball, float bits of the row's multiplicity w, 0); rowptr[ball] = first compact row of the ball,
+  // rowptr[nballs] = number of compact rows (read on the device: the grid is sized for the dense worst case).
+  const int4 *crow;
+  const int *rowptr;
+  int nballs;
 };
+
+__device__ __forceinline__ long long compact_tiles(const RowGemmArgs &a) {
+  return a.crow ? ((long long)a.rowptr[a.nballs] + 31) / 32 : a.R / 32;
+}
+__device__ __forceinline__ float row_weight(const RowGemmArgs &a, int row) {
+  return a.crow ? __int_as_float(reinterpret_cast<const int *>(a.crow + row)[2]) : 1.f;
+}
+// (ball, position of the row inside its ball): the pooled-gradient synthesis of the last layer's BatchNorm backward
+__device__ __forceinline__ void ball_of_row(const RowGemmArgs &a, int row, int &bm, int &sidx) {
+  if (a.crow) {
+    const int pk = reinterpret_cast<const int *>(a.crow + row)[1];
+    bm = pk >> 8;
+    sidx = pk & 255;
+  } else {
+    bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+    sidx = row - bm * a.pool_S;
+  }
+}
 
 template <typename T, int LOADER>
 __device__ __forceinline__ float4 load_a4(const RowGemmArgs &a, long long row, int col0, long long gather_base,
@@ -222,6 +247,27 @@ __device__ __forceinline__ void block_stats_to_slab(const double (&s1)[COUT / 32
 // (M*S % 32 == 0); other shapes take the row-by-row form.
 template <int NCT>
 __device__ __forceinline__ void scatter_rows(const RowGemmArgs &a, const f32x16 (&acc)[NCT], int trow0, int r, int half) {
+  if (a.crow) {  // compact rows: the copies are already summed, every row carries its global point row and its ball
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int4 cr = a.crow[trow0 + acc_row(i, half)];
+      const long long pn = cr.x;
+      const int bm = cr.y >> 8;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 32 * ct + r;
+        const float v = acc[ct][i];
+        if (col < a.C) {
+          if (a.dfeat_pm) atomicAdd(a.dfeat_pm + pn * a.C + col, v);
+        } else if (col < a.C + 3) {
+          const float gv = v / a.radius;
+          if (a.dxyz) atomicAdd(a.dxyz + pn * 3 + (col - a.C), gv);
+          if (a.dnew_xyz) atomicAdd(a.dnew_xyz + (long long)bm * 3 + (col - a.C), -gv);
+        }
+      }
+    }
+    return;
+  }
   const int tscene = a.tile_scene ? trow0 / (a.M * a.S) : -1;
   int pr[16];
 #pragma unroll
@@ -525,14 +571,14 @@ __device__ __forceinline__ void raw_load_pf(const RowGemmArgs &a, int row, int c
 }
 template <int LOADER>
 __device__ __forceinline__ uint4 finish_pf(const RawPF<LOADER == BNBWD> &w, const float (&ca)[8], const float (&cb)[8],
-                                           const float (&cc)[8]) {
+                                           const float (&cc)[8], float mult) {
   float y[8], o[8];
   unpack8(w.y, y);
   if constexpr (LOADER == BNBWD) {
     float g[8];
     unpack8(w.g, g);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], __builtin_fmaf(cb[i], y[i], cc[i]));
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], mult * __builtin_fmaf(cb[i], y[i], cc[i]));
   } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(0.f, __builtin_fmaf(y[i], ca[i], cb[i]));
@@ -564,7 +610,8 @@ __device__ __forceinline__ void raw_load8(const RowGemmArgs &a, int row, int col
   w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
   if (LOADER == BNBWD) {
     if (a.pool_g != nullptr) {  // kernel-uniform
-      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+      int bm, sidx_;
+      ball_of_row(a, row, bm, sidx_);
       const long long off = (long long)bm * a.ldin + col0;
       w.dp0 = ld4(a.pool_g + off);
       w.dp1 = ld4(a.pool_g + off + 4);
@@ -585,9 +632,11 @@ __device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Ra
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(0.f, __builtin_fmaf(y[i], ca[i], cb[i]));
   } else {
     float g[8];
+    const float mult = row_weight(a, row);
     if (a.pool_g != nullptr) {
-      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
-      const unsigned sidx = (unsigned)(row - bm * a.pool_S);
+      int bm_, si_;
+      ball_of_row(a, row, bm_, si_);
+      const unsigned sidx = (unsigned)si_;
       const float dp[8] = {w.dp0.x, w.dp0.y, w.dp0.z, w.dp0.w, w.dp1.x, w.dp1.y, w.dp1.z, w.dp1.w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -598,7 +647,7 @@ __device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Ra
       unpack8(w.g, g);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], __builtin_fmaf(cb[i], y[i], cc[i]));
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], mult * __builtin_fmaf(cb[i], y[i], cc[i]));
   }
   return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
 }
@@ -618,7 +667,8 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   const int wtile = 32 * (ldw > lde ? ldw : lde);  // per-wave LDS tile, shared by the A operand and the epilogue
   bf16 *sW = reinterpret_cast<bf16 *>(smem);
   bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * wtile;
-  const long long ntiles = a.R / 32;
+  const long long ntiles = compact_tiles(a);
+  const bool compact = a.crow != nullptr;
 
   {  // stage the weight once per workgroup
     const bf16 *W = reinterpret_cast<const bf16 *>(a.W);
@@ -644,7 +694,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   // the tile's matrix products) and waits for idx before it can ask for a feature row.
   constexpr int MAXCH = 10;  // chunks per lane: 32 * (K/8) / 64, K <= 160
   constexpr bool GATHER_PREFETCH = VLP3D_GATHER_PREFETCH != 0;
-  const bool fastg = LOADER == GATHER && a.tile_scene && nch <= 64 * MAXCH;
+  const bool fastg = LOADER == GATHER && (a.tile_scene || compact) && nch <= 64 * MAXCH;
   int crow[MAXCH], ccol[MAXCH], pidx[MAXCH];
   const long long tile_step = (long long)gridDim.x * 4;
   // The gathered rows of tile t+1 are requested BEFORE tile t goes to the matrix cores and stay in registers (gv0 / gv1)
@@ -658,9 +708,10 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   int prow = 0;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   const float inv_radius = 1.f / a.radius;
+  auto src_index = [&](long long row) -> int { return compact ? a.crow[row].x : a.idx[row]; };
   auto gather_issue = [&](long long tile) {  // pidx / prow hold the indices of `tile`
     const int row0 = (int)(tile * 32);
-    const int scene = row0 / (a.M * a.S);  // wave-uniform (R < 2^31)
+    const int scene = compact ? 0 : row0 / (a.M * a.S);  // wave-uniform (R < 2^31); compact rows carry global point rows
     const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
     const float *xbase = a.xyz + (long long)scene * a.N * 3;
 #pragma unroll
@@ -684,7 +735,8 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       if (64 * u + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[u] * ldw + ccol[u]) = pack8(gv0[u], gv1[u]);
     if (lane < 32) {  // same wave, later instruction: lands after the chunk writes above
       const int rr = row0 + lane;
-      const int bm = a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S;
+      const int bm = compact ? (reinterpret_cast<const int *>(a.crow + rr)[1] >> 8)
+                             : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
       const float *cc3 = a.new_xyz + (long long)bm * 3;  // a handful of L1-resident centres per tile
       *reinterpret_cast<uint2 *>(sA + lane * ldw + a.C) =
           pack4(make_float4((qx - cc3[0]) * inv_radius, (qy - cc3[1]) * inv_radius, (qz - cc3[2]) * inv_radius, 0.f));
@@ -706,14 +758,14 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
     if (vt0 < vend) {
       const long long t0 = map_tile(vt0);
 #pragma unroll
-      for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t0 * 32 + crow[u]];
-      prow = a.idx[t0 * 32 + (lane & 31)];
+      for (int u = 0; u < MAXCH; ++u) pidx[u] = src_index(t0 * 32 + crow[u]);
+      prow = src_index(t0 * 32 + (lane & 31));
       if (GATHER_PREFETCH) {
         gather_issue(t0);
         const long long t1 = map_tile(vt0 + vstep < vend ? vt0 + vstep : vt0);
 #pragma unroll
-        for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t1 * 32 + crow[u]];
-        prow = a.idx[t1 * 32 + (lane & 31)];
+        for (int u = 0; u < MAXCH; ++u) pidx[u] = src_index(t1 * 32 + crow[u]);
+        prow = src_index(t1 * 32 + (lane & 31));
       }
     }
   }
@@ -743,14 +795,14 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
           gather_issue(map_tile(vnext));  // in flight during the MFMAs / epilogue of this tile
           const long long t2 = map_tile(vnext + vstep < vend ? vnext + vstep : vnext);
 #pragma unroll
-          for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t2 * 32 + crow[u]];
-          prow = a.idx[t2 * 32 + (lane & 31)];
+          for (int u = 0; u < MAXCH; ++u) pidx[u] = src_index(t2 * 32 + crow[u]);
+          prow = src_index(t2 * 32 + (lane & 31));
         }
       } else {
         const long long t1 = map_tile(vnext < vend ? vnext : vt);
 #pragma unroll
-        for (int u = 0; u < MAXCH; ++u) pidx[u] = a.idx[t1 * 32 + crow[u]];  // in flight during the MFMAs / epilogue
-        prow = a.idx[t1 * 32 + (lane & 31)];
+        for (int u = 0; u < MAXCH; ++u) pidx[u] = src_index(t1 * 32 + crow[u]);  // in flight during the MFMAs / epilogue
+        prow = src_index(t1 * 32 + (lane & 31));
       }
     }
     // BN loaders with K <= 128 (at most 8 chunks per lane): the whole NEXT tile is requested before this tile goes to the
@@ -762,7 +814,8 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         const int c = 64 * u + lane;
         if (c < nch) {
           const int row = c >> kshift, ch = c & (kc - 1);
-          *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish_pf<HOIST ? LOADER : BNRELU>(hp[u], ca, cb, cc);
+          *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) =
+              finish_pf<HOIST ? LOADER : BNRELU>(hp[u], ca, cb, cc, LOADER == BNBWD ? row_weight(a, row0 + row) : 1.f);
         }
       }
       const long long vnext = vt + vstep;
@@ -833,6 +886,9 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
     if (EPI == STORE) {
       constexpr bool STAGED = COUT <= 128;  // wider outputs: the 2-byte LDS writes cost more than they save
       T *Y = reinterpret_cast<T *>(a.Yout) + (long long)row0 * a.ldout;
+      float wr[16];  // multiplicity of this lane's 16 accumulator rows in the BatchNorm batch sums (1 without a row map)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wr[i] = row_weight(a, row0 + acc_row(i, half));
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         float ps = 0.f, pq = 0.f;
@@ -841,8 +897,8 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
           const float v = acc[ct][i];
           if (STAGED) sA[acc_row(i, half) * lde + 32 * ct + r] = __float2bfloat16(v);
           else st1(Y + (long long)acc_row(i, half) * a.ldout + 32 * ct + r, v);
-          ps += v;
-          pq += v * v;
+          ps += wr[i] * v;
+          pq += wr[i] * (v * v);
         }
         s1[ct] += (double)ps;
         s2[ct] += (double)pq;
@@ -915,9 +971,10 @@ __global__ __launch_bounds__(256) void pool_kernel(const T *__restrict__ Y, int 
 // Same result, 8 channels per thread: 16-byte (bf16) / 2 x 16-byte (fp32) row segments, four rows in flight.  The
 // one-channel form reads 2 bytes per lane per dependent iteration and is latency bound (SA1: 174 us for 268 MB).
 template <typename T>
-__global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int S, int C, long long BM,
+__global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int S_dense, int C, long long BM,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                    float *__restrict__ out, unsigned char *__restrict__ sel_idx) {
+                                                    float *__restrict__ out, unsigned char *__restrict__ sel_idx,
+                                                    const int *__restrict__ rowptr) {
   const int c8n = C / 8;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= BM * c8n) return;
@@ -925,7 +982,11 @@ __global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int
   const int c0 = (int)(t - bm * c8n) * 8;
   float sc[8], best[8];
   int bi[8];
-  const T *p = Y + (bm * S) * C + c0;
+  // compact row map: the ball's distinct rows are rowptr[bm] .. rowptr[bm+1]-1 (the padded copies never win a strict
+  // comparison, so the selected position is the same as over the padded ball)
+  const long long r0 = rowptr ? rowptr[bm] : bm * S_dense;
+  const int S = rowptr ? rowptr[bm + 1] - (int)r0 : S_dense;
+  const T *p = Y + r0 * C + c0;
   auto row8 = [&](const T *q, float (&v)[8]) {
     const float4 a = ld4(q), b = ld4(q + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -1050,8 +1111,8 @@ __device__ __forceinline__ uint4 load_dy8_bf(const RowGemmArgs &a, int row, int 
   float y[8], g[8];
   unpack8(yr, y);
   if (a.pool_g != nullptr) {  // kernel-uniform
-    const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
-    const int sidx = row - bm * a.pool_S;
+    int bm, sidx;
+    ball_of_row(a, row, bm, sidx);
     const long long off = (long long)bm * a.ldin + col0;
     const float4 d0 = ld4(a.pool_g + off), d1 = ld4(a.pool_g + off + 4);
     const uint2 sl = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
@@ -1061,6 +1122,16 @@ __device__ __forceinline__ uint4 load_dy8_bf(const RowGemmArgs &a, int row, int 
     g[6] = (int)((sl.y >> 16) & 255u) == sidx ? d1.z : 0.f; g[7] = (int)(sl.y >> 24) == sidx ? d1.w : 0.f;
   } else {
     unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0), g);
+  }
+  if (a.crow) {  // compact rows: dY summed over the copies = k1 G + w (cb y + cc)  (bf16 folded constants: k1, k2 = cb, k3 = cc)
+    const float mult = row_weight(a, row);
+    float o[8];
+    const float ca[8] = {klo.k1.x, klo.k1.y, klo.k1.z, klo.k1.w, khi.k1.x, khi.k1.y, khi.k1.z, khi.k1.w};
+    const float cb[8] = {klo.k2.x, klo.k2.y, klo.k2.z, klo.k2.w, khi.k2.x, khi.k2.y, khi.k2.z, khi.k2.w};
+    const float cc[8] = {klo.k3.x, klo.k3.y, klo.k3.z, klo.k3.w, khi.k3.x, khi.k3.y, khi.k3.z, khi.k3.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], mult * __builtin_fmaf(cb[i], y[i], cc[i]));
+    return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
   }
   const float4 lo = klo.apply(make_float4(g[0], g[1], g[2], g[3]), make_float4(y[0], y[1], y[2], y[3]));
   const float4 hi = khi.apply(make_float4(g[4], g[5], g[6], g[7]), make_float4(y[4], y[5], y[6], y[7]));
@@ -1109,9 +1180,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
     off_k[i] = 32 * (tile_ok[i] ? t - ct * NKT : 0);
   }
 
-  const long long ntiles = w.src.R / 32;
-  const long long t0 = (long long)blockIdx.x * w.tiles_per_block;
-  const long long t1 = min(ntiles, t0 + w.tiles_per_block);
+  // with a compact row map the number of rows is only known on the device: the (worst-case sized) grid re-divides them
+  const bool compact = w.src.crow != nullptr;
+  const long long ntiles = compact ? compact_tiles(w.src) : w.src.R / 32;
+  const long long tpb = compact ? (ntiles + gridDim.x - 1) / gridDim.x : w.tiles_per_block;
+  const long long t0 = min(ntiles, (long long)blockIdx.x * tpb);
+  const long long t1 = min(ntiles, t0 + tpb);
   // Staging is BRANCH-FREE: every global load is unconditional (clamped address) and only the LDS stores are
   // predicated — hipcc otherwise branches around each load and waits vmcnt(0) per element, serialising them.
   static_assert((32 * COUT / 4) % 256 == 0, "dY tile must split evenly over 256 threads");
@@ -1165,10 +1239,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < MAXE_A; ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
-      pidx[j] = w.src.idx[row0 + row_of(e)];
+      pidx[j] = compact ? w.src.crow[row0 + row_of(e)].x : w.src.idx[row0 + row_of(e)];
     }
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
-    tp = w.src.idx[row0 + te / max(tc, 1)];
+    tp = compact ? w.src.crow[row0 + te / max(tc, 1)].x : w.src.idx[row0 + te / max(tc, 1)];
   };
   // M*S is a multiple of 32 (checked by the host), so a tile never straddles two scenes: the scene index is a
   // scalar that follows the (monotone) tile counter instead of two integer divisions per staged element.
@@ -1179,13 +1253,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
     const int row0 = (int)(tile * 32);
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
     const int trow = row0 + te / max(tc, 1);
-    if (LOADER == GATHER) {
+    if (LOADER == GATHER && !compact) {
       if (tile >= scene_end) {  // tiles advance by one and tiles_per_scene >= 1
         ++scene;
         scene_end += tiles_per_scene;
       }
     }
-    const long long pbase = (long long)scene * w.src.N;
+    const long long pbase = compact ? 0 : (long long)scene * w.src.N;  // compact rows carry global point rows
     if constexpr (ST16) {
 #pragma unroll
       for (int j = 0; j < NE_DY8; ++j) {
@@ -1235,7 +1309,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
     }
     vt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOADER == GATHER) {
-      const int bm = w.src.S_shift >= 0 ? (trow >> w.src.S_shift) : trow / w.src.S;
+      const int bm = compact ? (reinterpret_cast<const int *>(w.src.crow + trow)[1] >> 8)
+                             : (w.src.S_shift >= 0 ? (trow >> w.src.S_shift) : trow / w.src.S);
       const float *q = w.src.xyz + (pbase + tp) * 3;
       const float *c = w.src.new_xyz + (long long)bm * 3;
       const float x = (q[0] - c[0]) / w.src.radius, y = (q[1] - c[1]) / w.src.radius, z = (q[2] - c[2]) / w.src.radius;
@@ -1728,7 +1803,7 @@ int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
 
 extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm,
                                    int B, int N, int M, int S, int C, float radius, const void *W, int K, int cout,
-                                   void *Y, double *stats, int bf16_io, void *stream) {
+                                   void *Y, double *stats, int bf16_io, const void *crow, const int *rowptr, int nballs, void *stream) {
   if (!xyz || !new_xyz || !idx || !feat_pm || !W || !Y || !stats || B < 1 || N < 1 || M < 1 || S < 1 || C < 4 ||
       (C & 3) || K < C + 4 || (K % (bf16_io ? 16 : 8)) || (((long long)B * M * S) & 31))
     return VLP3D_EINVAL;
@@ -1737,33 +1812,42 @@ extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const
   a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
   a.W = W; a.K = K; a.R = (long long)B * M * S; a.Yout = Y; a.ldout = cout; a.stats = stats;
   a.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
+  if (crow) {
+    if (!rowptr || nballs < 1 || !bf16_io) return VLP3D_EINVAL;  // compact row map: bf16 LDS kernels only
+    a.crow = (const int4 *)crow; a.rowptr = rowptr; a.nballs = nballs;
+  }
   a.tile_scene = (((long long)M * S) & 31) == 0;
   return bf16_io ? launch_row_gemm<bf16>(GATHER, STORE, cout, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(GATHER, STORE, cout, a, (hipStream_t)stream);
 }
 
 extern "C" int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const float *scale, const float *shift,
-                                  const void *W, int cout, void *Y, double *stats, int bf16_io, void *stream) {
+                                  const void *W, int cout, void *Y, double *stats, int bf16_io, const void *crow, const int *rowptr, int nballs, void *stream) {
   if (!Yin || !scale || !shift || !W || !Y || !stats || R < 32 || (R & 31) || (K % (bf16_io ? 16 : 8)))
     return VLP3D_EINVAL;
   RowGemmArgs a = {};
   a.Yin = Yin; a.ldin = K; a.scale = scale; a.shift = shift;
   a.W = W; a.K = K; a.R = R; a.Yout = Y; a.ldout = cout; a.stats = stats;
+  if (crow) {
+    if (!rowptr || nballs < 1 || !bf16_io) return VLP3D_EINVAL;  // compact row map: bf16 LDS kernels only
+    a.crow = (const int4 *)crow; a.rowptr = rowptr; a.nballs = nballs;
+  }
   return bf16_io ? launch_row_gemm<bf16>(BNRELU, STORE, cout, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(BNRELU, STORE, cout, a, (hipStream_t)stream);
 }
 
 extern "C" int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift,
-                             float *out, unsigned char *sel_idx, int bf16_io, void *stream) {
+                             float *out, unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream) {
   if (!Y || !scale || !shift || !out || !sel_idx || BM < 1 || S < 1 || S > 255 || C < 1) return VLP3D_EINVAL;
+  if (rowptr && (C % 8)) return VLP3D_EINVAL;  // compact row map: the 8-channel kernel only
   if (C % 8 == 0) {
     const dim3 grid8((unsigned)((BM * (C / 8) + 255) / 256));
     if (bf16_io)
       hipLaunchKernelGGL((pool8_kernel<bf16>), grid8, dim3(256), 0, (hipStream_t)stream, (const bf16 *)Y, S, C, BM, scale,
-                         shift, out, sel_idx);
+                         shift, out, sel_idx, rowptr);
     else
       hipLaunchKernelGGL((pool8_kernel<float>), grid8, dim3(256), 0, (hipStream_t)stream, (const float *)Y, S, C, BM,
-                         scale, shift, out, sel_idx);
+                         scale, shift, out, sel_idx, rowptr);
     VLP3D_LAUNCH_CHECK();
     return VLP3D_OK;
   }
@@ -1800,7 +1884,7 @@ extern "C" int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsig
 extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT,
                                   int kprev, const void *Yprev, const float *prev4, void *Gprev, double *tstats,
                                   const float *pool_g, const unsigned char *pool_sel, int pool_S, int bf16_io,
-                                  void *stream) {
+                                  const void *crow, const int *rowptr, int nballs, void *stream) {
   if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || !WT || !Yprev || !prev4 || !Gprev || !tstats || R < 32 || (R & 31) ||
       (ld % (bf16_io ? 16 : 8)))
     return VLP3D_EINVAL;
@@ -1812,6 +1896,10 @@ extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int
   a.p_scale = prev4; a.p_shift = prev4 + kprev; a.p_rstd = prev4 + 2 * kprev; a.p_nmean_rstd = prev4 + 3 * kprev;
   a.tstats = tstats;
   if (!G) set_pool(a, pool_g, pool_sel, pool_S);
+  if (crow) {
+    if (!rowptr || nballs < 1 || !bf16_io) return VLP3D_EINVAL;  // compact row map: bf16 LDS kernels only
+    a.crow = (const int4 *)crow; a.rowptr = rowptr; a.nballs = nballs;
+  }
   return bf16_io ? launch_row_gemm<bf16>(BNBWD, MASK, kprev, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(BNBWD, MASK, kprev, a, (hipStream_t)stream);
 }
@@ -1820,7 +1908,7 @@ extern "C" int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int
 // (each optional; NOT zeroed here).  WT = W_1^T padded to (kpad x COUT_1) with kpad a multiple of 32.
 extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
                                    const int *idx, int B, int N, int M, int S, int C, float radius, float *dfeat_pm,
-                                   float *dxyz, float *dnew_xyz, int bf16_io, void *stream) {
+                                   float *dxyz, float *dnew_xyz, int bf16_io, const void *crow, const int *rowptr, int nballs, void *stream) {
   if (!G || !Y || !bn5 || !WT || !idx || (kpad & 31) || kpad < C + 3 || (ld % (bf16_io ? 16 : 8)) ||
       (((long long)B * M * S) & 31))
     return VLP3D_EINVAL;
@@ -1832,6 +1920,10 @@ extern "C" int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const f
   a.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   a.tile_scene = (((long long)M * S) & 31) == 0;
   a.dfeat_pm = dfeat_pm; a.dxyz = dxyz; a.dnew_xyz = dnew_xyz;
+  if (crow) {
+    if (!rowptr || nballs < 1 || !bf16_io) return VLP3D_EINVAL;  // compact row map: bf16 LDS kernels only
+    a.crow = (const int4 *)crow; a.rowptr = rowptr; a.nballs = nballs;
+  }
   return bf16_io ? launch_row_gemm<bf16>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream)
                  : launch_row_gemm<float>(BNBWD, SCATTER, kpad, a, (hipStream_t)stream);
 }
@@ -1842,7 +1934,8 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
                               const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                               const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                               float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
-                              const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, void *stream) {
+                              const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, const void *crow,
+                              const int *rowptr, int nballs, void *stream) {
   if ((!G && !(pool_g && pool_sel && pool_S > 0)) || !Y || !bn5 || (!dW && !defer_reduce) || !partials || max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 1 || (K & 3)) return VLP3D_EINVAL;
   WgradArgs w = {};
   w.src.K = K; w.src.R = R;
@@ -1859,6 +1952,12 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
   if (!G) set_pool(w.dy, pool_g, pool_sel, pool_S);
   w.dy.rstd = bn5; w.dy.nmean_rstd = bn5 + cout; w.dy.k1 = bn5 + 2 * cout; w.dy.k2 = bn5 + 3 * cout;
   w.dy.k3 = bn5 + 4 * cout;
+  if (crow) {  // compact row map: both loaders (the gathered / previous-layer operand and dY) index compact rows
+    if (!rowptr || nballs < 1 || !bf16_io) return VLP3D_EINVAL;
+    w.src.crow = w.dy.crow = (const int4 *)crow;
+    w.src.rowptr = w.dy.rowptr = rowptr;
+    w.src.nballs = w.dy.nballs = nballs;
+  }
   w.KP = (K + 31) & ~31;
   w.partials = partials;
   const long long ntiles = R / 32;

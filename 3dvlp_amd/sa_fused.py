@@ -45,8 +45,10 @@ class FusedSAMLP(Function):
     """(xyz, new_xyz, idx, feat_pm, W1,g1,b1, W2,g2,b2, W3,g3,b3) -> pooled (B*M, C3) fp32."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, *params):
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, *params):
         W, gam, bet = params[0::3], params[1::3], params[2::3]
+        # cmap = (rowptr, crow) of _lib.sa_compact: the stack then runs on the DISTINCT rows of every ball (bf16 only)
+        cm = (cmap[1], cmap[0], idx.shape[0] * idx.shape[1]) if (cmap is not None and use_bf16) else (None, None, 0)
         B, N, _ = xyz.shape
         _, M, S = idx.shape
         C = feat_pm.shape[2]
@@ -73,10 +75,10 @@ class FusedSAMLP(Function):
             st = torch.empty((nslab, 2, cout[l]), dtype=torch.float64, device=dev)
             if l == 0:
                 _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
-                          cout[0], y, st, bf)
+                          cout[0], y, st, bf, *cm)
             else:
                 _ext.call("vlp3d_sa_fwd_layer", Y[l - 1], R, Ks[l], vecs[l - 1][0], vecs[l - 1][1], Wd[l], cout[l], y,
-                          st, bf)
+                          st, bf, *cm)
             bn = bns[l]
             vec = torch.empty((4, cout[l]), dtype=torch.float32, device=dev)
             track = training and bn.track_running_stats
@@ -93,14 +95,16 @@ class FusedSAMLP(Function):
             vecs.append(vec)
         out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
         sel = torch.empty((B * M, cout[2]), dtype=torch.uint8, device=dev)
-        _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf)
+        _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf, cm[1])
         ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet)
+        ctx.cm = cm
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
         return out
 
     @staticmethod
     def backward(ctx, dP):
         B, N, M, S, C, R, radius, bf, dt, cout, Ks, training = ctx.cfg
+        cm = ctx.cm
         sv = ctx.saved_tensors
         xyz, new_xyz, idx, feat_pm, out, sel = sv[:6]
         Y, vecs, WTs, gam, bet = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21]
@@ -143,17 +147,17 @@ class FusedSAMLP(Function):
             if l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
                           vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
-                          *(pool if G is None else (None, None, 0)), bf, int(q is not None))
+                          *(pool if G is None else (None, None, 0)), bf, int(q is not None), *cm)
                 if q is not None:  # after the launch: the queue may sum right away
                     q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[l] * Ks[l], Ks[l], Ks[l])
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WTs[l], cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
-                          t[l - 1], *(pool if G is None else (None, None, 0)), bf)
+                          t[l - 1], *(pool if G is None else (None, None, 0)), bf, *cm)
                 G = Gp
             else:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None))
+                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None), *cm)
                 if q is not None:  # the batched slab sum writes [xyz | features] columns directly
                     q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[0] * Ks[0], Ks[0], C + 3, ncol_out=C + 3, rot=3)
                     dparams[0] = dW.view(cout[0], C + 3, 1, 1)
@@ -166,16 +170,17 @@ class FusedSAMLP(Function):
                     dxyz = arena[o + n_df:o + n_df + n_dx].view(B, N, 3) if need[0] else None
                     dnew = arena[o + n_df + n_dx:].view(B, M, 3) if need[1] else None
                     _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
-                              dxyz, dnew, bf)
-        return (dxyz, dnew, None, dfeat, None, None, None, None, *dparams)
+                              dxyz, dnew, bf, *cm)
+        return (dxyz, dnew, None, dfeat, None, None, None, None, None, *dparams)
 
 
-def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16):
-    """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32."""
+def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None):
+    """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32.
+    cmap: (rowptr, crow) of _lib.sa_compact(idx, N) — evaluate the stack on the distinct rows only (bf16 configuration)."""
     bns = [layer.bn.bn for layer in mlp_module]
     params = []
     for layer in mlp_module:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
     B, M = new_xyz.shape[:2]
-    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, *params)
+    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, *params)
     return out.view(B, M, -1)

@@ -128,7 +128,19 @@ int vlp3d_group_rows_grad(const void *dout, int dout_bf16, const int *idx, int B
  * backward: group_points x2, sub/div, cat, 3 x (1x1 conv, BatchNorm2d, ReLU), max_pool2d over nsample.
  * Rows r = (b*M + m)*S + s; Y_l (R x cout_l) pre-activations, G_l masked gradients; bf16_io: 0 = fp32 storage +
  * exact-fp32 MFMA, 1 = bf16 storage + bf16 MFMA (fp32 accumulate).  Per-channel vectors are fp32, batch
- * statistics fp64.  R = B*M*S must be a multiple of 32; cout in {32,64,128,256}. */
+ * statistics fp64.  R = B*M*S must be a multiple of 32; cout in {32,64,128,256}.
+ *
+ * COMPACT ROW MAP (optional; bf16_io only; csrc/sa_compact.hip).  ball_query pads a ball with copies of its first
+ * neighbour (ball_query_gpu.cu:14-49) and the reference runs the padded tensor through the whole stack.  With
+ * (crow, rowptr, nballs) the stack is evaluated on the DISTINCT rows of every ball, stored back to back — same result up
+ * to the order of float additions: a row's multiplicity w enters the BatchNorm batch sums and the BatchNorm-backward
+ * term (dY summed over the copies = k1 (G - w (k2 + yhat k3))), everything downstream is linear in that sum.
+ *   vlp3d_sa_compact(idx (B,M,S), ...) -> rowptr (B*M + 1 ints; rowptr[B*M] = number of compact rows P, read on the
+ *   device — launches stay sized for the dense worst case R) and crow (R x int4: global point row b*N + idx, (ball << 8) |
+ *   position in the ball, float bits of w, 0; rows P .. roundup32(P)-1 are zero-weight dummies).
+ * Every entry below that takes (crow, rowptr, nballs) treats its (R x .) matrices as compact when crow != NULL;
+ * NULL = dense rows.  Matrices keep their R-row allocation; rows past roundup32(P) are never touched. */
+int vlp3d_sa_compact(const int *idx, int B, int N, int M, int S, int *rowptr, void *crow, void *stream);
 
 /* layer 1: Y = [feat_pm[idx] | (xyz[idx]-new_xyz)/radius | 0] * W^T; W (cout x K) in column order
  * [features(C) | xyz(3) | 0], K >= C+4, K % 8 (fp32) / 16 (bf16) == 0.
@@ -137,13 +149,15 @@ int vlp3d_group_rows_grad(const void *dout, int dout_bf16, const int *idx, int B
 int vlp3d_sa_stat_slabs(long long R);
 int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
                         int M, int S, int C, float radius, const void *W, int K, int cout, void *Y, double *stats,
-                        int bf16_io, void *stream);
+                        int bf16_io, const void *crow, const int *rowptr, int nballs, void *stream);
 /* layers 2..: Y = relu(Yin*scale + shift) * W^T, Yin (R x K), W (cout x K). */
 int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const float *scale, const float *shift, const void *W,
-                       int cout, void *Y, double *stats, int bf16_io, void *stream);
-/* out (BM x C) f32 = relu(sel*scale + shift), sel = max_s Y (scale >= 0) / min_s Y (scale < 0); sel_idx u8. */
+                       int cout, void *Y, double *stats, int bf16_io, const void *crow, const int *rowptr, int nballs,
+                       void *stream);
+/* out (BM x C) f32 = relu(sel*scale + shift), sel = max_s Y (scale >= 0) / min_s Y (scale < 0); sel_idx u8
+ * (position inside the ball; with rowptr != NULL inside the ball's compact rows). */
 int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
-                  unsigned char *sel_idx, int bf16_io, void *stream);
+                  unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream);
 /* G (BM*S x C) = dP routed to the selected sample where out > 0 (max-pool + ReLU backward). */
 int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *sel_idx, long long BM, int S, int C,
                        void *G, int bf16_io, void *stream);
@@ -154,12 +168,13 @@ int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *s
  * the masked gradient is then synthesised on the fly (no dense (R x ld) gradient matrix is ever written). */
 int vlp3d_sa_bwd_layer(const void *G, const void *Y, long long R, int ld, const float *bn5, const void *WT, int kprev,
                        const void *Yprev, const float *prev4, void *Gprev, double *tstats, const float *pool_g,
-                       const unsigned char *pool_sel, int pool_S, int bf16_io, void *stream);
+                       const unsigned char *pool_sel, int pool_S, int bf16_io, const void *crow, const int *rowptr,
+                       int nballs, void *stream);
 /* layer 1 input gradient, scatter-added (NOT zeroed here) into dfeat_pm (B,N,C) / dxyz (B,N,3) / dnew_xyz (B,M,3)
  * (each optional).  WT = W_1^T zero-padded to (kpad x ld), kpad % 32 == 0. */
 int vlp3d_sa_bwd_gather(const void *G, const void *Y, int ld, const float *bn5, const void *WT, int kpad,
                         const int *idx, int B, int N, int M, int S, int C, float radius, float *dfeat_pm, float *dxyz,
-                        float *dnew_xyz, int bf16_io, void *stream);
+                        float *dnew_xyz, int bf16_io, const void *crow, const int *rowptr, int nballs, void *stream);
 /* dW (cout x K) f32 = sum_r BNbwd(G,Y)[r]^T A[r]; A = relu(Yprev*scale+shift) (gather == 0) or the gathered
  * layer-1 rows (gather != 0).  partials: scratch of max_blocks*cout*K floats (one slab per workgroup, summed by
  * a second kernel: no contended atomics); dW is fully written.  G = NULL + pooled tensors as in vlp3d_sa_bwd_layer. */
@@ -167,7 +182,8 @@ int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cout, const fl
                    const void *Yprev, int K, const float *scale, const float *shift, const float *xyz,
                    const float *new_xyz, const int *idx, const float *feat_pm, int N, int M, int S, int C,
                    float radius, float *dW, float *partials, int max_blocks, const float *pool_g,
-                   const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, void *stream);
+                   const unsigned char *pool_sel, int pool_S, int bf16_io, int defer_reduce, const void *crow,
+                   const int *rowptr, int nballs, void *stream);
 
 /* per-channel bookkeeping of the fused layer (one launch each instead of ~20 framework kernels):
  * bn_fold: vec (4 x C) = [scale | shift | rstd | -mean*rstd] from the fp64 batch sums `stats` (training) or the

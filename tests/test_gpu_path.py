@@ -1026,3 +1026,47 @@ def test_row_stack_final_prelu_equals_fp64_formula(training):
         assert _rel(got, exp) < 2e-4, _rel(got, exp)
     if not training:
         assert _rel(b.grad, bd.grad) < 2e-4
+
+
+@pytest.mark.parametrize("S,need_xyz_grad", [(64, False), (32, True)])
+def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad):
+    """The grouped MLP on the DISTINCT rows of every ball (csrc/sa_compact.hip: ball-query padding removed, multiplicities
+    in the BatchNorm sums and the BatchNorm-backward term) equals the padded evaluation: pooled output, running
+    statistics, every parameter gradient and the input gradients — at the tolerance of two bf16 runs that differ only in
+    the order of their float additions."""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    ext = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(21)
+    B, N, C = 2, 8192, 60  # C + 3 padded to 64 columns: a width the scatter kernel is instantiated for
+    xyz = torch.from_numpy(np.stack([synth.make_scene(30 + i, N)["xyz"] for i in range(B)]).astype(np.float32)).cuda()
+    feats0 = torch.randn(B, C, N, device="cuda")
+    res = []
+    for compact in (False, True):
+        torch.manual_seed(5)
+        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=S, mlp=[C, 64, 64, 128], use_xyz=True,
+                                     normalize_xyz=True).cuda().train()
+        m.mlp_dtype, m.compact = torch.bfloat16, compact
+        x = xyz.clone().requires_grad_(need_xyz_grad)
+        f = feats0.clone().requires_grad_(True)
+        geo = m.compute_geometry(x.detach())
+        assert (len(geo) == 5) == compact
+        if compact:
+            rowptr, crow = geo[3], geo[4]
+            P = int(rowptr[-1])
+            assert 0 < P < B * 512 * S and int(crow[:P, 2].view(torch.float32).sum().round()) == B * 512 * S  # multiplicities
+        new_xyz, out, _ = m(x, f, geometry=geo)
+        g = torch.randn_like(out)
+        out.backward(g)
+        res.append(dict(out=out.detach(), df=f.grad, dx=x.grad if need_xyz_grad else None,
+                        params=[p.grad for p in m.parameters()], bufs=[b.clone() for b in m.buffers()]))
+    a, b = res
+    assert _rel(b["out"], a["out"]) < 2e-3
+    assert _rel(b["df"], a["df"]) < 2e-2
+    if need_xyz_grad:
+        assert _rel(b["dx"], a["dx"]) < 2e-2
+    for pa, pb in zip(a["params"], b["params"]):
+        assert _rel(pb, pa) < 2e-2, _rel(pb, pa)
+    for ba, bb in zip(a["bufs"], b["bufs"]):
+        if ba.dtype.is_floating_point:
+            assert _rel(bb, ba) < 1e-4

@@ -27,11 +27,11 @@ for name, p in (("fps", None),):
     if which not in (name, "both"):
         continue
     for _ in range(3):
-        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, 1)
+        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, 1, None, None, 0)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(10):
-        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, 1)
+        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, 1, None, None, 0)
     e.record(); e.synchronize()
     print(name, "ms per launch", s.elapsed_time(e) / 10)

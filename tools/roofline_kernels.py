@@ -21,6 +21,8 @@ for _ in range(3):
 new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 for _ in range(3):
     idx = pu.ball_query(0.2, 64, xyz, new_xyz)
+rowptr_, crow_ = ext.sa_compact(idx, n)   # the bf16 step evaluates the distinct rows only
+cm = (crow_, rowptr_, B * m)
 for bf in (1, 0):
     dt = torch.bfloat16 if bf else torch.float32
     C, cout, R = 132, 64, B * m * 64
@@ -29,7 +31,7 @@ for bf in (1, 0):
     Y = torch.empty((R, cout), dtype=dt, device=dev)
     stats = torch.empty((int(ext.load().vlp3d_sa_stat_slabs(R)), 2, cout), dtype=torch.float64, device=dev)
     for _ in range(3):
-        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf)
+        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf, *(cm if bf else (None, None, 0)))
 q = torch.randn(64, 256, 128, device=dev)
 kc = torch.randn(64, 49, 128, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
