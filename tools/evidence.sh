@@ -1,10 +1,20 @@
-# Round evidence: bench JSON, rocprofv3 kernel stats + one steady-state step, PMC traffic of the roofline kernels.
-# Usage (on the GPU box): bash tools/evidence.sh r02_b
+# Round evidence: PMC traffic of the roofline kernels, bench JSON lines, rocprofv3 kernel stats + one steady-state step.
+# Usage (on the GPU box): bash tools/evidence.sh r02_e
 set -e
 tag=$1
 cd $GRAFT_REPO_ROOT
 out=$GRAFT_REPO_ROOT/gpurun_out
 export TMPDIR=/tmp
+cd /tmp
+for m in self cross; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f_$m -- python3 $GRAFT_REPO_ROOT/tools/roofline_kernels.py $m > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$m -- python3 $GRAFT_REPO_ROOT/tools/roofline_kernels.py $m > /dev/null 2>&1
+done
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pmc_f_self /tmp/pmc_w_self $out/${tag}_pmc_traffic.json /tmp/pmc_f_cross /tmp/pmc_w_cross > $out/${tag}_pmc_traffic.txt
+cp /tmp/pmc_f_self/*/*counter_collection.csv $out/${tag}_pmc_fetch_size_counter_collection.csv
+cp /tmp/pmc_w_self/*/*counter_collection.csv $out/${tag}_pmc_write_size_counter_collection.csv
+cp $out/${tag}_pmc_traffic.json $GRAFT_REPO_ROOT/profiles/r02_pmc_traffic.json   # bench.py reads the table of THIS run
+cd $GRAFT_REPO_ROOT
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 python bench.py --no-cpu-baseline --no-kernels --host-batches > $out/${tag}_bench_host_batches.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-kernels --dtype fp32 > $out/${tag}_bench_fp32.json 2>/dev/null
@@ -13,11 +23,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_g -o g -- pyth
 cp /tmp/prof_g/g_kernel_stats.csv $out/${tag}_bench_default_kernel_stats.csv
 mkdir -p /tmp/pg/x && cp /tmp/prof_g/g_kernel_trace.csv /tmp/pg/x/
 python3 $GRAFT_REPO_ROOT/tools/trace_last_step.py /tmp/pg 400 > $out/${tag}_steady_state_step.txt
-for m in self cross; do
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f_$m -- python3 $GRAFT_REPO_ROOT/tools/roofline_kernels.py $m > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$m -- python3 $GRAFT_REPO_ROOT/tools/roofline_kernels.py $m > /dev/null 2>&1
-done
-python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pmc_f_self /tmp/pmc_w_self $out/${tag}_pmc_traffic.json /tmp/pmc_f_cross /tmp/pmc_w_cross > $out/${tag}_pmc_traffic.txt
-cp /tmp/pmc_f_self/*/*counter_collection.csv $out/${tag}_pmc_fetch_size_counter_collection.csv
-cp /tmp/pmc_w_self/*/*counter_collection.csv $out/${tag}_pmc_write_size_counter_collection.csv
 head -3 $out/${tag}_steady_state_step.txt
