@@ -393,10 +393,12 @@ def test_geometry_pipeline_and_graph_equal_inline_step():
                 assert torch.equal(r["bufs"][n], b), (name, n, r["bufs"][n], b)  # counters advanced exactly once
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_pipeline_never_uses_stale_geometry(use_graph):
+@pytest.mark.parametrize("use_graph,bf16", [(False, False), (True, False), (True, True)])
+def test_pipeline_never_uses_stale_geometry(use_graph, bf16):
     """Alternating two DIFFERENT batches, with and without announcing the next one: every step must use the geometry
-    of the batch it runs (`run(A)` then `run(B)` used A's FPS / ball-query indices for B)."""
+    of the batch it runs (`run(A)` then `run(B)` used A's FPS / ball-query indices for B).  The bf16 case also
+    replays the captured graphs with a DIFFERENT number of distinct rows per batch (compact row map, csrc/sa_compact.hip:
+    the row count is read on the device)."""
     gs = importlib.import_module("3dvlp_amd.grounding_step")
     synth = importlib.import_module("3dvlp_amd.synth")
     devc = torch.device("cuda:0")
@@ -407,7 +409,7 @@ def test_pipeline_never_uses_stale_geometry(use_graph):
     seq = [(A, None), (Bb, None), (A, Bb), (Bb, A), (A, A), (Bb, None)]
     out = {}
     for name, kw in (("inline", {}), ("pipe", {"pipeline": True, "use_graph": use_graph})):
-        step = gs.GroundingStep(devc, lr=0.0, **kw)   # lr 0: the model stays put, every step is comparable
+        step = gs.GroundingStep(devc, lr=0.0, sa_dtype=torch.bfloat16 if bf16 else None, **kw)   # lr 0: the model stays put
         _eval_dropout_train_bn(step)
         out[name] = []
         for cur, nxt in seq:
@@ -415,8 +417,9 @@ def test_pipeline_never_uses_stale_geometry(use_graph):
             torch.cuda.synchronize()
             out[name].append((loss, step.bucket.flat.clone()))
     for i, ((l0, g0), (l1, g1)) in enumerate(zip(out["inline"], out["pipe"])):
-        assert abs(l0 - l1) <= 1e-5 * abs(l0), (i, l0, l1)
-        assert _rel(g1, g0) < 1e-4, (i, _rel(g1, g0))
+        # bf16: storage rounding turns the atomics' ordering noise into last-bit flips of stored activations
+        assert abs(l0 - l1) <= (2e-3 if bf16 else 1e-5) * abs(l0), (i, l0, l1)
+        assert _rel(g1, g0) < (3e-2 if bf16 else 1e-4), (i, _rel(g1, g0))
     # and the two batches really differ (so stale geometry would have been visible)
     assert abs(out["inline"][0][0] - out["inline"][1][0]) > 1e-3 * abs(out["inline"][0][0])
 
