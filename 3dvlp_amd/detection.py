@@ -430,10 +430,12 @@ class RelationModule(nn.Module):
         B, K = features.shape[:2]
         corners = data_dict["pred_bbox_corner"]
 
-        fused_inputs = self.fused_bias and corners.is_cuda and data_dict["point_clouds"].shape[-1] >= 134
+        # the multiview channels: columns 6.. of the raw cloud, or 3.. of the loader's point-major feature split
+        src_pc, col0 = (data_dict["k/feat_pm"], 3) if "k/feat_pm" in data_dict else (data_dict.get("point_clouds"), 6)
+        fused_inputs = self.fused_bias and corners.is_cuda and src_pc is not None and src_pc.shape[-1] >= col0 + 128
         if fused_inputs:  # obj_feat, manual_bbox_feat and the corner mean in ONE launch (csrc/glue.hip), no gradient
             obj_feat, manual_bbox_feat, centre = glue.relation_inputs(
-                data_dict["point_clouds"], data_dict["seed_inds"], data_dict["aggregated_vote_inds"], corners)
+                src_pc, data_dict["seed_inds"], data_dict["aggregated_vote_inds"], corners, col0)
         # pairwise geometry (layer-independent): delta[b,i,j] = centre_j - centre_i, plus its norm
         centre = centre if fused_inputs else corners.mean(dim=-2)
         pair = None

@@ -220,7 +220,7 @@ class GroundingStep:
     def _tag(batch):
         """Identity of a batch's coordinates: (address, in-place version) of point_clouds.  The prepared geometry is
         only ever used for the batch it was computed from."""
-        pc = batch["point_clouds"]
+        pc = batch["point_clouds"] if "point_clouds" in batch else batch["k/xyz"]  # (the static inputs keep the split only)
         return (pc.data_ptr(), pc._version, tuple(pc.shape))
 
     def _fwd_bwd(self, batch, next_batch=None):
@@ -233,7 +233,7 @@ class GroundingStep:
             cur = torch.cuda.current_stream()
             if self._geom_next is None or self._geom_tag != self._tag(batch):
                 # nothing prepared, or prepared for another batch: geometry inline (correct, just not overlapped)
-                fresh = backbone.compute_geometry(batch["point_clouds"])
+                fresh = backbone.compute_geometry(self._coords(batch))
                 if self._geom_next is None:
                     self._geom_next = fresh
                     self._geom_cur = {k: tuple(t.clone() for t in v) for k, v in fresh.items()}
@@ -245,7 +245,7 @@ class GroundingStep:
             nxt_batch = batch if next_batch is None else next_batch
             self._side.wait_stream(cur)  # fork: the side branch may overwrite _geom_next from here on
             with torch.cuda.stream(self._side):
-                nxt = backbone.compute_geometry(nxt_batch["point_clouds"])
+                nxt = backbone.compute_geometry(self._coords(nxt_batch))
                 self._copy_geometry(self._geom_next, nxt)
             self._geom_tag = self._tag(nxt_batch)
             geometry = self._geom_cur
@@ -273,9 +273,16 @@ class GroundingStep:
         return list(self.model.buffers()) + [add_norm.state(self.device)]
 
     def _capture(self, batch, next_batch):
-        clone = lambda b: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        # static inputs of the captured graphs.  With the loader's split of the cloud (k/xyz, k/feat_pm) the step never reads
+        # `point_clouds` itself: it is left out (173 MB less to refill per step when batches change); of the NEXT batch
+        # only the coordinates are needed (its geometry).
+        split = "k/xyz" in batch and "k/feat_pm" in batch
+        clone = lambda b: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()
+                           if not (split and k == "point_clouds")}
         self._static_batch = clone(batch)
-        self._static_next = clone(batch if next_batch is None else next_batch)  # always its own buffers
+        nb = batch if next_batch is None else next_batch
+        ck = "k/xyz" if "k/xyz" in nb else "point_clouds"
+        self._static_next = {ck: nb[ck].clone()}  # always its own buffer
         self._static_tag = self._tag(batch)
         self._next_src_tag = self._tag(batch if next_batch is None else next_batch)
         # the warm-up passes are real training forwards (BN momentum updates, counters, dropout seed): snapshot the
@@ -304,7 +311,7 @@ class GroundingStep:
             with torch.cuda.graph(self._gC):
                 self._copy_geometry(self._geom_cur, self._geom_next)
             with torch.cuda.graph(self._gS, stream=self._side):
-                nxt = backbone.compute_geometry(self._static_next["point_clouds"])
+                nxt = backbone.compute_geometry(self._coords(self._static_next))
                 self._copy_geometry(self._geom_next, nxt)
             with torch.cuda.graph(self._gM):
                 self.bucket.zero()
@@ -329,7 +336,7 @@ class GroundingStep:
         if self._geom_for != self._static_tag:
             # the prepared geometry belongs to another batch than the one about to run: recompute inline (eager)
             cur.wait_stream(self._side)
-            fresh = self.model.backbone_net.compute_geometry(self._static_batch["point_clouds"])
+            fresh = self.model.backbone_net.compute_geometry(self._coords(self._static_batch))
             self._copy_geometry(self._geom_next, fresh)
         self._gC.replay()
         self._side.wait_stream(cur)          # fork: geometry of the next batch may overwrite _geom_next now
@@ -341,9 +348,15 @@ class GroundingStep:
 
     @staticmethod
     def _refill(static, batch):
-        for k, v in batch.items():
-            if torch.is_tensor(v) and static[k].data_ptr() != v.data_ptr():
-                static[k].copy_(v, non_blocking=True)
+        for k, sv in static.items():
+            v = batch[k]
+            if torch.is_tensor(v) and sv.data_ptr() != v.data_ptr():
+                sv.copy_(v, non_blocking=True)
+
+    @staticmethod
+    def _coords(batch):
+        """Coordinates of a batch for compute_geometry: the loader's k/xyz (B,N,3) when present, else the cloud."""
+        return batch["k/xyz"] if "k/xyz" in batch else batch["point_clouds"]
 
     def run(self, batch, next_batch=None):
         if self.use_graph:

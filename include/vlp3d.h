@@ -425,7 +425,9 @@ int vlp3d_vote_epilogue_bwd(const float *d_vote_xyz, const float *d_vote_f, cons
 int vlp3d_l2norm_rows(const float *x, long long R, int C, float eps, float *y, float *norm, void *stream);
 int vlp3d_l2norm_rows_bwd(const float *g, const float *y, const float *norm, long long R, int C, float eps, float *dx,
                           void *stream);
-int vlp3d_relation_inputs(const float *pc, int Cpc, int N, const int *seed_inds, int S, const int *vote_inds,
+/* pc (B,N,Cpc) point-major rows whose columns col0 .. col0+127 are the 128 multiview channels: the raw cloud (Cpc = 3+132,
+ * col0 = 6) or the loader's feature split k/feat_pm (Cpc = 132, col0 = 3). */
+int vlp3d_relation_inputs(const float *pc, int Cpc, int col0, int N, const int *seed_inds, int S, const int *vote_inds,
                           const float *corners, int B, int K, float *obj_feat, float *bbox_feat, float *centre, void *stream);
 int vlp3d_copy_paste_map(const long long *obj_mask, int B, int K, const float *coin, int *src, void *stream);
 int vlp3d_gather_rows(const float *x, const int *src, long long R, int D, float *out, void *stream);
