@@ -129,22 +129,15 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
     k_d = ld4(a.bn5 + 3 * a.K + scol); k_e = ld4(a.bn5 + 4 * a.K + scol);
   }
   // A row-major weight has every lane of a fragment load on a different row (32 cache lines per instruction: the forward
-  // product ran 11 us where the K-major dX product of the same size ran 6); staged through LDS the global reads are
-  // coalesced row segments, read once per workgroup instead of once per tile, and the fragments are two ds_read_b64.
-  const int wld = a.K + 4;  // shorts per staged weight row
-  short *sW = reinterpret_cast<short *>(sA + 32 * lds_ld);
-  if (a.wlds) {
-    const int k4n = a.K / 4;
-    for (int c = threadIdx.x; c < 128 * k4n; c += 256) {
-      const int n = c / k4n, k4 = c - n * k4n;
-      const int gcol = blockIdx.y * 128 + n;
-      const float4 wv = gcol < a.N ? ld4(a.W + (long long)gcol * a.ldw + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      short4 pk;
-      pk.x = bf16_bits_(wv.x); pk.y = bf16_bits_(wv.y); pk.z = bf16_bits_(wv.z); pk.w = bf16_bits_(wv.w);
-      *reinterpret_cast<short4 *>(sW + n * wld + 4 * k4) = pk;
-    }
-    // visible after the first __syncthreads() of the tile loop below
-  }
+  // product ran 11 us where the K-major dX product of the same size ran 6).  With a.wlds (bf16 products, row-major weight)
+  // both operands go through LDS as bf16: the A tile [32][K + 4] and, 128 columns of K at a time, the workgroup's 128 x 128
+  // weight chunk [128][WKC + 4] — coalesced row segments from global memory, fragments by ds_read_b64, no conversions in
+  // the product loop.
+  constexpr int WKC = 128;
+  const int ldb = a.K + 4;   // shorts per A row (wlds)
+  const int wld = WKC + 4;   // shorts per staged weight row
+  short *sAb = reinterpret_cast<short *>(sA);
+  short *sW = sAb + 32 * ldb;
   double s1 = 0.0, s2 = 0.0;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long row0 = tile * 32;
@@ -174,23 +167,43 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsArgs a) {
           v = make_float4(k_c.x * (gg.x - k_d.x - (y.x * k_a.x + k_b.x) * k_e.x), k_c.y * (gg.y - k_d.y - (y.y * k_a.y + k_b.y) * k_e.y),
                           k_c.z * (gg.z - k_d.z - (y.z * k_a.z + k_b.z) * k_e.z), k_c.w * (gg.w - k_d.w - (y.w * k_a.w + k_b.w) * k_e.w));
         }
-        *reinterpret_cast<float4 *>(sA + srow[j] * lds_ld + scl[j]) = v;
+        if (a.wlds) {
+          short4 pk;
+          pk.x = bf16_bits_(v.x); pk.y = bf16_bits_(v.y); pk.z = bf16_bits_(v.z); pk.w = bf16_bits_(v.w);
+          *reinterpret_cast<short4 *>(sAb + srow[j] * ldb + scl[j]) = pk;
+        } else {
+          *reinterpret_cast<float4 *>(sA + srow[j] * lds_ld + scl[j]) = v;
+        }
       }
     }
     __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (active && a.wlds) {
-      const float *sa = sA + r * lds_ld;
+    if (a.wlds) {  // workgroup-uniform: every wave takes part in staging the weight chunks
+      const short *sa = sAb + r * ldb + 4 * half;
       const short *sw = sW + (32 * wave + r) * wld + 4 * half;
-      for (int kb = 0; kb < a.K; kb += 16) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(sa + kb + 4 * half);
-        const float4 a1 = *reinterpret_cast<const float4 *>(sa + kb + 8 + 4 * half);
-        const short4 w0 = *reinterpret_cast<const short4 *>(sw + kb), w1 = *reinterpret_cast<const short4 *>(sw + kb + 8);
-        bf16x8_t bw;
-        bw[0] = w0.x; bw[1] = w0.y; bw[2] = w0.z; bw[3] = w0.w; bw[4] = w1.x; bw[5] = w1.y; bw[6] = w1.z; bw[7] = w1.w;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_bf16x8(a0, a1), bw, acc, 0, 0, 0);
+      for (int k0 = 0; k0 < a.K; k0 += WKC) {
+        const int kc = min(WKC, a.K - k0), k4n = kc / 4;
+        if (k0 > 0) __syncthreads();  // the previous chunk's fragment reads are done
+        for (int c = threadIdx.x; c < 128 * k4n; c += 256) {
+          const int n = c / k4n, k4 = c - n * k4n;
+          const int gcol = blockIdx.y * 128 + n;
+          const float4 wv = gcol < a.N ? ld4(a.W + (long long)gcol * a.ldw + k0 + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          short4 pk;
+          pk.x = bf16_bits_(wv.x); pk.y = bf16_bits_(wv.y); pk.z = bf16_bits_(wv.z); pk.w = bf16_bits_(wv.w);
+          *reinterpret_cast<short4 *>(sW + n * wld + 4 * k4) = pk;
+        }
+        __syncthreads();
+        if (active)
+          for (int kb = 0; kb < kc; kb += 16) {
+            const short4 a0 = *reinterpret_cast<const short4 *>(sa + k0 + kb), a1 = *reinterpret_cast<const short4 *>(sa + k0 + kb + 8);
+            const short4 w0 = *reinterpret_cast<const short4 *>(sw + kb), w1 = *reinterpret_cast<const short4 *>(sw + kb + 8);
+            bf16x8_t av, bw;
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            bw[0] = w0.x; bw[1] = w0.y; bw[2] = w0.z; bw[3] = w0.w; bw[4] = w1.x; bw[5] = w1.y; bw[6] = w1.z; bw[7] = w1.w;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc, 0, 0, 0);
+          }
       }
     } else if (active) {
       const float *sa = sA + r * lds_ld;
@@ -368,9 +381,8 @@ int launch(const RowsArgs &a, hipStream_t s) {
   const dim3 grid(rows_blocks(a.R), (a.N + 127) / 128);
   size_t lds = (size_t)32 * (a.K + 4) * sizeof(float);
   RowsArgs b = a;
-  const size_t wbytes = (size_t)128 * (a.K + 4) * sizeof(short);
-  b.wlds = a.bfm && !a.wt && a.K % 16 == 0 && lds + wbytes <= 100 * 1024;
-  if (b.wlds) lds += wbytes;
+  b.wlds = a.bfm && !a.wt && a.K % 16 == 0;
+  if (b.wlds) lds = ((size_t)32 * (a.K + 4) + (size_t)128 * (128 + 4)) * sizeof(short);  // bf16 A tile + one weight chunk
   auto kern = rows_gemm_kernel<LOADER, EPI>;
   if (lds > 64 * 1024) {
     if (lds > 150 * 1024) return VLP3D_EINVAL;
