@@ -146,8 +146,8 @@ __device__ __forceinline__ float4 load_a4(const RowGemmArgs &a, long long row, i
   // BNBWD
   float4 g;
   if (a.pool_g != nullptr) {  // kernel-uniform
-    const int bm = a.pool_shift >= 0 ? ((int)row >> a.pool_shift) : ((int)row / a.pool_S);
-    const int sidx = (int)row - bm * a.pool_S;
+    int bm, sidx;
+    ball_of_row(a, (int)row, bm, sidx);
     const long long off = (long long)bm * a.ldin + col0;
     const float4 dp = ld4(a.pool_g + off);
     const uchar4 sl = *reinterpret_cast<const uchar4 *>(a.pool_sel + off);
@@ -158,6 +158,11 @@ __device__ __forceinline__ float4 load_a4(const RowGemmArgs &a, long long row, i
   }
   const float4 rs = ld4(a.rstd + col0), nm = ld4(a.nmean_rstd + col0);
   const float4 k1 = ld4(a.k1 + col0), k2 = ld4(a.k2 + col0), k3 = ld4(a.k3 + col0);
+  if (a.crow) {  // compact rows: dY summed over the copies of the row, k1 (G - w (k2 + yhat k3))
+    const float w = row_weight(a, (int)row);
+    return make_float4(k1.x * (g.x - w * (k2.x + (y.x * rs.x + nm.x) * k3.x)), k1.y * (g.y - w * (k2.y + (y.y * rs.y + nm.y) * k3.y)),
+                       k1.z * (g.z - w * (k2.z + (y.z * rs.z + nm.z) * k3.z)), k1.w * (g.w - w * (k2.w + (y.w * rs.w + nm.w) * k3.w)));
+  }
   return make_float4(k1.x * (g.x - k2.x - (y.x * rs.x + nm.x) * k3.x), k1.y * (g.y - k2.y - (y.y * rs.y + nm.y) * k3.y),
                      k1.z * (g.z - k2.z - (y.z * rs.z + nm.z) * k3.z), k1.w * (g.w - k2.w - (y.w * rs.w + nm.w) * k3.w));
 }
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void row_gemm_kernel(RowGemmArgs a) {
   constexpr int NCT = COUT / 32;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ntiles = a.R / 32;
+  const long long ntiles = compact_tiles(a);  // compact row map: BNBWD loader + SCATTER epilogue only (host-checked)
   if ((EPI == BIAS || EPI == BIAS_WT) && gridDim.y > 1) {  // column-split launch of a small linear layer
     const int c0 = blockIdx.y * COUT;                       // this block owns COUT of the output columns
     a.W = reinterpret_cast<const T *>(a.W) + (EPI == BIAS_WT ? (long long)c0 : (long long)c0 * a.K);
@@ -506,11 +511,18 @@ template <int LOADER>
 __device__ __forceinline__ void tile_chunk_load(const RowGemmArgs &a, int row, int col0, float4 &v0, float4 &v1) {
   long long gb = 0, xb = 0, cb = 0;
   if (LOADER == GATHER) {
-    const int bm = row / a.S, b = bm / a.M;
-    const long long p = a.idx[row];
-    gb = ((long long)b * a.N + p) * a.C;
-    xb = ((long long)b * a.N + p) * 3;
-    cb = (long long)bm * 3;
+    if (a.crow) {  // compact rows carry their global point row and their ball
+      const int4 cr = a.crow[row];
+      gb = (long long)cr.x * a.C;
+      xb = (long long)cr.x * 3;
+      cb = (long long)(cr.y >> 8) * 3;
+    } else {
+      const int bm = row / a.S, b = bm / a.M;
+      const long long p = a.idx[row];
+      gb = ((long long)b * a.N + p) * a.C;
+      xb = ((long long)b * a.N + p) * 3;
+      cb = (long long)bm * 3;
+    }
   }
   v0 = load_a4<bf16, LOADER>(a, row, col0, gb, xb, cb);
   v1 = load_a4<bf16, LOADER>(a, row, col0 + 4, gb, xb, cb);
@@ -1743,6 +1755,8 @@ int launch_bf16(int cout, const RowGemmArgs &a, hipStream_t s) {
   const bool cols_fixed = LOADER == GATHER || (a.K % 8 == 0 && 64 % (a.K / 8) == 0);  // hoisted per-lane constants
   if (lds_shape && a.K % 16 == 0 && cols_fixed && need <= 158 * 1024)
     return launch_row_gemm_lds<LOADER, EPI>(cout, a, s);
+  // the compact row map is implemented by the LDS kernels, and by the direct kernel for the wide scatter layer only
+  if (a.crow && !(LOADER == BNBWD && EPI == SCATTER)) return VLP3D_EINVAL;
   return launch_row_gemm_t<bf16, LOADER, EPI>(cout, a, s);
 }
 

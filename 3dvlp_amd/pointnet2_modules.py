@@ -71,10 +71,10 @@ class PointnetSAModuleVotes(nn.Module):
         return inds, new_xyz, idx
 
     def _use_compact(self, xyz):
-        """Distinct-row evaluation of the grouped MLP (csrc/sa_compact.hip): bf16 configuration, balls of >= 32 samples
-        (where ball-query padding dominates: 39 % / 18 % distinct rows at SA1 / SA2 of the bench scenes)."""
+        """Distinct-row evaluation of the grouped MLP (csrc/sa_compact.hip): bf16 configuration (39 % / 18 % / 72 % / 80 % of
+        the padded rows are distinct at SA1 .. SA4 of the bench scenes)."""
         return (self.compact and self.fused == "mfma" and xyz.is_cuda and self.mlp_dtype == torch.bfloat16
-                and self.nsample >= 32)
+                and self.nsample >= int(os.environ.get("VLP3D_SA_COMPACT_MIN_S", 16)))
 
     def _forward_rows(self, xyz, features, inds, geometry=None):
         """Same math as the reference sequence, on GEMM-ready rows: group_rows -> (linear, BN, ReLU) x L ->

@@ -1031,8 +1031,8 @@ def test_row_stack_final_prelu_equals_fp64_formula(training):
         assert _rel(b.grad, bd.grad) < 2e-4
 
 
-@pytest.mark.parametrize("S,need_xyz_grad", [(64, False), (32, True)])
-def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad):
+@pytest.mark.parametrize("S,need_xyz_grad,C", [(64, False, 60), (32, True, 60), (16, True, 256)])
+def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad, C):
     """The grouped MLP on the DISTINCT rows of every ball (csrc/sa_compact.hip: ball-query padding removed, multiplicities
     in the BatchNorm sums and the BatchNorm-backward term) equals the padded evaluation: pooled output, running
     statistics, every parameter gradient and the input gradients — at the tolerance of two bf16 runs that differ only in
@@ -1041,13 +1041,13 @@ def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad):
     synth = importlib.import_module("3dvlp_amd.synth")
     ext = importlib.import_module("3dvlp_amd._lib")
     torch.manual_seed(21)
-    B, N, C = 2, 8192, 60  # C + 3 padded to 64 columns: a width the scatter kernel is instantiated for
+    B, N = 2, 8192  # C + 3 padded to 64 / 288 columns: widths the scatter kernels are instantiated for
     xyz = torch.from_numpy(np.stack([synth.make_scene(30 + i, N)["xyz"] for i in range(B)]).astype(np.float32)).cuda()
     feats0 = torch.randn(B, C, N, device="cuda")
     res = []
     for compact in (False, True):
         torch.manual_seed(5)
-        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=S, mlp=[C, 64, 64, 128], use_xyz=True,
+        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=S, mlp=[C, 64, 64, 128] if C < 128 else [C, 128, 128, 256], use_xyz=True,
                                      normalize_xyz=True).cuda().train()
         m.mlp_dtype, m.compact = torch.bfloat16, compact
         x = xyz.clone().requires_grad_(need_xyz_grad)
