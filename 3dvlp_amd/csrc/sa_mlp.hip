@@ -681,6 +681,15 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * wtile;
   const long long ntiles = compact_tiles(a);
   const bool compact = a.crow != nullptr;
+  if ((long long)blockIdx.x * 4 >= ntiles) {
+    // no tile for any wave of this workgroup (a compact row map shrinks the work under a grid sized for the padded rows):
+    // leave before staging the weight; the statistic slab of this workgroup is still part of the sums
+    if (EPI == STORE || EPI == MASK) {
+      double *slab = ((EPI == STORE) ? a.stats : a.tstats) + (size_t)blockIdx.x * 2 * COUT;
+      for (int i = threadIdx.x; i < 2 * COUT; i += 256) slab[i] = 0.0;
+    }
+    return;
+  }
 
   {  // stage the weight once per workgroup
     const bf16 *W = reinterpret_cast<const bf16 *>(a.W);
