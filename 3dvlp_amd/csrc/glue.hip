@@ -185,44 +185,59 @@ __global__ __launch_bounds__(256) void relation_inputs_kernel(const float *__res
 // J_i = objects in scenes 0..i, pool = object proposals in (scene, proposal) order.  One workgroup, B*K <= 8192.
 __global__ __launch_bounds__(1024) void copy_paste_map_kernel(const long long *__restrict__ obj_mask, int B, int K,
                                                               const float *__restrict__ coin, int *__restrict__ src) {
-  extern __shared__ int sm[];  // [B*K] object flags -> pool positions; [B] n_obj; [B] J
-  int *flag = sm, *pool = sm + B * K, *nobj = pool + B * K, *J = nobj + B;
-  const int n = B * K;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) flag[i] = obj_mask[i] != 0;
-  __syncthreads();
-  if ((int)threadIdx.x < B) {
+  // One WAVE per scene (scenes beyond the 16 waves: a second round); a lane owns K/64 consecutive slots, prefix counts of
+  // the object flags by a shuffle scan (the first version walked the K slots of a scene in one thread, three times: 34 us).
+  extern __shared__ int sm[];  // [B*K] pool positions; [B] n_obj; [B*K] exclusive object prefix inside the scene
+  int *pool = sm, *nobj = sm + B * K, *pre = nobj + B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int per = (K + 63) / 64;
+  for (int b = wave; b < B; b += nwaves) {
     int c = 0;
-    for (int k = 0; k < K; ++k) c += flag[threadIdx.x * K + k];
-    nobj[threadIdx.x] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < B; ++b) { acc += nobj[b]; J[b] = acc; }
-  }
-  __syncthreads();
-  const int total = J[B - 1];
-  // pool: object slots in (scene, proposal) order; one thread per scene walks its K slots (B <= 32, K <= 1024)
-  if ((int)threadIdx.x < B) {
-    const int b = threadIdx.x;
-    int p = J[b] - nobj[b];
-    for (int k = 0; k < K; ++k)
-      if (flag[b * K + k]) pool[p++] = b * K + k;
-  }
-  __syncthreads();
-  const bool use = coin[0] < 0.5f;
-  if ((int)threadIdx.x < B) {
-    const int b = threadIdx.x;
-    int rank = 0;
-    for (int k = 0; k < K; ++k) {
-      const int i = b * K + k;
-      int s = i;
-      if (!flag[i]) {
-        if (use && total > 0 && rank < total - nobj[b]) s = pool[(J[b] + rank) % total];
-        ++rank;
+    for (int j = 0; j < per; ++j) {
+      const int k = lane * per + j;
+      if (k < K) {
+        pre[b * K + k] = c;  // objects before slot k among this lane's slots (lane offset added below)
+        c += obj_mask[b * K + k] != 0;
       }
-      src[i] = s;
     }
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    const int before = inc - c;
+    for (int j = 0; j < per; ++j) {
+      const int k = lane * per + j;
+      if (k < K) pre[b * K + k] += before;
+    }
+    if (lane == 63) nobj[b] = inc;
+  }
+  __syncthreads();
+  const int n = B * K;
+  int total = 0;
+  for (int b = 0; b < B; ++b) total += nobj[b];
+  const bool use = coin[0] < 0.5f;
+  // pool: object slots in (scene, proposal) order
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int b = i / K;
+    if (obj_mask[i] != 0) {
+      int jb = 0;
+      for (int q = 0; q < b; ++q) jb += nobj[q];  // objects in the scenes before b
+      pool[jb + pre[i]] = i;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int b = i / K, k = i - b * K;
+    int s = i;
+    if (obj_mask[i] == 0) {
+      int J = 0;
+      for (int q = 0; q <= b; ++q) J += nobj[q];  // objects in scenes 0..b
+      const int rank = k - pre[i];                // background slots before this one in its scene
+      if (use && total > 0 && rank < total - nobj[b]) s = pool[(J + rank) % total];
+    }
+    src[i] = s;
   }
 }
 
