@@ -22,6 +22,7 @@
 // and `pool` takes the max over nsample through the monotone BN+ReLU (max or min of Y by the sign of the scale).
 // T = float uses v_mfma_f32_32x32x2_f32 (exact fp32: parity path); T = bf16 uses v_mfma_f32_32x32x16_bf16.
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -2170,7 +2171,12 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   int st;
   const size_t esz = bf16_mma ? 2 : 4;  // staged element size
   const int pad = bf16_mma ? 8 : 0;     // the bf16 tiles carry 4 shorts of row padding each
-  if ((N > 256 || (N / 32) * (w.KP / 32) > 36) && N % 128 == 0 && N <= 1024) {
+  if (bf16_mma && N % 64 == 0 && N <= 512 && w.KP <= 256) {
+    // 64-column workgroup blocks: two to eight times the workgroups for the same slab volume (these launches have few
+    // row tiles; with one workgroup per 128 rows and all columns half of the CUs stayed idle)
+    const size_t lds64 = (size_t)32 * (64 + w.KP + pad) * esz;
+    st = launch_wgrad_c<float, PLAIN, 64, PLAIN, true>(w, s, dim3((unsigned)nblk, N / 64), lds64);
+  } else if ((N > 256 || (N / 32) * (w.KP / 32) > 36) && N % 128 == 0 && N <= 1024) {
     // wide layers (merged q/k/v) or more than 9 output tiles per wave: 128-column workgroup blocks
     const size_t lds128 = (size_t)32 * (128 + w.KP + pad) * esz;
     if (lds128 > 64 * 1024) return VLP3D_EINVAL;
