@@ -8,6 +8,8 @@
 // (seed, call id, element index), recomputed bit-for-bit in the backward kernel.  `seed` lives in device memory
 // (one 64-bit word the step driver advances once per step, inside the replayed graph), `call_id` distinguishes the
 // call sites of a step.  Kept for backward: xhat (the normalised rows) and rstd.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -211,8 +213,13 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const float *__restric
   reinterpret_cast<float4 *>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+static int add_norm_rows_per_wave() {
+  static const int v = getenv("VLP3D_ADDNORM_RPW") ? atoi(getenv("VLP3D_ADDNORM_RPW")) : 8;  // 16 left half of the CUs idle at 16384 rows
+  return v < 1 ? 1 : v;
+}
 extern "C" int vlp3d_add_norm_blocks(long long R) {  // workgroups (= partial slabs) of the backward kernel
-  const long long waves = (R + 15) / 16;             // 16 rows per wave
+  const int rpw = add_norm_rows_per_wave();
+  const long long waves = (R + rpw - 1) / rpw;
   long long blocks = (waves + 3) / 4;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -246,9 +253,9 @@ extern "C" int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const fl
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 64: hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
-    case 128: hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
-    case 256: hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, 16, dx, dy, partials); break;
+    case 64: hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
+    case 128: hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
+    case 256: hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
     default: return VLP3D_EINVAL;
   }
   hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
