@@ -11,6 +11,7 @@ Differences that are deliberate: the box decode stays on the device 
 round-trips through numpy inside forward, proposal_module_fcos.py:127-130), and the relation
 module's pairwise tensors are built by broadcasting instead of .repeat().
 """
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -364,7 +365,7 @@ class ProposalModule(nn.Module):
 
 class _RelationBias(torch.autograd.Function):
     """Fused pairwise-geometry bias MLP (csrc/relation_bias.hip): centre (B,K,3), packed params -> (B,4,K,K)."""
-    SLAB_BLOCKS = 256  # workgroups of the backward kernel (one partial-gradient slab each)
+    SLAB_BLOCKS = int(os.environ.get("VLP3D_RELBIAS_BLOCKS", 1024))  # workgroups of the backward kernel (one partial-gradient slab each)
 
     @staticmethod
     def forward(ctx, centre, params):
