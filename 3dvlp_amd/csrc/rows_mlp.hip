@@ -16,6 +16,7 @@
 // The weight is (N x K) row-major, or K-major (wt = 1: (K x ldw), i.e. the SAME buffer read as the transposed operand of
 // the input-gradient product — no transposed copies).
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -487,8 +488,16 @@ extern "C" int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *
                                   float *d_known, void *stream) {
   if (!dX || !idx || !weight || !d_known || B < 1 || n < 1 || m < 1 || m > 1024 || C1 < 16 || (C1 & 15) || ld < C1)
     return VLP3D_EINVAL;
-  hipLaunchKernelGGL(fp_rows_grad_kernel<16>, dim3(C1 / 16, B), dim3(256), (size_t)m * 16 * sizeof(float),
-                     (hipStream_t)stream, dX, idx, weight, n, m, C1, ld, d_known);
+  static const int ch = getenv("VLP3D_FPGRAD_CH") ? atoi(getenv("VLP3D_FPGRAD_CH")) : 8;  // 16: only C1/16 x B = 128 workgroups
+  if (ch == 8)
+    hipLaunchKernelGGL(fp_rows_grad_kernel<8>, dim3(C1 / 8, B), dim3(256), (size_t)m * 8 * sizeof(float),
+                       (hipStream_t)stream, dX, idx, weight, n, m, C1, ld, d_known);
+  else if (ch == 4)
+    hipLaunchKernelGGL(fp_rows_grad_kernel<4>, dim3(C1 / 4, B), dim3(256), (size_t)m * 4 * sizeof(float),
+                       (hipStream_t)stream, dX, idx, weight, n, m, C1, ld, d_known);
+  else
+    hipLaunchKernelGGL(fp_rows_grad_kernel<16>, dim3(C1 / 16, B), dim3(256), (size_t)m * 16 * sizeof(float),
+                       (hipStream_t)stream, dX, idx, weight, n, m, C1, ld, d_known);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
