@@ -17,6 +17,7 @@
 // The summation index of the first product is permuted too (half h of the wave covers head
 // dims 16h..16h+15) so that every lane reads 64 contiguous bytes of its row.
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -706,6 +707,11 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
 }
 
 // row strides (floats) of q / k / v (and of dq / dk / dv): >= H*D and a multiple of 4 (16-byte row slices)
+int sdpa_lds_min_bh() {
+  static const int v = getenv("VLP3D_SDPA_LDS_MIN_BH") ? atoi(getenv("VLP3D_SDPA_LDS_MIN_BH")) : 64;
+  return v;
+}
+
 bool bad_ld(int ldq, int ldk, int ldv, int H) {
   return ldq < H * D || ldk < H * D || ldv < H * D || ((ldq | ldk | ldv) & 3);
 }
@@ -751,7 +757,7 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(vlp3d_cdiv(nq, 32), H, B), gk(vlp3d_cdiv(nk, 32), H, B);
   if (bf16_mma) {
-    if (nk <= 288 && (long long)B * H >= 64) {  // K, V and K^T of a head staged once in LDS (<= 63 KB) and shared by
+    if (nk <= 288 && (long long)B * H >= sdpa_lds_min_bh()) {  // K, V and K^T of a head staged once in LDS (<= 63 KB) and shared by
       // four query waves; with few (batch, head) pairs the one-wave form keeps more CUs busy
       const int nkp = (nk + 31) & ~31;
       const size_t lds = ((size_t)2 * nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
