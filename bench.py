@@ -224,6 +224,7 @@ def kernel_rooflines(args, batch, ext):
 
 
 def main():
+    global B_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -236,10 +237,13 @@ def main():
     ap.add_argument("--host-batches", action="store_true",
                     help="feed every step a batch that starts in (pinned) HOST memory through input_pipeline.Prefetcher: the "
                          "PCIe-inclusive rate (never the headline `value`; reported in DESIGN.md)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=B_PER_GPU,
+                    help="scenes per GPU and step (default 8 = BASELINE cfg2, the headline; 32 = cfg3's per-GPU batch)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute the backbone geometry (FPS / ball query) inline instead of one batch ahead")
     args = ap.parse_args()
+    B_PER_GPU = args.scenes_per_gpu
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -346,7 +350,8 @@ def main():
             "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "cfg2: ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
+            "config": {"workload": ("cfg2" if B_PER_GPU == 8 else "cfg3 per-GPU batch (%d scenes)" % B_PER_GPU) +
+                       ": ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
                        "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                        "step": "fwd + the reference's loss (loss_joint.py: vote, objectness, box + sem-cls, DIoU + "
                                "SoftmaxRankingLoss reference, OCC/OSC; epoch 50) + bwd + flat grad all-reduce + AdamW",

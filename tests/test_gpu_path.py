@@ -1073,3 +1073,19 @@ def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad, C):
     for ba, bb in zip(a["bufs"], b["bufs"]):
         if ba.dtype.is_floating_point:
             assert _rel(bb, ba) < 1e-4
+
+
+@pytest.mark.parametrize("name,B,N", [("cfg3: 32 scenes per GPU", 32, 40000), ("cfg5: 80 000-point scenes", 4, 80000)])
+def test_step_runs_at_other_baseline_shapes(name, B, N):
+    """BASELINE.json cfg3 (batch 32 per GPU, epoch >= 50: OCC/OSC active) and cfg5 (80k-point scenes: pruned FPS with two slot
+    states per lane, grid ball query) through the captured, pipelined bf16 step: finite losses, and the loss goes down on a
+    repeated batch."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    devc = torch.device("cuda:0")
+    batch = gs.batch_to_device(synth.make_batch(0, B, num_points=N, lang_num_max=8), devc)
+    step = gs.GroundingStep(devc, epoch=50, sa_dtype=torch.bfloat16, use_graph=True, pipeline=True)
+    losses = [float(step.run(batch)) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), (name, losses)
+    assert min(losses[3:]) < losses[0], (name, losses)
