@@ -469,7 +469,8 @@ class RelationModule(nn.Module):
                 dist_weights = relation_bias(centre, self.self_attn_fc[i])  # (B,4,K,K) additive bias
             else:
                 dist_weights = self.self_attn_fc[i](pair).permute(0, 3, 1, 2)
-            features = features + _linear(obj_feat, self.obj_embedding[i].weight, self.obj_embedding[i].bias) * 0.1
+            # features + 0.1 * embedding as ONE element-wise launch (relation_module.py:117: two)
+            features = torch.add(features, _linear(obj_feat, self.obj_embedding[i].weight, self.obj_embedding[i].bias), alpha=0.1)
             be = self.bbox_embedding[i]
             if glue.smallk_supported(manual_bbox_feat, be.weight) and not torch.is_autocast_enabled("cuda"):
                 features = glue.small_linear(manual_bbox_feat, be.weight, be.bias, base=features)  # add folded in
