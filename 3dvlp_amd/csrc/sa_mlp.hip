@@ -706,6 +706,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   for (int ct = 0; ct < NCT; ++ct) s1[ct] = s2[ct] = 0.0;
 
   const int nch = 32 * kc;  // chunks of this wave's tile; 64 lanes take them 64 at a time, 4 batches in flight
+  const unsigned kc_inv = ((1u << 20) + kc - 1) / kc;  // c / kc == (c * kc_inv) >> 20 for c < 32 * kc, kc <= 64
   // kc divides 64 (host-checked): fixed columns per lane.  Wide outputs keep the accumulators' registers instead.
   constexpr bool HOIST = (LOADER == BNRELU || LOADER == BNBWD) && !(LOADER == BNRELU && COUT >= 256);
   float ca[8], cb[8], cc[8];
@@ -874,19 +875,20 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         continue;
       }
       float4 v0[4], v1[4];
+      int vrow[4], vch[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
         const int c = min(c0 + 64 * u + lane, nch - 1);
-        const int row = c / kc, ch = c - row * kc;
-        tile_chunk_load<LOADER>(a, row0 + row, ch * 8, v0[u], v1[u]);
+        // chunk -> (row, 16-byte column) by a multiply-shift (kc <= 36, c < 1152: exact): the division by a run-time kc
+        // was a ~30-instruction sequence per chunk, 17 chunks per lane and tile at K = 272
+        vrow[u] = (int)(((unsigned)c * kc_inv) >> 20);
+        vch[u] = c - vrow[u] * kc;
+        tile_chunk_load<LOADER>(a, row0 + vrow[u], vch[u] * 8, v0[u], v1[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + 64 * u + lane;
-        if (c < nch) {
-          const int row = c / kc, ch = c - row * kc;
-          *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = pack8(v0[u], v1[u]);
-        }
+        if (c < nch) *reinterpret_cast<uint4 *>(sA + vrow[u] * ldw + vch[u] * 8) = pack8(v0[u], v1[u]);
       }
     }
     f32x16 acc[NCT];
