@@ -21,6 +21,8 @@ SIGNATURES = {
     "vlp3d_abi_version": [],
     "vlp3d_fp_contract": [],
     "vlp3d_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_fps_prefix_check": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_furthest_point_sampling_cond": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_fps_workspace_bytes": [_i, _i],
     "vlp3d_furthest_point_sampling_pruned": [_vp, _i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "vlp3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -167,12 +169,30 @@ FPS_PRUNED_MIN_N = 8192   # below this the all-register dense kernel wins (no so
 FPS_PRUNED_MAX_N = 131072  # 64 slots per wave and lane-slot, two lane-slots above 65536 points
 
 
-def furthest_point_sampling(points, nsamples, algorithm=None):
-    """algorithm: None = pick by N, "dense" (csrc/fps.hip) or "pruned" (csrc/fps_pruned.hip) — identical output."""
+FPS_PREFIX_MAX_N = 65536
+
+
+def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False, return_flag=False):
+    """algorithm: None = pick by N, "dense" (csrc/fps.hip) or "pruned" (csrc/fps_pruned.hip) — identical output.
+
+    prefix_hint=True says the caller EXPECTS `points` to be an earlier FPS's samples in sampling order (every backbone
+    level after the first): two parallel kernels then try to prove that the result is 0..nsamples-1 and the sequential
+    kernel runs only if the proof fails — the output is the same with or without the hint.  return_flag adds the
+    device int (0 = proven) for tests."""
     _chk_float(points, "points")
     _chk_dev(points)
     B, N, _ = points.shape
     out = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)
+    if prefix_hint and 1 <= nsamples <= N <= FPS_PREFIX_MAX_N:
+        v = torch.empty((B, nsamples), dtype=torch.float32, device=points.device)
+        flag = torch.empty((1,), dtype=torch.int32, device=points.device)
+        tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            _check(load().vlp3d_fps_prefix_check(_p(points), B, N, int(nsamples), _p(v), _p(flag), _stream()),
+                   "fps_prefix_check")
+            _check(load().vlp3d_furthest_point_sampling_cond(_p(points), B, N, int(nsamples), _p(tmp), _p(out),
+                                                             _p(flag), _stream()), "furthest_point_sampling_cond")
+        return (out, flag) if return_flag else out
     if algorithm is None:
         algorithm = "pruned" if FPS_PRUNED_MIN_N <= N <= FPS_PRUNED_MAX_N else "dense"
     with torch.cuda.device(points.device):

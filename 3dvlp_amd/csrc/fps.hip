@@ -54,9 +54,17 @@ __device__ __forceinline__ float vmin(float a, float b) {
 template <int THREADS, int R, int L>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ xyz_all,
                                                       float *__restrict__ temp_all,
-                                                      int *__restrict__ idx_all, int N, int m, int log2P) {
+                                                      int *__restrict__ idx_all, int N, int m, int log2P,
+                                                      const int *__restrict__ not_prefix) {
   __shared__ unsigned long long s_best[3];
   __shared__ float4 s_pts[L > 0 ? L * THREADS : 1];
+  if (not_prefix != nullptr && *not_prefix == 0) {
+    // fps_prefix_check proved that the sampling order is 0, 1, 2, ..: the points are the output of an earlier FPS, in
+    // its order, and no step has a tie (see below)
+    int *__restrict__ out = idx_all + (size_t)blockIdx.x * m;
+    for (int j = threadIdx.x; j < m; j += THREADS) out[j] = j;
+    return;
+  }
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -173,15 +181,14 @@ int reference_log2_block(int n) {
 
 }  // namespace
 
-extern "C" int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *temp, int *idx,
-                                             void *stream) {
+static int fps_dense(const float *xyz, int B, int N, int m, float *temp, int *idx, const int *not_prefix, void *stream) {
   if (!xyz || !temp || !idx || B < 1 || N < 1 || m < 0) return VLP3D_EINVAL;
   if ((long long)N * 3 >= (1ll << 31)) return VLP3D_EINVAL;
   if (m == 0) return VLP3D_OK;
   hipStream_t s = (hipStream_t)stream;
   const int log2P = reference_log2_block(N);
 #define FPS_LAUNCH(T, R, L) \
-  hipLaunchKernelGGL((fps_kernel<T, R, L>), dim3(B), dim3(T), 0, s, xyz, temp, idx, N, m, log2P)
+  hipLaunchKernelGGL((fps_kernel<T, R, L>), dim3(B), dim3(T), 0, s, xyz, temp, idx, N, m, log2P, not_prefix)
   // THREADS must be a multiple of P = 2^log2P (the reference's block size) so that all points of
   // one thread share k mod P: then "lowest slot wins" inside a thread is the reference's order.
   if (N < 512) FPS_LAUNCH(256, 2, 0);        // P <= 256
@@ -194,4 +201,70 @@ extern "C" int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int
 #undef FPS_LAUNCH
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
+}
+
+extern "C" int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *temp, int *idx,
+                                             void *stream) {
+  return fps_dense(xyz, B, N, m, temp, idx, nullptr, stream);
+}
+
+// ---- FPS of an FPS-ordered point set ---------------------------------------------------------------------------------
+// The backbone samples every level from the PREVIOUS level's samples, which are stored in sampling order
+// (backbone_module.py:93-117; its fp2_inds = sa1_inds[:, :num_seed] relies on the same fact): greedy FPS restricted to a
+// prefix-closed subset that starts at the same point picks 0, 1, 2, ... again — the j-th sample maximises the distance to
+// samples 0..j-1 over ALL points, hence over the subset.  That makes m-1 dependent block-wide argmaxes (0.6 + 0.2 + 0.2 ms
+// for SA2..SA4 at cfg2, one workgroup per scene) replaceable by a fully parallel PROOF: for every step j < m and every
+// point p > j,   min_{q<j} d(p, q)  <  v_j = min_{q<j} d(j, q)   strictly, v_j > 0, and no point in the skip ball.
+// Strict inequalities leave no tie for the reference's reduction order to decide, and the distances are the sequential
+// kernel's own expression (vlp3d_sumsq3(p - q)), bit for bit.  If anything fails (not FPS-ordered input, a tie, a skipped
+// point) *not_prefix becomes 1 and the conditional entry below runs the sequential kernel: exact either way.
+namespace {
+__global__ __launch_bounds__(256) void fps_prefix_v_kernel(const float *__restrict__ xyz_all, int N, int m,
+                                                           float *__restrict__ v_all, int *__restrict__ not_prefix) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *not_prefix = 0;  // the check kernel runs after this one
+  if (i >= m) return;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+  float v = 1e10f;
+  for (int q = 0; q < i; ++q) v = fminf(v, vlp3d_sumsq3(x - xyz[q * 3], y - xyz[q * 3 + 1], z - xyz[q * 3 + 2]));
+  v_all[(size_t)b * m + i] = v;
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float *__restrict__ xyz_all, int N, int m,
+                                                               const float *__restrict__ v_all,
+                                                               int *__restrict__ not_prefix) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= N) return;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  const float *__restrict__ v = v_all + (size_t)b * m;
+  const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
+  bool bad = vlp3d_fps_skipped(x, y, z);
+  if (p >= 1 && p < m) bad = bad || !(v[p] > 0.f);
+  const int steps = p < m ? p : m;  // steps 1 .. steps-1 happen while p is still unselected
+  float r = 1e10f;
+  for (int j = 1; j < m; ++j) {  // uniform trip count: the sample coordinates and v[j] are scalar loads
+    const float qx = xyz[(j - 1) * 3], qy = xyz[(j - 1) * 3 + 1], qz = xyz[(j - 1) * 3 + 2];
+    r = fminf(r, vlp3d_sumsq3(x - qx, y - qy, z - qz));  // min over samples q < j
+    bad = bad || (j < steps && !(r < v[j]));
+  }
+  if (bad) *not_prefix = 1;
+}
+}  // namespace
+
+// v: (B, m) floats of scratch; not_prefix: one int (0 = "the sampling order is 0..m-1" proven).  N, m <= 65536.
+extern "C" int vlp3d_fps_prefix_check(const float *xyz, int B, int N, int m, float *v, int *not_prefix, void *stream) {
+  if (!xyz || !v || !not_prefix || B < 1 || N < 1 || m < 1 || m > N || N > 65536) return VLP3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fps_prefix_v_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// vlp3d_furthest_point_sampling, skipped (idx = 0..m-1) when *not_prefix == 0 (vlp3d_fps_prefix_check ran before on the
+// same stream); not_prefix == NULL: unconditional.
+extern "C" int vlp3d_furthest_point_sampling_cond(const float *xyz, int B, int N, int m, float *temp, int *idx,
+                                                  const int *not_prefix, void *stream) {
+  return fps_dense(xyz, B, N, m, temp, idx, not_prefix, stream);
 }

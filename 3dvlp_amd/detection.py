@@ -24,6 +24,10 @@ from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
+# sa2..sa4 sample from the previous level's FPS-ordered new_xyz: prove "indices = 0..m-1" in parallel instead of running the
+# sequential kernel (csrc/fps.hip vlp3d_fps_prefix_check; identical output).  VLP3D_FPS_PREFIX=0 turns the hint off.
+FPS_PREFIX_HINT = os.environ.get("VLP3D_FPS_PREFIX", "1") != "0"
+
 
 class Pointnet2Backbone(nn.Module):
     """4 set-abstraction + 2 feature-propagation layers; reads/writes the reference's data_dict keys."""
@@ -61,7 +65,7 @@ class Pointnet2Backbone(nn.Module):
         xyz = point_clouds[..., :3].contiguous()
         g = {}
         for name in ("sa1", "sa2", "sa3", "sa4"):
-            g[name] = getattr(self, name).compute_geometry(xyz)
+            g[name] = getattr(self, name).compute_geometry(xyz, fps_ordered=(name != "sa1" and FPS_PREFIX_HINT))
             xyz = g[name][1]
         g["fp1"] = PointnetFPModule.compute_geometry(g["sa3"][1], g["sa4"][1])
         g["fp2"] = PointnetFPModule.compute_geometry(g["sa2"][1], g["sa3"][1])

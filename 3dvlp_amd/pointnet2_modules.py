@@ -60,10 +60,11 @@ class PointnetSAModuleVotes(nn.Module):
         self.compact = os.environ.get("VLP3D_SA_COMPACT", "1") != "0"
 
     @torch.no_grad()
-    def compute_geometry(self, xyz):
+    def compute_geometry(self, xyz, fps_ordered=False):
         """The weight-independent part of the layer: (inds, new_xyz, ball-query idx).  Depends only on the
-        coordinates, so a step driver may compute it ahead of time on a side stream (grounding_step.py)."""
-        inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        coordinates, so a step driver may compute it ahead of time on a side stream (grounding_step.py).
+        fps_ordered: xyz is the previous level's new_xyz (FPS samples in sampling order) — a hint, see _lib."""
+        inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, fps_ordered)
         new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         if self._use_compact(xyz):

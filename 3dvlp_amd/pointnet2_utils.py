@@ -21,15 +21,16 @@ _ext.load()  # fail at import time, loudly, when the HIP library is missing
 
 class FurthestPointSampling(Function):
     @staticmethod
-    def forward(ctx, xyz, npoint):
-        """xyz (B,N,3) f32 -> (B,npoint) i32 indices, first index 0."""
-        out = _ext.furthest_point_sampling(xyz, npoint)
+    def forward(ctx, xyz, npoint, prefix_hint=False):
+        """xyz (B,N,3) f32 -> (B,npoint) i32 indices, first index 0.  prefix_hint (not in the reference): the caller expects
+        xyz to be an earlier FPS's samples in sampling order — same result, usually without the sequential kernel."""
+        out = _ext.furthest_point_sampling(xyz, npoint, prefix_hint=prefix_hint)
         ctx.mark_non_differentiable(out)
         return out
 
     @staticmethod
     def backward(ctx, a=None):
-        return None, None
+        return None, None, None
 
 
 furthest_point_sample = FurthestPointSampling.apply

@@ -47,6 +47,16 @@ int vlp3d_fp_contract(void);
  * tie order as the reference's 512-thread LDS tree. */
 int vlp3d_furthest_point_sampling(const float *xyz, int B, int N, int m, float *temp, int *idx, void *stream);
 
+/* FPS of a point set that is itself an earlier FPS's output in sampling order (every backbone level after the first,
+ * backbone_module.py:93-117: sa2..sa4 sample from the previous level's new_xyz): vlp3d_fps_prefix_check proves in two
+ * parallel kernels that the sequential result is 0..m-1 (strict inequalities at every step, no skipped point) and
+ * writes *not_prefix = 0, or 1 when the proof fails; vlp3d_furthest_point_sampling_cond then fills idx with 0..m-1 or
+ * runs the sequential kernel.  Same output as vlp3d_furthest_point_sampling either way.  v: (B, m) floats of scratch;
+ * N <= 65536.  not_prefix == NULL in _cond: unconditional. */
+int vlp3d_fps_prefix_check(const float *xyz, int B, int N, int m, float *v, int *not_prefix, void *stream);
+int vlp3d_furthest_point_sampling_cond(const float *xyz, int B, int N, int m, float *temp, int *idx,
+                                       const int *not_prefix, void *stream);
+
 /* Same output as vlp3d_furthest_point_sampling, computed with distance-bound pruning (csrc/fps_pruned.hip):
  * points are Morton-sorted into 64-point slots and a slot whose bounding box is farther from the new sample than
  * its current maximum is skipped.  workspace: vlp3d_fps_workspace_bytes(B,N) bytes of scratch.  N <= 131072. */

@@ -114,6 +114,78 @@ def test_fps_pruned_degenerate_sets_equal_dense_and_oracle(ext, kind, N, m):
     assert (pruned == orc.furthest_point_sampling(xyz, m)).all()
 
 
+@pytest.mark.parametrize("B,N,n1,m", [(2, 6000, 2048, 1024), (3, 3000, 1024, 512), (2, 1500, 512, 256), (1, 900, 300, 300),
+                                      (2, 40000, 2048, 1)])
+def test_fps_prefix_hint_proves_arange_on_fps_ordered_input(ext, B, N, n1, m):
+    """sa2..sa4 sample from the previous level's samples, stored in sampling order: the parallel proof must succeed
+    (flag 0) and the result is 0..m-1 == the sequential kernel == the oracle."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    xyz = np.stack([synth.make_scene(3100 + i, N)["xyz"] for i in range(B)])
+    t = dev(xyz)
+    first = ext.furthest_point_sampling(t, n1).long()
+    level = torch.gather(t, 1, first[..., None].expand(-1, -1, 3)).contiguous()
+    got, flag = ext.furthest_point_sampling(level, m, prefix_hint=True, return_flag=True)
+    assert int(flag.item()) == 0
+    assert (got.cpu().numpy() == np.arange(m)[None]).all()
+    assert torch.equal(got, ext.furthest_point_sampling(level, m, "dense"))
+    assert (got.cpu().numpy() == orc.furthest_point_sampling(level.cpu().numpy(), m)).all()
+
+
+@pytest.mark.parametrize("kind", ["random", "swapped", "tie", "skip", "dup"])
+def test_fps_prefix_hint_falls_back_exactly(ext, kind):
+    """A wrong hint, an exact tie at some step, a point inside the skip ball or a duplicate: the proof fails (flag 1)
+    and the sequential kernel runs — same indices as without the hint and as the oracle."""
+    rng = np.random.default_rng(17)
+    B, N, m = 2, 1024, 256
+    base = dev(scene(rng, B, 5000))
+    first = ext.furthest_point_sampling(base, N).long()
+    level = torch.gather(base, 1, first[..., None].expand(-1, -1, 3)).contiguous().cpu().numpy()
+    if kind == "random":
+        level = scene(rng, B, N)
+    elif kind == "swapped":
+        level[1, [40, 41]] = level[1, [41, 40]]
+    elif kind == "tie":      # points 0 and 1 then two candidates at exactly the same distance to both
+        level[0, 0] = (1, 1, 1)
+        level[0, 1] = (3, 1, 1)
+        level[0, 2] = (2, 2.5, 1)
+        level[0, 3] = (2, -0.5, 1)
+        level[0, 4:] = level[0, 4:] * 0.01 + np.float32(1.5)
+    elif kind == "skip":
+        level[1, 700] = (0.01, 0.01, 0.01)
+    else:
+        level[0, 300] = level[0, 7]   # a duplicate of sample 7 ties with it at step 7
+    t = dev(level)
+    got, flag = ext.furthest_point_sampling(t, m, prefix_hint=True, return_flag=True)
+    want = orc.furthest_point_sampling(level, m)
+    assert (got.cpu().numpy() == want).all()
+    assert torch.equal(got, ext.furthest_point_sampling(t, m, "dense"))
+    assert int(flag.item()) == 1
+
+
+def test_fps_prefix_hint_in_graph_replays_with_new_points(ext):
+    """The flag is rewritten by every replay: ordered input -> 0..m-1, then unordered input -> the sequential result."""
+    rng = np.random.default_rng(5)
+    B, N, m = 2, 2048, 1024
+    base = dev(scene(rng, B, 9000))
+    first = ext.furthest_point_sampling(base, N).long()
+    ordered = torch.gather(base, 1, first[..., None].expand(-1, -1, 3)).contiguous()
+    unordered = dev(scene(rng, B, N))
+    buf = ordered.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ext.furthest_point_sampling(buf, m, prefix_hint=True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ext.furthest_point_sampling(buf, m, prefix_hint=True)
+    for src in (ordered, unordered, ordered, unordered):
+        buf.copy_(src)
+        g.replay()
+        assert torch.equal(out, ext.furthest_point_sampling(src, m, "dense"))
+    assert not torch.equal(ext.furthest_point_sampling(unordered, m, "dense")[0].cpu(), torch.arange(m, dtype=torch.int32))
+
+
 def test_fps_all_points_skipped(pu):
     xyz = np.full((2, 100, 3), 0.001, np.float32)
     got = pu.furthest_point_sample(dev(xyz), 10).cpu().numpy()
