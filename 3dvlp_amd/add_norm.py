@@ -73,6 +73,58 @@ def add_norm(x, y, norm, p=0.0, training=True, mask_out=None):
     return _AddNorm.apply(x, y, norm.weight, norm.bias, p, norm.eps, _CALLS[0], state(x.device), mask_out)
 
 
+class _SumNorm(Function):
+    """(s, n) = (x + dropout_p(y), norm(s)) — the pre-norm residual stream of the caption decoder (csrc/add_norm.hip
+    vlp3d_sum_norm_*).  y None: s = x (first norm of a stack; s is then x itself, no copy)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, p, eps, std_mode, call_id, seed, mask):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        y2 = None if y is None else y.reshape(-1, D).contiguous()
+        R = x2.shape[0]
+        out, xhat = torch.empty_like(x2), torch.empty_like(x2)
+        ssum = None if y is None else torch.empty_like(x2)
+        rstd = torch.empty((R,), dtype=torch.float32, device=x.device)
+        kappa = torch.empty((R,), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_sum_norm_fwd", x2, y2, gamma.contiguous(), beta.contiguous(), R, D, float(p), seed, call_id,
+                  float(eps), int(std_mode), ssum, out, xhat, rstd, kappa, mask)
+        ctx.save_for_backward(xhat, rstd, kappa, gamma, seed)
+        ctx.cfg = (R, D, float(p), call_id, x.shape, y is not None)
+        if y is None:
+            return x.view_as(x), out.view(x.shape)
+        return ssum.view(x.shape), out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dsum, dout):
+        xhat, rstd, kappa, gamma, seed = ctx.saved_tensors
+        R, D, p, call_id, shape, has_y = ctx.cfg
+        if dout is None:
+            dout = torch.zeros(shape, dtype=torch.float32, device=xhat.device)
+        d2 = dout.reshape(R, D).contiguous()
+        r2 = None if dsum is None else dsum.reshape(R, D).contiguous()
+        dx = torch.empty_like(d2)
+        dy = torch.empty_like(d2) if has_y else None
+        nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
+        part = torch.empty((nblk, 2, D), dtype=torch.float32, device=d2.device)
+        dgb = torch.empty((2, D), dtype=torch.float32, device=d2.device)
+        _ext.call("vlp3d_sum_norm_bwd", d2, r2, xhat, rstd, kappa, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
+                  dgb)
+        return dx.view(shape), (dy.view(shape) if has_y else None), dgb[0], dgb[1], None, None, None, None, None, None
+
+
+def sum_norm_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] in _DIMS and x.numel() < 2 ** 32
+
+
+def sum_norm(x, y, gamma, beta, eps, p=0.0, training=True, std_mode=True, mask_out=None):
+    """Returns (s, n): s = x + dropout_p(y) (y may be None), n = norm(s) with scale gamma / shift beta.
+    std_mode=True: the captioner's LayerNorm (transformer_captioner.py:117-129); False: nn.LayerNorm."""
+    p = float(p) if (training and y is not None) else 0.0
+    _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
+    return _SumNorm.apply(x, y, gamma, beta, p, eps, std_mode, _CALLS[0], state(x.device), mask_out)
+
+
 class _ActDropout(Function):
     @staticmethod
     def forward(ctx, z, kind, p, call_id, seed, mask):

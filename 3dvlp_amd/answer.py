@@ -3,7 +3,7 @@
 of models/vqa/mcan_module.py:18-112.  Same attribute names and state-dict keys (the reference also constructs — and never
 calls — lang_feat_linear, object_feat_linear, object_cls and attflat_lang; they are kept so that checkpoints load strictly).
 The linear layers run on the MFMA kernels (mfma_linear), GELU + Dropout as one launch (add_norm.act_dropout).
-The caption head (models/caption_module/caption_module.py) is a BERT decoder and is not part of this package."""
+The caption head of the joint model is 3dvlp_amd/caption.py."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
                                                            const unsigned long long *__restrict__ seed, int call_id,
                                                            float eps, float *__restrict__ out,
                                                            float *__restrict__ xhat, float *__restrict__ rstd,
-                                                           unsigned char *__restrict__ mask) {
+                                                           unsigned char *__restrict__ mask, int std_mode,
+                                                           float *__restrict__ sum_out, float *__restrict__ kappa) {
   constexpr int D = 64 * EPL;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,13 +58,14 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     const long long e = row * D + c0 + i;
-    float yv = y[e];
+    float yv = y ? y[e] : 0.f;
     if (p > 0.f) {
       const bool keep = keep_element(mix, (unsigned)e, thresh);
       yv = keep ? yv * inv_keep : 0.f;
       if (mask) mask[e] = keep ? 1 : 0;
     }
     r[i] = x[e] + yv;
+    if (sum_out) sum_out[e] = r[i];
     s += r[i];
   }
   const float mean = wave_sum(s) * (1.0f / D);
@@ -73,7 +75,28 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
     const float d = r[i] - mean;
     q += d * d;
   }
-  const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+  q = wave_sum(q);
+  if (std_mode) {
+    // the captioner's own LayerNorm (transformer_captioner.py:117-129): a * (x - mean) / (std + eps) + b with the UNBIASED
+    // standard deviation and eps added to it.  With n = (x - mean) / (std + eps), r = 1 / (std + eps):
+    //   dx = r * (g - mean(g) - n * mean(g n) * kappa),  kappa = D (std + eps) / ((D - 1) std)      (g = dout * a)
+    // — the plain LayerNorm backward with one extra per-row factor, so both forms share the backward kernel.
+    const float sd = sqrtf(q * (1.0f / (D - 1)));
+    const float den = sd + eps;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const long long e = row * D + c0 + i;
+      const float h = (r[i] - mean) / den;
+      xhat[e] = h;
+      out[e] = gamma[c0 + i] * h + beta[c0 + i];
+    }
+    if (lane == 0) {
+      rstd[row] = 1.0f / den;
+      kappa[row] = (float)D * den / ((float)(D - 1) * sd);
+    }
+    return;
+  }
+  const float rs = rsqrtf(q * (1.0f / D) + eps);
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     const long long e = row * D + c0 + i;
@@ -81,7 +104,10 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
     xhat[e] = h;
     out[e] = h * gamma[c0 + i] + beta[c0 + i];
   }
-  if (lane == 0) rstd[row] = rs;
+  if (lane == 0) {
+    rstd[row] = rs;
+    if (kappa) kappa[row] = 1.0f;
+  }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * gamma;   dy = dx * mask / (1 - p);
@@ -92,7 +118,9 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(const float *__restri
                                                            const float *__restrict__ gamma, long long R, float p,
                                                            const unsigned long long *__restrict__ seed, int call_id,
                                                            int rows_per_wave, float *__restrict__ dx,
-                                                           float *__restrict__ dy, float *__restrict__ partials) {
+                                                           float *__restrict__ dy, float *__restrict__ partials,
+                                                           const float *__restrict__ dres,
+                                                           const float *__restrict__ kappa) {
   constexpr int D = 64 * EPL;
   __shared__ float red[4][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,16 +151,21 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(const float *__restri
       s1 += g[i];
       s2 += g[i] * h[i];
     }
-    const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+    const float m1 = wave_sum(s1) * (1.0f / D);
+    float m2 = wave_sum(s2) * (1.0f / D);
+    if (kappa) m2 *= kappa[row];
     const float rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       const long long e = row * D + c0 + i;
-      const float v = rs * (g[i] - m1 - h[i] * m2);
+      float v = rs * (g[i] - m1 - h[i] * m2);
+      if (dres) v += dres[e];  // the sum x + dropout(y) was also an output (pre-norm residual stream): its gradient joins here
       dx[e] = v;
-      float w = v;
-      if (p > 0.f) w = keep_element(mix, (unsigned)e, thresh) ? v * inv_keep : 0.f;
-      dy[e] = w;
+      if (dy) {
+        float w = v;
+        if (p > 0.f) w = keep_element(mix, (unsigned)e, thresh) ? v * inv_keep : 0.f;
+        dy[e] = w;
+      }
     }
   }
 #pragma unroll
@@ -225,20 +258,69 @@ extern "C" int vlp3d_add_norm_blocks(long long R) {  // workgroups (= partial sl
   return (int)blocks;
 }
 
-extern "C" int vlp3d_add_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R,
-                                  int D, float p, const unsigned long long *seed, int call_id, float eps, float *out,
-                                  float *xhat, float *rstd, unsigned char *mask, void *stream) {
-  if (!x || !y || !gamma || !beta || !out || !xhat || !rstd || R < 1 || p < 0.f || p >= 1.f || (p > 0.f && !seed) ||
-      R * (long long)D >= (1ll << 32))
+static int add_norm_fwd_any(const float *x, const float *y, const float *gamma, const float *beta, long long R, int D,
+                            float p, const unsigned long long *seed, int call_id, float eps, float *out, float *xhat,
+                            float *rstd, unsigned char *mask, int std_mode, float *sum_out, float *kappa, void *stream) {
+  if (!x || !gamma || !beta || !out || !xhat || !rstd || R < 1 || p < 0.f || p >= 1.f || (p > 0.f && (!seed || !y)) ||
+      (std_mode && !kappa) || R * (long long)D >= (1ll << 32))
     return VLP3D_EINVAL;
   const dim3 grid((unsigned)((R + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+#define ADD_NORM_FWD(EPL) \
+  hipLaunchKernelGGL(add_norm_fwd_kernel<EPL>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, \
+                     mask, std_mode, sum_out, kappa)
   switch (D) {
-    case 64: hipLaunchKernelGGL(add_norm_fwd_kernel<1>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
-    case 128: hipLaunchKernelGGL(add_norm_fwd_kernel<2>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
-    case 256: hipLaunchKernelGGL(add_norm_fwd_kernel<4>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, mask); break;
+    case 64: ADD_NORM_FWD(1); break;
+    case 128: ADD_NORM_FWD(2); break;
+    case 256: ADD_NORM_FWD(4); break;
     default: return VLP3D_EINVAL;
   }
+#undef ADD_NORM_FWD
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_add_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R,
+                                  int D, float p, const unsigned long long *seed, int call_id, float eps, float *out,
+                                  float *xhat, float *rstd, unsigned char *mask, void *stream) {
+  if (!y) return VLP3D_EINVAL;
+  return add_norm_fwd_any(x, y, gamma, beta, R, D, p, seed, call_id, eps, out, xhat, rstd, mask, 0, nullptr, nullptr, stream);
+}
+
+// Pre-norm residual stream (transformer_captioner.py:132-145 SublayerConnection: x + dropout(sublayer(norm(x)))): ONE
+// launch produces the new stream value s = x + dropout_p(y) (sum_out; y == NULL: s = x, the first norm of a stack) AND
+// norm(s) for the next sublayer.  std_mode 1 = the captioner's LayerNorm (:117-129, unbiased std, eps outside the root),
+// 0 = nn.LayerNorm.  kappa (R) is scratch kept for backward (required with std_mode 1).
+extern "C" int vlp3d_sum_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R,
+                                  int D, float p, const unsigned long long *seed, int call_id, float eps, int std_mode,
+                                  float *sum_out, float *out, float *xhat, float *rstd, float *kappa,
+                                  unsigned char *mask, void *stream) {
+  return add_norm_fwd_any(x, y, gamma, beta, R, D, p, seed, call_id, eps, out, xhat, rstd, mask, std_mode ? 1 : 0, sum_out,
+                          kappa, stream);
+}
+
+static int add_norm_bwd_any(const float *dout, const float *dres, const float *xhat, const float *rstd,
+                            const float *kappa, const float *gamma, long long R, int D, float p,
+                            const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
+                            float *dgamma_dbeta, void *stream) {
+  if (!dout || !xhat || !rstd || !gamma || !dx || !partials || !dgamma_dbeta || R < 1 || p < 0.f || p >= 1.f ||
+      (p > 0.f && !seed) || R * (long long)D >= (1ll << 32))
+    return VLP3D_EINVAL;
+  const int nblk = vlp3d_add_norm_blocks(R);
+  const dim3 grid((unsigned)nblk), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ADD_NORM_BWD(EPL) \
+  hipLaunchKernelGGL(add_norm_bwd_kernel<EPL>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, \
+                     add_norm_rows_per_wave(), dx, dy, partials, dres, kappa)
+  switch (D) {
+    case 64: ADD_NORM_BWD(1); break;
+    case 128: ADD_NORM_BWD(2); break;
+    case 256: ADD_NORM_BWD(4); break;
+    default: return VLP3D_EINVAL;
+  }
+#undef ADD_NORM_BWD
+  hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
+                     dgamma_dbeta);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
@@ -246,22 +328,18 @@ extern "C" int vlp3d_add_norm_fwd(const float *x, const float *y, const float *g
 extern "C" int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const float *rstd, const float *gamma,
                                   long long R, int D, float p, const unsigned long long *seed, int call_id, float *dx,
                                   float *dy, float *partials, float *dgamma_dbeta, void *stream) {
-  if (!dout || !xhat || !rstd || !gamma || !dx || !dy || !partials || !dgamma_dbeta || R < 1 || p < 0.f || p >= 1.f ||
-      (p > 0.f && !seed) || R * (long long)D >= (1ll << 32))
-    return VLP3D_EINVAL;
-  const int nblk = vlp3d_add_norm_blocks(R);
-  const dim3 grid((unsigned)nblk), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  switch (D) {
-    case 64: hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
-    case 128: hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
-    case 256: hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, s, dout, xhat, rstd, gamma, R, p, seed, call_id, add_norm_rows_per_wave(), dx, dy, partials); break;
-    default: return VLP3D_EINVAL;
-  }
-  hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
-                     dgamma_dbeta);
-  VLP3D_LAUNCH_CHECK();
-  return VLP3D_OK;
+  if (!dy) return VLP3D_EINVAL;
+  return add_norm_bwd_any(dout, nullptr, xhat, rstd, nullptr, gamma, R, D, p, seed, call_id, dx, dy, partials, dgamma_dbeta,
+                          stream);
+}
+
+// Backward of vlp3d_sum_norm_fwd: dout = gradient of the normalised output, dres = gradient of sum_out (NULL: none);
+// dx = total gradient of the stream value (= of x), dy = dx * mask / (1 - p) (NULL when there was no y).
+extern "C" int vlp3d_sum_norm_bwd(const float *dout, const float *dres, const float *xhat, const float *rstd,
+                                  const float *kappa, const float *gamma, long long R, int D, float p,
+                                  const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
+                                  float *dgamma_dbeta, void *stream) {
+  return add_norm_bwd_any(dout, dres, xhat, rstd, kappa, gamma, R, D, p, seed, call_id, dx, dy, partials, dgamma_dbeta, stream);
 }
 
 // out = dropout_p(act(z)) (dout == NULL) or dz = dout * act'(z) * mask / (1-p) (dout given); n % 4 == 0, n < 2^32.

@@ -164,7 +164,7 @@ __device__ __forceinline__ float column_sum32(const float *__restrict__ A, int r
   return s + __shfl_xor(s, 32);
 }
 
-__global__ __launch_bounds__(256) void relation_bias_bwd_kernel(const float *__restrict__ centre,
+__global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *__restrict__ centre,
                                                                  const float *__restrict__ Pg,
                                                                  const float *__restrict__ dout, int B, int K,
                                                                  float *__restrict__ slabs) {
