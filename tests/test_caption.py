@@ -176,15 +176,17 @@ def test_sum_norm_kernel_vs_fp64(D, std_mode, with_y, p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("early_guide", [True])
-def test_forward_train_gpu_matches_oracle_fwd_and_grads(early_guide):
+@pytest.mark.parametrize("early_guide,T", [(True, 16), (True, 17)])
+def test_forward_train_gpu_matches_oracle_fwd_and_grads(early_guide, T):
     """Fused residual stream + MFMA linears (exact fp32 configuration) against the fp64 restatement: outputs 1e-4, every
     parameter gradient 1e-3 of its largest entry (train mode, dropout 0)."""
     m = make_model(3, early_guide).cuda().train()
     for mod in m.modules():   # the attention-probability dropout is 0.1 whatever transformer_dropout says (:297)
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    e = make_endpoints(4, 4, 32, 17, device="cuda")   # 16 sequences x 17 positions: rows not a multiple of 32 at the FFN
+    # 16 sequences x T positions: T = 16 -> 256 rows, every projection on the MFMA kernels; T = 17 -> rows not a multiple
+    # of 32, the projections take the library path (the residual-stream kernel has no row constraint)
+    e = make_endpoints(4, 4, 32, T, device="cuda")
     feats = e["aggregated_vote_features"].requires_grad_(True)
     out = m(dict(e))
     loss, _ = cap.compute_cap_loss({**out, "input_ids": e["input_ids"]})
@@ -237,3 +239,37 @@ def test_caption_head_full_size_step_and_greedy():
     e2 = make_endpoints(2, 1, 256, 8, device="cuda")
     ys = m(dict(e2), is_eval=True)["lang_cap"]
     assert ys.shape == (2, 256, 6) and (ys[..., 0] == 101).all() and int(ys.max()) < 30522
+
+
+@pytest.mark.gpu
+def test_caption_head_trains_on_the_grounding_steps_proposal_features():
+    """cfg4's composition: the caption head reads the SHARED proposal features of the detection + grounding forward
+    (jointnet.py:214-215); one joint loss, one backward — gradients reach both the caption decoder and the backbone."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    step = gs.GroundingStep(dev, use_graph=False, pipeline=False, sa_dtype=torch.bfloat16)
+    head = cap.TransformerDecoderModel(30522).to(dev).train()
+    batch = gs.batch_to_device(synth.make_batch(0, 2, 40000, 8), dev)
+    ids = torch.randint(1000, 30000, (2, 8, 32), device=dev)
+    ids[..., 0] = 101
+    ids[..., 20:] = 0
+    batch["input_ids"] = ids
+    step.bucket.zero()
+    loss, d = step.forward_loss(batch)
+    for k in ("aggregated_vote_features", "aggregated_vote_xyz", "objectness_scores"):
+        assert k in d, k
+    d = head(d)
+    cap_loss, cap_acc = cap.compute_cap_loss(d)
+    assert d["lang_cap"].shape == (16, 31, 30522) and d["match_idx"].shape == (16,)
+    total = loss + cap_loss
+    step._backward(total)
+    assert torch.isfinite(total)
+    bad = [n for n, p in head.named_parameters()
+           if "src_attn" not in n and "sublayer.1." not in n and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not bad, bad
+    assert float(head.model.generator.proj.weight.grad.abs().max()) > 0
+    sa1 = step.model.backbone_net.sa1.mlp_module.layer0.conv.weight
+    g = sa1.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
