@@ -4,7 +4,7 @@ f = (glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv") + glob.glob(sys.argv[1] + 
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel" in r["Kernel_Name"]]
-pairs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if marks[i + 1] - marks[i] > 500]
+pairs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if marks[i + 1] - marks[i] > 200]
 a, b = pairs[-1]
 side_names = ("fps_", "ball_query", "three_nn", "gather_points_kernel")
 def short(n):
