@@ -583,11 +583,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
 // converted to bf16 ONCE while staging, row-major (S = Q K^T, dP = dO V^T: a lane's operand = two ds_read_b128) and
 // transposed (dV^T += dO^T P, dK^T += Q^T dS: four ds_read_b64 in the accumulator's row order); lse / delta as fp32.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
+__global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
     const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nqp, int nk, int ldq, int ldk,
-    int ldv, float scale, float *__restrict__ dk, float *__restrict__ dv) {
+    int ldv, float scale, float *__restrict__ dk, float *__restrict__ dv, int wpb, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) short sm_q[];
   constexpr int KS = D + 8;
   const int TS = nqp + 4;
@@ -623,8 +623,13 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
     sDl[c] = delta[stat];
   }
   __syncthreads();
-  const int k0 = (blockIdx.x * (nthr >> 6) + wave) * 32;
-  if (k0 >= nk) return;
+  // wave -> (key tile kt of the workgroup, query split qs): the qsplit waves of a key tile walk interleaved query tiles and
+  // their partial dK / dV meet in LDS at the end — with one wave per key tile a (batch, head) pair of the relation module
+  // (8 key tiles x 8 dependent query iterations) kept 64 workgroups of 4 waves busy, a quarter of the chip at one wave per
+  // SIMD.  No wave leaves before the last barrier.
+  const int kt = wave % wpb, qs = wave / wpb;
+  const int k0 = (blockIdx.x * wpb + kt) * 32;
+  const bool tile_ok = k0 < nk;
   const int ki = min(k0 + r, nk - 1);
   const long long krow = (long long)b * nk + ki;
   const bool k_ok = k0 + r < nk;
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
     }
   const long long stat0 = ((long long)b * H + h) * nq;
   f32x16 dka = zero16(), dva = zero16();
-  for (int q0 = 0; q0 < nq; q0 += 32) {
+  for (int q0 = tile_ok ? 32 * qs : nq; q0 < nq; q0 += 32 * qsplit) {
     f32x16 s = zero16(), dp = zero16();
     const short *qr = sQ + (q0 + r) * KS + 16 * half, *dr = sDO + (q0 + r) * KS + 16 * half;
 #pragma unroll
@@ -691,7 +696,29 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
       dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sb, dka, 0, 0, 0);
     }
   }
-  if (k_ok) {
+  // tree over the query splits through LDS (the staged operands are dead after the barrier): slot = 32 floats per lane
+  float *red = reinterpret_cast<float *>(sm_q);
+  for (int step = qsplit >> 1; step >= 1; step >>= 1) {
+    __syncthreads();
+    if (qs >= step && qs < 2 * step) {
+      float *slot = red + (size_t)((qs - step) * wpb + kt) * 2048 + lane;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        slot[64 * i] = dka[i];
+        slot[64 * (16 + i)] = dva[i];
+      }
+    }
+    __syncthreads();
+    if (qs < step) {
+      const float *slot = red + (size_t)(qs * wpb + kt) * 2048 + lane;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        dka[i] += slot[64 * i];
+        dva[i] += slot[64 * (16 + i)];
+      }
+    }
+  }
+  if (k_ok && qs == 0) {
     float *__restrict__ rk = dk + krow * ldk + h * D;
     float *__restrict__ rv = dv + krow * ldv + h * D;
 #pragma unroll
@@ -710,6 +737,20 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_lds_kernel(
 int sdpa_lds_min_bh() {
   static const int v = getenv("VLP3D_SDPA_LDS_MIN_BH") ? atoi(getenv("VLP3D_SDPA_LDS_MIN_BH")) : 64;
   return v;
+}
+
+// Workgroup shape of the LDS dK/dV kernel: key tiles per workgroup x query splits per key tile.  Measured (dq + dkv, us) at
+// (B*H, nq, nk) = (256, 256, 256) / (256, 256, 49) / (32, 256, 256 + bias): 4x1 61.0 / 42.4 / 95.7, 4x2 56.0 / 32.0 / 73.5,
+// 2x4 64.7 / 26.0 / 61.8, 1x8 82.0 / 25.8 / 56.1 — many key-tile waves: share the staging; few: split the queries.
+int dkv_wpb(long long key_tile_waves) {
+  static const int v = getenv("VLP3D_SDPA_DKV_WPB") ? atoi(getenv("VLP3D_SDPA_DKV_WPB")) : 0;
+  if (v > 0) return v > 4 ? 4 : v;
+  return key_tile_waves >= 2048 ? 4 : 1;
+}
+int dkv_qsplit(long long key_tile_waves) {  // power of two
+  static const int v = getenv("VLP3D_SDPA_DKV_QSPLIT") ? atoi(getenv("VLP3D_SDPA_DKV_QSPLIT")) : 0;
+  if (v > 0) return v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1));
+  return key_tile_waves >= 2048 ? 2 : 8;
 }
 
 bool bad_ld(int ldq, int ldk, int ldv, int H) {
@@ -769,14 +810,27 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
     const int nqp = (nq + 31) & ~31;
     const size_t lds_kv = ((size_t)2 * nqp * (D + 8) + (size_t)2 * D * (nqp + 4)) * sizeof(short) + (size_t)2 * nqp * sizeof(float);
     if (nq <= 512 && lds_kv <= 150 * 1024) {  // Q, dO (+ transposes) of a head staged once per workgroup of up to 4 key tiles
-      const int tiles = vlp3d_cdiv(nk, 32), wpb = tiles < 4 ? tiles : 4;
-      if (lds_kv > 64 * 1024) {
+      // workgroup = wpb key tiles x qsplit query splits, at most 8 waves (174 registers per lane)
+      const int tiles = vlp3d_cdiv(nk, 32), qtiles = nqp / 32;
+      const long long ktw = (long long)B * H * tiles;
+      int wpb = dkv_wpb(ktw), qsplit = dkv_qsplit(ktw);
+      if (wpb > tiles) wpb = tiles;
+      while (qsplit > qtiles) qsplit >>= 1;
+      while (wpb * qsplit > 8) {
+        if (qsplit > 1 && qsplit >= wpb) qsplit >>= 1;
+        else --wpb;
+      }
+      size_t lds_all = lds_kv;
+      const size_t lds_red = (size_t)(qsplit >> 1) * wpb * 2048 * sizeof(float);
+      if (lds_red > lds_all) lds_all = lds_red;
+      if (lds_all > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb), lds_kv, s, q, k, v, bias,
-                         bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv);
+      hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s, q,
+                         k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
+                         qsplit);
     } else
       hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
                          H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
