@@ -88,6 +88,45 @@ __device__ __forceinline__ float apply_bias(float raw, int bias_mode, const floa
   return raw;
 }
 
+// The 16 bias values a lane (query row `bias_row`, half) needs for key tile k0: keys k0 + acc_row(i, half), i.e. four runs
+// of four consecutive floats -> four 16-byte loads per lane when the row is 16-byte aligned and the tile is full (the
+// element-wise form issued 16 dword loads per tile, each touching 32..64 cache lines of 32..64 different rows).
+__device__ __forceinline__ void load_bias_tile(const float *__restrict__ bias, int bias_mode, long long bias_row, int k0,
+                                               int half, int nk, float (&bt)[16]) {
+  if (bias_mode == 0) return;
+  if ((nk & 3) == 0 && k0 + 32 <= nk) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4 *>(bias + bias_row + k0 + 8 * g + 4 * half);
+      bt[4 * g + 0] = t.x; bt[4 * g + 1] = t.y; bt[4 * g + 2] = t.z; bt[4 * g + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      bt[i] = key < nk ? bias[bias_row + key] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ float apply_bias_value(float raw, int bias_mode, float bv) {
+  return bias_mode == 1 ? raw + bv : (bias_mode == 2 ? raw * bv : raw);
+}
+__device__ __forceinline__ void store_dbias_tile(float *__restrict__ dbias, long long bias_row, int k0, int half, int nk,
+                                                 const float (&dv)[16]) {
+  if ((nk & 3) == 0 && k0 + 32 <= nk) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(dbias + bias_row + k0 + 8 * g + 4 * half) =
+          make_float4(dv[4 * g + 0], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, half);
+      if (key < nk) dbias[bias_row + key] = dv[i];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: wave = 32 queries of one (b,h); loop over key tiles; online softmax.
 // ---------------------------------------------------------------------------------------------
@@ -125,6 +164,8 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   for (int k0 = 0; k0 < nk; k0 += 32) {
     float knext[16], vnext[16];
     load_tile(min(k0 + 32, nk - 1), knext, vnext);  // clamped: the last prefetch re-reads valid rows and is unused
+    float bt[16];
+    load_bias_tile(bias, bias_mode, bias_row, k0, half, nk, bt);
     f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());  // s[reg] = S[query r][key k0 + acc_row(reg, half)]
 
     float tmax = -__builtin_inff();
@@ -133,7 +174,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
       const int key = k0 + acc_row(i, half);
       float x = -__builtin_inff();
       if (key < nk) {
-        x = apply_bias(s[i] * scale, bias_mode, bias, bias_row + key);
+        x = apply_bias_value(s[i] * scale, bias_mode, bt[i]);
         if (mask != nullptr && mask[(long long)b * nk + key] == 0.f) x = -10000.f;
       }
       s[i] = x;
@@ -230,6 +271,8 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
   const long long bias_row = (((long long)b * H + h) * nq + qi) * nk;
   for (int k0 = 0; k0 < nk; k0 += 32) {
     f32x16 s = zero16();
+    float bt[16];
+    load_bias_tile(bias, bias_mode, bias_row, k0, half, nk, bt);
     const short *kr = sK + (k0 + r) * KS + 16 * half;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -242,7 +285,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
       const int key = k0 + acc_row(i, half);
       float x = -__builtin_inff();
       if (key < nk) {
-        x = apply_bias(s[i] * scale, bias_mode, bias, bias_row + key);
+        x = apply_bias_value(s[i] * scale, bias_mode, bt[i]);
         if (mask != nullptr && mask[(long long)b * nk + key] == 0.f) x = -10000.f;
       }
       s[i] = x;
@@ -335,6 +378,8 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
   for (int k0 = 0; k0 < nk; k0 += 32) {
     float knext[16], vnext[16], kcnext[16];  // next tile in flight while this one is computed
     load_tile(min(k0 + 32, nk - 1), knext, vnext, kcnext);
+    float bt[16], db[16] = {};
+    load_bias_tile(bias, bias_mode, bias_row, k0, half, nk, bt);
     f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());    // S^T  [key][query]
     f32x16 dp = mfma_rows<BF>(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
 #pragma unroll
@@ -343,16 +388,17 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
       float ds = 0.f;
       if (key < nk) {
         const float raw = s[i] * scale;
-        float x = apply_bias(raw, bias_mode, bias, bias_row + key);
+        float x = apply_bias_value(raw, bias_mode, bt[i]);
         const bool masked = mask != nullptr && mask[(long long)b * nk + key] == 0.f;
         if (masked) x = -10000.f;
         const float p = __expf(x - lse_q);
         ds = masked ? 0.f : p * (dp[i] - dl);  // d/d(pre-softmax score); masked_fill blocks the gradient
-        if (dbias != nullptr && q_ok) dbias[bias_row + key] = bias_mode == 2 ? ds * raw : ds;
-        if (bias_mode == 2) ds *= bias[bias_row + key];
+        db[i] = bias_mode == 2 ? ds * raw : ds;
+        if (bias_mode == 2) ds *= bt[i];
       }
       s[i] = ds;
     }
+    if (dbias != nullptr && q_ok) store_dbias_tile(dbias, bias_row, k0, half, nk, db);
     // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query]
     dqa = mfma_rows<BF>(kcol, s, dqa);
 #pragma unroll
@@ -440,6 +486,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   f32x16 dqa = zero16();
   for (int k0 = 0; k0 < nk; k0 += 32) {
     f32x16 s = zero16(), dp = zero16();
+    float bt[16], db[16] = {};
+    load_bias_tile(bias, bias_mode, bias_row, k0, half, nk, bt);
     const short *kr = sK + (k0 + r) * KS + 16 * half, *vr = sV + (k0 + r) * KS + 16 * half;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -452,16 +500,17 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
       float ds = 0.f;
       if (key < nk) {
         const float raw = s[i] * scale;
-        float x = apply_bias(raw, bias_mode, bias, bias_row + key);
+        float x = apply_bias_value(raw, bias_mode, bt[i]);
         const bool masked = mask != nullptr && mask[(long long)b * nk + key] == 0.f;
         if (masked) x = -10000.f;
         const float p = __expf(x - lse_q);
         ds = masked ? 0.f : p * (dp[i] - dl);
-        if (dbias != nullptr && q_ok) dbias[bias_row + key] = bias_mode == 2 ? ds * raw : ds;
-        if (bias_mode == 2) ds *= bias[bias_row + key];
+        db[i] = bias_mode == 2 ? ds * raw : ds;
+        if (bias_mode == 2) ds *= bt[i];
       }
       s[i] = ds;
     }
+    if (dbias != nullptr && q_ok) store_dbias_tile(dbias, bias_row, k0, half, nk, db);
     // dQ^T[dim][query] += K^T[dim][key] * dS^T[key][query], keys in the accumulator's row order (see the forward)
     const short *kt = sKt + r * TS + k0 + 4 * half;
 #pragma unroll
