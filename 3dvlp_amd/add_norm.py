@@ -90,6 +90,7 @@ class _SumNorm(Function):
         _ext.call("vlp3d_sum_norm_fwd", x2, y2, gamma.contiguous(), beta.contiguous(), R, D, float(p), seed, call_id,
                   float(eps), int(std_mode), ssum, out, xhat, rstd, kappa, mask)
         ctx.save_for_backward(xhat, rstd, kappa, gamma, seed)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernels take NULL), not as zero fills
         ctx.cfg = (R, D, float(p), call_id, x.shape, y is not None)
         if y is None:
             return x.view_as(x), out.view(x.shape)

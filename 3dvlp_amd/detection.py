@@ -267,6 +267,7 @@ class _BoxDecode(torch.autograd.Function):
                   centre, corners, cls)
         ctx.save_for_backward(rois, heading, cls)
         ctx.nh = NH
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernels take NULL), not as zero fills
         ctx.mark_non_differentiable(corners)
         return heading, size, centre, corners
 

@@ -27,6 +27,7 @@ class _RoiSplit(Function):
         _ext.call("vlp3d_roi_split", out, ld, R, NH, NC, scale, hreg, hres, hcls, rois, obj, sem, omask, sarg)
         ctx.save_for_backward(rois)
         ctx.cfg = (R, NH, NC, scale, ld, out.shape)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernels take NULL), not as zero fills
         ctx.mark_non_differentiable(omask, sarg)
         return hreg, hres, hcls, rois, obj, sem, omask, sarg
 
@@ -60,6 +61,7 @@ class _VoteEpilogue(Function):
         _ext.call("vlp3d_vote_epilogue", seed_xyz, seed_pm, net, ld, B * S, C, vx, vf, norm)
         ctx.save_for_backward(vf, norm)
         ctx.cfg = (B * S, C, ld, tuple(net.shape))
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernels take NULL), not as zero fills
         return vx, vf
 
     @staticmethod
