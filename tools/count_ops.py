@@ -36,15 +36,19 @@ def pre(name):
 def post(m, a, o): phase[0] = "fwd:glue"
 for name, m in step.model.named_children():
     m.register_forward_pre_hook(pre(name)); m.register_forward_hook(post)
+# as the pipelined step runs it: geometry prepared beforehand (side stream), bf16 linears, deferred counters / slab sums
+geometry = step.model.backbone_net.compute_geometry(step._coords(batch))
+_orig_loss = gs.grounding_loss
+def _loss(*a, **k):
+    phase[0] = "loss"
+    return _orig_loss(*a, **k)
+gs.grounding_loss = _loss
 with Mode():
     step.bucket.zero()
     phase[0] = "fwd:glue"
-    d = dict(batch); d["epoch"] = step.epoch
-    d = step.model(d)
-    phase[0] = "loss"
-    loss = gs.grounding_loss(d, step.model.dataset_config)
+    loss, d = step.forward_loss(batch, geometry)
     phase[0] = "backward"
-    loss.backward()
+    step._backward(loss)
     phase[0] = "collect+opt"
     step.bucket.collect(); step.opt.step()
 torch.cuda.synchronize()
