@@ -33,6 +33,9 @@ def adjacency_groups(module):
                 heads.append(m.sem_cls_predictor)
             groups.append([h.weight for h in heads])
             groups.append([h.bias for h in heads])
+        elif name == "RelationModule":  # the packed parameter block of each pairwise-bias MLP (csrc/relation_bias.hip)
+            for fc in m.self_attn_fc:
+                groups.append(list(fc.parameters()))
     return groups
 
 

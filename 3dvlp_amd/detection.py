@@ -396,7 +396,7 @@ class _RelationBias(torch.autograd.Function):
 
 def relation_bias(centre, fc):
     """fc = the reference's self_attn_fc[i] Sequential; returns its output on all pairs as (B,4,K,K)."""
-    params = torch.cat([p.reshape(-1) for p in fc.parameters()])
+    params = merge_adjacent([p.reshape(-1) for p in fc.parameters()])  # a view when the step driver's FlatParams packed them
     return _RelationBias.apply(centre.detach(), params)
 
 

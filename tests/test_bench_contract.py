@@ -30,7 +30,9 @@ def test_bench_json_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "reference's loss" in d["config"]["step"]
     sm = d["step_ms"]
-    assert sm["p10"] <= sm["median"] <= sm["p90"] and abs(sm["median"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
+    # two timed steps right after the capture: the wall-clock mean may contain a slow first replay, the per-step events
+    # may not exceed it by much
+    assert 0 < sm["p10"] <= sm["median"] <= sm["p90"] and sm["median"] < 1.5 * d["ms_per_step"]
     rs = d["roofline_step"]
     assert rs["flops_per_step"] > 3e11 and 0 < rs["frac_mfma"] < 1 and 0 < rs["frac_hbm"] < 1
     names = " ".join(k["kernel"] for k in d["roofline_kernels"])
