@@ -94,7 +94,7 @@ __device__ __forceinline__ float apply_bias(float raw, int bias_mode, const floa
 __device__ __forceinline__ void load_bias_tile(const float *__restrict__ bias, int bias_mode, long long bias_row, int k0,
                                                int half, int nk, float (&bt)[16]) {
   if (bias_mode == 0) return;
-  if ((nk & 3) == 0 && k0 + 32 <= nk) {
+  if ((nk & 3) == 0 && k0 + 32 <= nk && (reinterpret_cast<size_t>(bias) & 15) == 0) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 t = *reinterpret_cast<const float4 *>(bias + bias_row + k0 + 8 * g + 4 * half);
@@ -113,7 +113,7 @@ __device__ __forceinline__ float apply_bias_value(float raw, int bias_mode, floa
 }
 __device__ __forceinline__ void store_dbias_tile(float *__restrict__ dbias, long long bias_row, int k0, int half, int nk,
                                                  const float (&dv)[16]) {
-  if ((nk & 3) == 0 && k0 + 32 <= nk) {
+  if ((nk & 3) == 0 && k0 + 32 <= nk && (reinterpret_cast<size_t>(dbias) & 15) == 0) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4 *>(dbias + bias_row + k0 + 8 * g + 4 * half) =
