@@ -48,6 +48,7 @@ SIGNATURES = {
     "vlp3d_sa_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                        _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
+    "vlp3d_linear_wgrad_batch": [_vp, _i, _vp],
     "vlp3d_copy_batch": [_vp, _i, _vp],
     "vlp3d_smallk_fwd": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
     "vlp3d_smallk_bwd": [_vp, _vp, _i, ctypes.c_longlong, _i, _i, _vp, _vp],
@@ -496,6 +497,12 @@ class SlabReduceDesc(ctypes.Structure):
                 ("n_mat", _i), ("n_bias", _i), ("K", _i), ("ldo", _i), ("ncol_out", _i), ("rot", _i)]
 
 
+class LinearWgradJob(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_linear_wgrad_job."""
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("partials", ctypes.c_void_p), ("R", ctypes.c_longlong),
+                ("K", _i), ("N", _i), ("max_blocks", _i), ("with_bias", _i)]
+
+
 class CopyDesc(ctypes.Structure):
     """include/vlp3d.h: vlp3d_copy_desc."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
@@ -536,26 +543,54 @@ class SlabReduceQueue:
         self.items = []
         self.pending = 0
         self.added = 0
+        self.wjobs = []    # queued weight-gradient launches of plain linear layers (vlp3d_linear_wgrad_batch) ...
+        self.witems = []   # ... and their slab sums, which become due once the batch has run
 
     def add(self, partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
         self.items.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), int(ncol_out), int(rot)))
         self.added += 1
         self.pending += 4 * int(nblk) * (int(n_mat) + int(n_bias))
         if self.pending >= self.FLUSH_BYTES or len(self.items) >= 40:
-            self.flush()
+            self.flush(everything=False)
 
-    def flush(self):
-        if not self.items:
+    def add_linear_wgrad(self, dy, x, partials, R, K, N, max_blocks, with_bias, nblk, dst, dbias):
+        """Queue the weight gradient of a plain linear layer itself (not only its slab sum): these launches are a few
+        hundred workgroups each and feed nothing but the optimiser, so up to 48 of them run as ONE launch at the end of
+        backward (csrc/sa_mlp.hip linear_wgrad_batch_kernel).  dy / x stay referenced until then."""
+        self.wjobs.append((dy, x, partials, int(R), int(K), int(N), int(max_blocks), int(bool(with_bias))))
+        self.witems.append((partials, dst, dbias, int(nblk), int(N) * int(K), int(N) if with_bias else 0, int(K), int(K), 0, 0))
+        self.added += 1
+        if len(self.wjobs) >= 48:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        if not self.wjobs:
             return
-        arr = (SlabReduceDesc * len(self.items))()
-        for d, (partials, dst, dbias, nblk, n_mat, n_bias, K, ldo, ncol_out, rot) in zip(arr, self.items):
-            d.partials, d.dst, d.dbias = partials.data_ptr(), dst.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
-            d.nblk, d.n_mat, d.n_bias, d.K, d.ldo, d.ncol_out, d.rot = nblk, n_mat, n_bias, K, ldo, ncol_out, rot
-        dev = self.items[0][0].device
+        arr = (LinearWgradJob * len(self.wjobs))()
+        for d, (dy, x, partials, R, K, N, max_blocks, with_bias) in zip(arr, self.wjobs):
+            d.dY, d.X, d.partials = dy.data_ptr(), x.data_ptr(), partials.data_ptr()
+            d.R, d.K, d.N, d.max_blocks, d.with_bias = R, K, N, max_blocks, with_bias
+        dev = self.wjobs[0][0].device
         with torch.cuda.device(dev):
-            _check(load().vlp3d_slab_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.items), _stream()),
-                   "vlp3d_slab_reduce_batch")
-        self.items = []
+            _check(load().vlp3d_linear_wgrad_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.wjobs), _stream()),
+                   "vlp3d_linear_wgrad_batch")
+        self.items.extend(self.witems)
+        self.wjobs, self.witems = [], []
+
+    def flush(self, everything=True):
+        """Sum the slabs that are due; everything=True (end of backward) first runs the queued linear weight gradients."""
+        if everything:
+            self.flush_wgrads()
+        while self.items:
+            chunk, self.items = self.items[:40], self.items[40:]
+            arr = (SlabReduceDesc * len(chunk))()
+            for d, (partials, dst, dbias, nblk, n_mat, n_bias, K, ldo, ncol_out, rot) in zip(arr, chunk):
+                d.partials, d.dst, d.dbias = partials.data_ptr(), dst.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
+                d.nblk, d.n_mat, d.n_bias, d.K, d.ldo, d.ncol_out, d.rot = nblk, n_mat, n_bias, K, ldo, ncol_out, rot
+            dev = chunk[0][0].device
+            with torch.cuda.device(dev):
+                _check(load().vlp3d_slab_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream()),
+                       "vlp3d_slab_reduce_batch")
         self.pending = 0
 
 

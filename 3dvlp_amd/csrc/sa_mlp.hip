@@ -1173,8 +1173,10 @@ struct WgradArgs {
 
 // BFM (fp32 storage only): stage the fp32 tiles as bf16 and contract with the bf16 MFMA — the timing configuration of the
 // plain linear layers (same operand rounding as the bf16 grouped MLPs; accumulation stays fp32).
+// The body takes its block coordinates as arguments: wgrad_kernel passes the launch's own, the batched linear form
+// (linear_wgrad_batch_kernel below) the coordinates inside one job of its table.
 template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>  // MAXT = output tiles per wave
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, const int by, const int gx, const int gy) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
@@ -1207,8 +1209,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   // with a compact row map the number of rows is only known on the device: the (worst-case sized) grid re-divides them
   const bool compact = w.src.crow != nullptr;
   const long long ntiles = compact ? compact_tiles(w.src) : w.src.R / 32;
-  const long long tpb = compact ? (ntiles + gridDim.x - 1) / gridDim.x : w.tiles_per_block;
-  const long long t0 = min(ntiles, (long long)blockIdx.x * tpb);
+  const long long tpb = compact ? (ntiles + gx - 1) / gx : w.tiles_per_block;
+  const long long t0 = min(ntiles, (long long)bx * tpb);
   const long long t1 = min(ntiles, t0 + tpb);
   // Staging is BRANCH-FREE: every global load is unconditional (clamped address) and only the LDS stores are
   // predicated — hipcc otherwise branches around each load and waits vmcnt(0) per element, serialising them.
@@ -1232,9 +1234,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   uint4 pdy[ST16 ? NE_DY8 : 1], pa8[A8 ? MAXE_A8 : 1];
   const int kf8 = KF / 8, nef8 = 32 * kf8, kfs8 = A8 ? __builtin_ctz(kf8 > 0 ? kf8 : 1) : 0;
 
-  // column-block mode (gridDim.y > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
+  // column-block mode (gy > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
   // runs as two 128-wide halves (64 instead of 144 accumulator registers: three waves per SIMD instead of one)
-  const int coff = blockIdx.y * COUT;
+  const int coff = by * COUT;
   DyConsts<T> dyk, dyk2;
   if (DYL == BNBWD) {
     if (ST16) {
@@ -1454,10 +1456,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   }
   // partial dW of this workgroup's rows: plain coalesced stores into its own slab (summed by wgrad_reduce);
   // thousands of workgroups atomically adding into the same 36 KB matrix run an order of magnitude slower
-  // slab of this row chunk: [Ntot x K | Ntot bias sums (colsum)] with Ntot = COUT * gridDim.y; this workgroup fills
+  // slab of this row chunk: [Ntot x K | Ntot bias sums (colsum)] with Ntot = COUT * gy; this workgroup fills
   // rows coff .. coff + COUT of the matrix and its part of the bias segment
-  const long long ntot = (long long)COUT * gridDim.y;
-  float *slab0 = w.partials + (long long)blockIdx.x * (ntot * K + (w.colsum ? ntot : 0));
+  const long long ntot = (long long)COUT * gy;
+  float *slab0 = w.partials + (long long)bx * (ntot * K + (w.colsum ? ntot : 0));
   float *slab = slab0 + (long long)coff * K;
   if (!ST16 && w.colsum && (int)threadIdx.x < COUT) slab0[ntot * K + coff + threadIdx.x] = csum;
 #pragma unroll
@@ -1470,6 +1472,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) slab[(long long)(32 * ct + acc_row(e, half)) * K + k] = acc[i][e];
   }
+}
+
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
+  wgrad_body<T, COUT, LOADER, MAXT, DYL, BFM>(w, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// Weight gradients of SEVERAL plain linear layers in one launch (bf16-MFMA timing configuration, 64-column blocks): the
+// backward pass of the grounding step issues 33 such launches of 6-19 us each, every one of them a few hundred workgroups
+// that leave most of the chip idle behind a memory latency; none of them feeds anything but the optimiser.  The step driver
+// therefore queues them (operands stay alive) and runs them together: blockIdx.z = job, blockIdx.x / y = the job's row group
+// / column block (workgroups beyond a job's own grid leave at once).
+struct LinWgradJob {
+  const float *dY, *X;
+  float *partials;
+  int R, K, N, nblk, tpb, colsum;
+};
+constexpr int LIN_WGRAD_BATCH = 48;
+struct LinWgradBatch {
+  LinWgradJob j[LIN_WGRAD_BATCH];
+};
+template <int MAXT>
+__global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(LinWgradBatch t) {
+  const LinWgradJob &jb = t.j[blockIdx.z];
+  const int ncb = jb.N / 64;
+  if ((int)blockIdx.x >= jb.nblk || (int)blockIdx.y >= ncb) return;
+  WgradArgs w = {};
+  w.colsum = jb.colsum;
+  w.src.K = jb.K; w.src.R = jb.R; w.src.Yin = jb.X; w.src.ldin = jb.K;
+  w.dy.Yin = jb.dY; w.dy.ldin = jb.N;
+  w.KP = (jb.K + 31) & ~31;
+  w.partials = jb.partials;
+  w.tiles_per_block = jb.tpb;
+  wgrad_body<float, 64, PLAIN, MAXT, PLAIN, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
 }
 
 // dW[i] = sum_b partials[b][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups
@@ -2200,6 +2236,59 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   const int n = N * K + (with_bias ? N : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblk, n, dW);
   VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// vlp3d_linear_wgrad (bf16_mma = 1, defer_reduce = 1) for `count` layers at once: every job writes its own slabs
+// (jobs[i].partials, same layout and slab count as the single entry gives for jobs[i].max_blocks); the caller sums them with
+// vlp3d_slab_reduce_batch afterwards.  Jobs need N % 64 == 0, N <= 512, K <= 256 (the 64-column-block form).
+extern "C" int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int count, void *stream) {
+  if (!jobs || count < 1) return VLP3D_EINVAL;
+  LinWgradBatch tab[3];
+  int n[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0}, kp[3] = {0, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  auto launch = [&](int b) -> int {
+    if (n[b] == 0) return VLP3D_OK;
+    const dim3 grid((unsigned)gx[b], (unsigned)gy[b], (unsigned)n[b]);
+    const size_t lds = (size_t)32 * (64 + kp[b] + 8) * 2;
+    if (b == 0) hipLaunchKernelGGL(linear_wgrad_batch_kernel<1>, grid, dim3(256), lds, s, tab[0]);
+    else if (b == 1) hipLaunchKernelGGL(linear_wgrad_batch_kernel<3>, grid, dim3(256), lds, s, tab[1]);
+    else hipLaunchKernelGGL(linear_wgrad_batch_kernel<4>, grid, dim3(256), lds, s, tab[2]);
+    n[b] = gx[b] = gy[b] = kp[b] = 0;
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  };
+  for (int i = 0; i < count; ++i) {
+    const vlp3d_linear_wgrad_job &q = jobs[i];
+    const int K = q.K, N = q.N;
+    const long long R = q.R;
+    if (!q.dY || !q.X || !q.partials || q.max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
+        ((K / 4) & (K / 4 - 1)) || (N & 63) || N > 512 || K > 256)
+      return VLP3D_EINVAL;
+    const int KP = (K + 31) & ~31;
+    const int per_wave = (2 * (KP / 32) + 3) / 4;  // output tiles per wave of a 64-column block
+    const int b = per_wave <= 1 ? 0 : (per_wave <= 3 ? 1 : 2);
+    const long long ntiles = R / 32;
+    long long tpb = (ntiles + q.max_blocks - 1) / q.max_blocks;
+    if (tpb < 1) tpb = 1;
+    LinWgradJob &j = tab[b].j[n[b]];
+    j.dY = q.dY; j.X = q.X; j.partials = q.partials;
+    j.R = (int)R; j.K = K; j.N = N;
+    j.nblk = (int)((ntiles + tpb - 1) / tpb);
+    j.tpb = (int)tpb;
+    j.colsum = q.with_bias != 0;
+    if (j.nblk > gx[b]) gx[b] = j.nblk;
+    if (N / 64 > gy[b]) gy[b] = N / 64;
+    if (KP > kp[b]) kp[b] = KP;
+    if (++n[b] == LIN_WGRAD_BATCH) {
+      const int st = launch(b);
+      if (st != VLP3D_OK) return st;
+    }
+  }
+  for (int b = 0; b < 3; ++b) {
+    const int st = launch(b);
+    if (st != VLP3D_OK) return st;
+  }
   return VLP3D_OK;
 }
 

@@ -16,6 +16,7 @@ _ext.load()
 BF16_MMA = False       # timing configuration (set by the step driver together with the bf16 grouped MLPs): bf16 MFMA operands
 _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
 WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BLOCKS", 128))     # at most this many workgroups (= partial [dW | db] slabs)
+BATCH_WGRAD = os.environ.get("VLP3D_LINEAR_WGRAD_BATCH", "1") != "0"  # queue the weight gradients, one launch for all
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
@@ -80,9 +81,15 @@ class _Linear(Function):
             nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
             part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
             q = _ext.slab_queue()
-            _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None), ctx.bf)
-            if q is not None:
-                q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None, N if want_db else 0)
+            if q is not None and ctx.bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256:
+                # not launched now: up to 48 of these run as ONE launch when the queue is flushed (end of backward)
+                q.add_linear_wgrad(dy2, x2, part, R, K, N, nblk, want_db, _ext.wgrad_slabs(R, nblk), dwb,
+                                   dwb[N * K:] if want_db else None)
+            else:
+                _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None), ctx.bf)
+                if q is not None:
+                    q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None,
+                          N if want_db else 0)
             dw = dwb[:N * K].view(N, K)
             if want_db:
                 db = dwb[N * K:]

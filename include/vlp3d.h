@@ -404,6 +404,21 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
  *             dslope_slabs [nslab][C] fp64 receives the partial sums of its gradient.
  * fp_rows / fp_rows_grad: X = [three_interpolate(known) | unknown] on point-major features (pointnet2_modules.py:393-411,
  *             blend order of interpolate_gpu.cu:103-104) and the adjoint w.r.t. known (m <= 1024). */
+/* One weight-gradient job of vlp3d_linear_wgrad_batch: the arguments of vlp3d_linear_wgrad(dY, X, R, K, N, NULL, partials,
+ * max_blocks, with_bias, defer_reduce = 1, bf16_mma = 1). */
+typedef struct vlp3d_linear_wgrad_job {
+  const float *dY;
+  const float *X;
+  float *partials;
+  long long R;
+  int K, N, max_blocks, with_bias;
+} vlp3d_linear_wgrad_job;
+/* The weight gradients of `count` plain linear layers (nn.Linear backward, attention.py / mmattention.py / match_module.py
+ * projections and FFNs) in one or a few launches instead of one each: they feed nothing but the optimiser, so the step driver
+ * queues them during backward and runs them together (bf16-MFMA configuration; N % 64 == 0, N <= 512, K <= 256).  Every job
+ * writes its own slabs exactly as the single entry would; sum them with vlp3d_slab_reduce_batch. */
+int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int count, void *stream);
+
 /* bf16_mma != 0: bf16 MFMA operands rounded in registers / LDS (timing configuration), fp32 I/O, statistics, accumulation */
 int vlp3d_rows_slabs(long long R);
 int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W, const float *bias, int N,

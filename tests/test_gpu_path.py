@@ -903,6 +903,50 @@ def test_deferred_slab_reduce_equals_immediate():
         assert _rel(g1, g0) <= max(2e-5, 3 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
 
 
+def test_linear_wgrad_batch_equals_single_launches():
+    """Weight gradients of many plain linear layers queued during backward and run as ONE launch at the flush
+    (vlp3d_linear_wgrad_batch: every register bucket, with / without bias, row counts from 64 to 16 384) are bit-equal to the
+    per-layer launches (same body, same slabs), and the immediate mode is untouched by the queue code."""
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    ext = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(11)
+    shapes = [(2048, 128, 128, True), (2048, 128, 384, True), (16384, 128, 256, True), (3200, 256, 128, False),
+              (64, 32, 64, True), (2048, 64, 128, True), (4096, 256, 512, True), (2048, 128, 64, False)] * 7  # 56 > 48 jobs
+    xs = [torch.randn(R, K, device="cuda", requires_grad=True) for R, K, N, b in shapes]
+    ws = [(torch.randn(N, K, device="cuda") * 0.1).requires_grad_(True) for R, K, N, b in shapes]
+    bs = [torch.randn(N, device="cuda").requires_grad_(True) if b else None for R, K, N, b in shapes]
+    gy = [torch.randn(R, N, device="cuda") for R, K, N, b in shapes]
+    assert all(ml.supported(x, w) for x, w in zip(xs, ws))
+
+    def run(batched, deferred):
+        for t in xs + ws + [b for b in bs if b is not None]:
+            t.grad = None
+        old = ml.BATCH_WGRAD
+        ml.BATCH_WGRAD = batched
+        try:
+            with ml.bf16_mma(True):
+                loss = sum((ml.linear(x, w, b) * g).sum() for x, w, b, g in zip(xs, ws, bs, gy))
+            if deferred:
+                with ext.deferred_slab_reduce() as q:
+                    loss.backward()
+                    assert (len(q.wjobs) > 0) == batched
+            else:
+                loss.backward()
+        finally:
+            ml.BATCH_WGRAD = old
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in ws + [b for b in bs if b is not None] + xs]
+
+    ref = run(False, False)
+    for batched, deferred in ((False, True), (True, True), (True, False)):
+        got = run(batched, deferred)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    w64 = ws[0].detach().double()
+    want = (gy[0].double().t() @ xs[0].detach().double())
+    assert _rel(ref[0].double(), want) < 2e-2  # bf16 operands
+
+
 @pytest.mark.parametrize("kind,p", [("relu", 0.1), ("gelu", 0.5), ("gelu", 0.0)])
 def test_act_dropout_equals_torch_with_same_mask(kind, p):
     """dropout(relu(.)) (attention.py:104-112) / Dropout(GELU(.)) (match_module.py:40-47) as one launch each way: values and
