@@ -62,7 +62,11 @@ class _AddNorm(Function):
         nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
         part = torch.empty((nblk, 2, D), dtype=torch.float32, device=dout.device)
         dgb = torch.empty((2, D), dtype=torch.float32, device=dout.device)
-        _ext.call("vlp3d_add_norm_bwd", d2, xhat, rstd, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part, dgb)
+        q = _ext.slab_queue()  # deferred: [dgamma | dbeta] is summed with the other slabs of the backward pass
+        _ext.call("vlp3d_sum_norm_bwd", d2, None, xhat, rstd, None, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
+                  dgb, int(q is not None))
+        if q is not None:
+            q.add(part, nblk, dgb, 2 * D, 2 * D, 2 * D)
         return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None, None, None
 
 
@@ -109,8 +113,11 @@ class _SumNorm(Function):
         nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
         part = torch.empty((nblk, 2, D), dtype=torch.float32, device=d2.device)
         dgb = torch.empty((2, D), dtype=torch.float32, device=d2.device)
+        q = _ext.slab_queue()
         _ext.call("vlp3d_sum_norm_bwd", d2, r2, xhat, rstd, kappa, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
-                  dgb)
+                  dgb, int(q is not None))
+        if q is not None:
+            q.add(part, nblk, dgb, 2 * D, 2 * D, 2 * D)
         return dx.view(shape), (dy.view(shape) if has_y else None), dgb[0], dgb[1], None, None, None, None, None, None
 
 

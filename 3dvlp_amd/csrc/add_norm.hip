@@ -302,9 +302,9 @@ extern "C" int vlp3d_sum_norm_fwd(const float *x, const float *y, const float *g
 static int add_norm_bwd_any(const float *dout, const float *dres, const float *xhat, const float *rstd,
                             const float *kappa, const float *gamma, long long R, int D, float p,
                             const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
-                            float *dgamma_dbeta, void *stream) {
-  if (!dout || !xhat || !rstd || !gamma || !dx || !partials || !dgamma_dbeta || R < 1 || p < 0.f || p >= 1.f ||
-      (p > 0.f && !seed) || R * (long long)D >= (1ll << 32))
+                            float *dgamma_dbeta, int defer_reduce, void *stream) {
+  if (!dout || !xhat || !rstd || !gamma || !dx || !partials || (!dgamma_dbeta && !defer_reduce) || R < 1 || p < 0.f ||
+      p >= 1.f || (p > 0.f && !seed) || R * (long long)D >= (1ll << 32))
     return VLP3D_EINVAL;
   const int nblk = vlp3d_add_norm_blocks(R);
   const dim3 grid((unsigned)nblk), block(256);
@@ -319,8 +319,9 @@ static int add_norm_bwd_any(const float *dout, const float *dres, const float *x
     default: return VLP3D_EINVAL;
   }
 #undef ADD_NORM_BWD
-  hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
-                     dgamma_dbeta);
+  if (!defer_reduce)  // else the caller sums the vlp3d_add_norm_blocks(R) slabs of 2*D floats later (vlp3d_slab_reduce_batch)
+    hipLaunchKernelGGL(add_norm_slab_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partials, nblk, 2 * D,
+                       dgamma_dbeta);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
@@ -330,16 +331,19 @@ extern "C" int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const fl
                                   float *dy, float *partials, float *dgamma_dbeta, void *stream) {
   if (!dy) return VLP3D_EINVAL;
   return add_norm_bwd_any(dout, nullptr, xhat, rstd, nullptr, gamma, R, D, p, seed, call_id, dx, dy, partials, dgamma_dbeta,
-                          stream);
+                          0, stream);
 }
 
 // Backward of vlp3d_sum_norm_fwd: dout = gradient of the normalised output, dres = gradient of sum_out (NULL: none);
 // dx = total gradient of the stream value (= of x), dy = dx * mask / (1 - p) (NULL when there was no y).
+// defer_reduce 1: [dgamma | dbeta] is NOT formed; the vlp3d_add_norm_blocks(R) slabs of 2*D floats in `partials` are left for
+// vlp3d_slab_reduce_batch (n_mat = K = ldo = 2*D) — the step driver sums them with all the other slabs of the backward pass.
 extern "C" int vlp3d_sum_norm_bwd(const float *dout, const float *dres, const float *xhat, const float *rstd,
                                   const float *kappa, const float *gamma, long long R, int D, float p,
                                   const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
-                                  float *dgamma_dbeta, void *stream) {
-  return add_norm_bwd_any(dout, dres, xhat, rstd, kappa, gamma, R, D, p, seed, call_id, dx, dy, partials, dgamma_dbeta, stream);
+                                  float *dgamma_dbeta, int defer_reduce, void *stream) {
+  return add_norm_bwd_any(dout, dres, xhat, rstd, kappa, gamma, R, D, p, seed, call_id, dx, dy, partials, dgamma_dbeta,
+                          defer_reduce, stream);
 }
 
 // out = dropout_p(act(z)) (dout == NULL) or dz = dout * act'(z) * mask / (1-p) (dout given); n % 4 == 0, n < 2^32.

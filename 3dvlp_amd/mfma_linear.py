@@ -17,6 +17,7 @@ BF16_MMA = False       # timing configuration (set by the step driver together w
 _ROWS_PER_BLOCK = 64   # rows a workgroup of the weight-gradient kernel accumulates before writing its slab
 WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BLOCKS", 128))     # at most this many workgroups (= partial [dW | db] slabs)
 BATCH_WGRAD = os.environ.get("VLP3D_LINEAR_WGRAD_BATCH", "1") != "0"  # queue the weight gradients, one launch for all
+BATCH_WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BATCH_BLOCKS", 32))  # row groups per layer inside a batch
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
@@ -79,9 +80,12 @@ class _Linear(Function):
             # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
             dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy.device)
             nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
-            part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
             q = _ext.slab_queue()
-            if q is not None and ctx.bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256:
+            batched = q is not None and ctx.bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
+            if batched:  # the batch supplies the parallelism: fewer, longer row groups per layer = a quarter of the slab traffic
+                nblk = max(8, min(BATCH_WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))
+            part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
+            if batched:
                 # not launched now: up to 48 of these run as ONE launch when the queue is flushed (end of backward)
                 q.add_linear_wgrad(dy2, x2, part, R, K, N, nblk, want_db, _ext.wgrad_slabs(R, nblk), dwb,
                                    dwb[N * K:] if want_db else None)

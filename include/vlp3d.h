@@ -332,13 +332,14 @@ int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const float *rstd, 
  * unbiased std): one launch gives the new stream value sum_out = x + dropout_p(y) (y NULL: = x) AND out = norm(sum_out).
  * std_mode 1 = that LayerNorm, 0 = nn.LayerNorm.  kappa (R): scratch kept for backward (required with std_mode 1, else
  * optional).  bwd: dout = gradient of out, dres = gradient of sum_out or NULL; dx = total gradient of x,
- * dy = dx * mask/(1-p) (NULL without y).  Other arguments as vlp3d_add_norm_*. */
+ * dy = dx * mask/(1-p) (NULL without y); defer_reduce 1 leaves the vlp3d_add_norm_blocks(R) slabs of 2*D floats in
+ * `partials` for vlp3d_slab_reduce_batch instead of forming dgamma_dbeta.  Other arguments as vlp3d_add_norm_*. */
 int vlp3d_sum_norm_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R, int D,
                        float p, const unsigned long long *seed, int call_id, float eps, int std_mode, float *sum_out,
                        float *out, float *xhat, float *rstd, float *kappa, unsigned char *mask, void *stream);
 int vlp3d_sum_norm_bwd(const float *dout, const float *dres, const float *xhat, const float *rstd, const float *kappa,
                        const float *gamma, long long R, int D, float p, const unsigned long long *seed, int call_id,
-                       float *dx, float *dy, float *partials, float *dgamma_dbeta, void *stream);
+                       float *dx, float *dy, float *partials, float *dgamma_dbeta, int defer_reduce, void *stream);
 
 /* ---- box decode of the proposal module (csrc/box_decode.hip) ------------------------------------------------
  * Replaces decode_pred_box (models/proposal_module/proposal_module_fcos.py:94-144) + get_3d_box_batch

@@ -918,11 +918,12 @@ def test_linear_wgrad_batch_equals_single_launches():
     gy = [torch.randn(R, N, device="cuda") for R, K, N, b in shapes]
     assert all(ml.supported(x, w) for x, w in zip(xs, ws))
 
-    def run(batched, deferred):
+    def run(batched, deferred, blocks=None):
         for t in xs + ws + [b for b in bs if b is not None]:
             t.grad = None
-        old = ml.BATCH_WGRAD
+        old = ml.BATCH_WGRAD, ml.BATCH_WGRAD_BLOCKS
         ml.BATCH_WGRAD = batched
+        ml.BATCH_WGRAD_BLOCKS = ml.WGRAD_BLOCKS if blocks is None else blocks  # same row groups: same summation order
         try:
             with ml.bf16_mma(True):
                 loss = sum((ml.linear(x, w, b) * g).sum() for x, w, b, g in zip(xs, ws, bs, gy))
@@ -933,7 +934,7 @@ def test_linear_wgrad_batch_equals_single_launches():
             else:
                 loss.backward()
         finally:
-            ml.BATCH_WGRAD = old
+            ml.BATCH_WGRAD, ml.BATCH_WGRAD_BLOCKS = old
         torch.cuda.synchronize()
         return [t.grad.clone() for t in ws + [b for b in bs if b is not None] + xs]
 
@@ -942,7 +943,8 @@ def test_linear_wgrad_batch_equals_single_launches():
         got = run(batched, deferred)
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
-    w64 = ws[0].detach().double()
+    for a, b in zip(run(True, True, blocks=32), ref):  # the default inside a batch: fewer, longer row groups per layer
+        assert _rel(a, b) < 1e-5
     want = (gy[0].double().t() @ xs[0].detach().double())
     assert _rel(ref[0].double(), want) < 2e-2  # bf16 operands
 
