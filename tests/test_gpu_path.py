@@ -867,8 +867,11 @@ def test_flat_params_merge_views_and_flat_adamw_equal_torch():
     assert net["unused"].weight.grad is None and torch.equal(net["unused"].weight, ref["unused"].weight)
 
 
-def test_deferred_slab_reduce_equals_immediate():
-    """Weight gradients with every slab sum of the backward pass batched into one launch at its end
+@pytest.mark.parametrize("bf16", [False, True])
+def test_deferred_slab_reduce_equals_immediate(bf16):
+    """bf16=True additionally queues the weight-gradient LAUNCHES of the plain linear layers (vlp3d_linear_wgrad_batch; same
+    kernel body, run at the flush).
+    Weight gradients with every slab sum of the backward pass batched into one launch at its end
     (_lib.deferred_slab_reduce, vlp3d_slab_reduce_batch) equal the per-layer reduce launches: SA stacks incl. the
     [xyz | features] column rotation of the gather layer, rows stacks with K slices and bias sums, nn.Linear [dW | db]."""
     gs = importlib.import_module("3dvlp_amd.grounding_step")
@@ -877,7 +880,7 @@ def test_deferred_slab_reduce_equals_immediate():
     devc = torch.device("cuda:0")
     batch = gs.batch_to_device(synth.make_batch(0, 2, num_points=8192, lang_num_max=2), devc)
     batch["random"] = torch.tensor(0.25, device=devc)
-    step = gs.GroundingStep(devc)
+    step = gs.GroundingStep(devc, sa_dtype=torch.bfloat16) if bf16 else gs.GroundingStep(devc)
     _eval_dropout_train_bn(step)
     state = [b.clone() for b in step.model.buffers()]
     grads = []
@@ -890,7 +893,7 @@ def test_deferred_slab_reduce_equals_immediate():
             with ext.deferred_slab_reduce() as q:
                 q.FLUSH_BYTES = 1 << 40  # everything in one batch (more than 40 entries: two launches)
                 loss.backward()
-                assert q.added > 20
+                assert q.added > 20 and (len(q.wjobs) >= 20) == bf16
         else:
             loss.backward()
         step.bucket.collect()
