@@ -49,6 +49,7 @@ SIGNATURES = {
                        _i, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_slab_reduce_batch": [_vp, _i, _vp],
     "vlp3d_linear_wgrad_batch": [_vp, _i, _vp],
+    "vlp3d_rows_wgrad_batch": [_vp, _i, _vp],
     "vlp3d_copy_batch": [_vp, _i, _vp],
     "vlp3d_smallk_fwd": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
     "vlp3d_smallk_bwd": [_vp, _vp, _i, ctypes.c_longlong, _i, _i, _vp, _vp],
@@ -503,6 +504,14 @@ class LinearWgradJob(ctypes.Structure):
                 ("K", _i), ("N", _i), ("max_blocks", _i), ("with_bias", _i)]
 
 
+class RowsWgradJob(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_rows_wgrad_job."""
+    _fields_ = [("G", ctypes.c_void_p), ("Ypre", ctypes.c_void_p), ("ldg", _i), ("bn5", ctypes.c_void_p),
+                ("X", ctypes.c_void_p), ("lda", _i), ("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p),
+                ("R", ctypes.c_longlong), ("K", _i), ("N", _i), ("partials", ctypes.c_void_p), ("max_blocks", _i),
+                ("with_bias", _i)]
+
+
 class CopyDesc(ctypes.Structure):
     """include/vlp3d.h: vlp3d_copy_desc."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
@@ -544,7 +553,8 @@ class SlabReduceQueue:
         self.pending = 0
         self.added = 0
         self.wjobs = []    # queued weight-gradient launches of plain linear layers (vlp3d_linear_wgrad_batch) ...
-        self.witems = []   # ... and their slab sums, which become due once the batch has run
+        self.rjobs = []    # ... and of rows-stack layers (vlp3d_rows_wgrad_batch): (field dict incl. tensors, kept tensors) ...
+        self.witems = []   # ... and their slab sums, which become due once the batches have run
 
     def add(self, partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
         self.items.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), int(ncol_out), int(rot)))
@@ -563,19 +573,37 @@ class SlabReduceQueue:
         if len(self.wjobs) >= 48:
             self.flush_wgrads()
 
+    def add_rows_wgrad(self, fields, keep, slab):
+        """Queue one K-slice of a rows-stack weight gradient: `fields` = the RowsWgradJob fields (tensors as tensors, a
+        (tensor, element offset) pair for a pointer into a tensor), `keep` = further tensors to hold, slab = the arguments
+        of `add` for its slabs."""
+        self.rjobs.append((fields, keep))
+        partials, nblk, dst, n_mat, K, ldo, dbias, n_bias = slab
+        self.witems.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), 0, 0))
+        self.added += 1
+
     def flush_wgrads(self):
-        if not self.wjobs:
+        if not self.wjobs and not self.rjobs:
             return
-        arr = (LinearWgradJob * len(self.wjobs))()
+        n = len(self.wjobs) + len(self.rjobs)
+        arr = (RowsWgradJob * n)()
+        dev = None
         for d, (dy, x, partials, R, K, N, max_blocks, with_bias) in zip(arr, self.wjobs):
-            d.dY, d.X, d.partials = dy.data_ptr(), x.data_ptr(), partials.data_ptr()
-            d.R, d.K, d.N, d.max_blocks, d.with_bias = R, K, N, max_blocks, with_bias
-        dev = self.wjobs[0][0].device
+            dev = dy.device
+            d.G, d.X, d.partials = dy.data_ptr(), x.data_ptr(), partials.data_ptr()
+            d.ldg, d.lda, d.R, d.K, d.N, d.max_blocks, d.with_bias = N, K, R, K, N, max_blocks, with_bias
+        for d, (fields, _keep) in zip(arr[len(self.wjobs):], self.rjobs):
+            for k, v in fields.items():
+                if isinstance(v, tuple):  # (tensor, element offset)
+                    v = v[0].data_ptr() + v[0].element_size() * v[1]
+                elif torch.is_tensor(v):
+                    dev = v.device
+                    v = v.data_ptr()
+                setattr(d, k, v)
         with torch.cuda.device(dev):
-            _check(load().vlp3d_linear_wgrad_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.wjobs), _stream()),
-                   "vlp3d_linear_wgrad_batch")
+            _check(load().vlp3d_rows_wgrad_batch(ctypes.cast(arr, ctypes.c_void_p), n, _stream()), "vlp3d_rows_wgrad_batch")
         self.items.extend(self.witems)
-        self.wjobs, self.witems = [], []
+        self.wjobs, self.rjobs, self.witems = [], [], []
 
     def flush(self, everything=True):
         """Sum the slabs that are due; everything=True (end of backward) first runs the queued linear weight gradients."""

@@ -1174,7 +1174,7 @@ struct WgradArgs {
 // BFM (fp32 storage only): stage the fp32 tiles as bf16 and contract with the bf16 MFMA — the timing configuration of the
 // plain linear layers (same operand rounding as the bf16 grouped MLPs; accumulation stays fp32).
 // The body takes its block coordinates as arguments: wgrad_kernel passes the launch's own, the batched linear form
-// (linear_wgrad_batch_kernel below) the coordinates inside one job of its table.
+// (rows_wgrad_batch_kernel below) the coordinates inside one job of its table.
 template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>  // MAXT = output tiles per wave
 __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, const int by, const int gx, const int gy) {
   extern __shared__ float lds[];
@@ -1479,33 +1479,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
   wgrad_body<T, COUT, LOADER, MAXT, DYL, BFM>(w, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
-// Weight gradients of SEVERAL plain linear layers in one launch (bf16-MFMA timing configuration, 64-column blocks): the
-// backward pass of the grounding step issues 33 such launches of 6-19 us each, every one of them a few hundred workgroups
-// that leave most of the chip idle behind a memory latency; none of them feeds anything but the optimiser.  The step driver
-// therefore queues them (operands stay alive) and runs them together: blockIdx.z = job, blockIdx.x / y = the job's row group
-// / column block (workgroups beyond a job's own grid leave at once).
-struct LinWgradJob {
-  const float *dY, *X;
+// Weight gradients of SEVERAL plain linear layers / rows-stack layers in one launch (bf16-MFMA timing configuration,
+// 64-column blocks): the backward pass of the grounding step issues 33 + 13 such launches of 6-19 us each, every one of them
+// a few hundred workgroups that leave most of the chip idle behind a memory latency; none of them feeds anything but the
+// optimiser.  The step driver therefore queues them (operands stay alive) and runs them together: blockIdx.z = job,
+// blockIdx.x / y = the job's row group / column block (workgroups beyond a job's own grid leave at once).
+struct RowsWgradJob {  // vlp3d_rows_wgrad's operands (a plain linear layer: Ypre = bn5 = a_scale = a_shift = NULL)
+  const float *G, *Ypre, *bn5, *X, *a_scale, *a_shift;
   float *partials;
-  int R, K, N, nblk, tpb, colsum;
+  int R, K, N, ldg, lda, nblk, tpb, colsum;
 };
-constexpr int LIN_WGRAD_BATCH = 48;
-struct LinWgradBatch {
-  LinWgradJob j[LIN_WGRAD_BATCH];
+constexpr int ROWS_WGRAD_BATCH = 40;  // 40 x 88 bytes of kernel arguments
+struct RowsWgradBatch {
+  RowsWgradJob j[ROWS_WGRAD_BATCH];
 };
-template <int MAXT>
-__global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(LinWgradBatch t) {
-  const LinWgradJob &jb = t.j[blockIdx.z];
+template <int LOADER, int DYL, int MAXT>
+__global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsWgradBatch t) {
+  const RowsWgradJob &jb = t.j[blockIdx.z];
   const int ncb = jb.N / 64;
   if ((int)blockIdx.x >= jb.nblk || (int)blockIdx.y >= ncb) return;
   WgradArgs w = {};
   w.colsum = jb.colsum;
-  w.src.K = jb.K; w.src.R = jb.R; w.src.Yin = jb.X; w.src.ldin = jb.K;
-  w.dy.Yin = jb.dY; w.dy.ldin = jb.N;
+  w.src.K = jb.K; w.src.R = jb.R; w.src.Yin = jb.X; w.src.ldin = jb.lda; w.src.scale = jb.a_scale; w.src.shift = jb.a_shift;
+  w.dy.ldin = jb.ldg;
+  if (DYL == BNBWD) {
+    const int N = jb.N;
+    w.dy.Gin = jb.G; w.dy.Yin = jb.Ypre;
+    w.dy.rstd = jb.bn5; w.dy.nmean_rstd = jb.bn5 + N; w.dy.k1 = jb.bn5 + 2 * N; w.dy.k2 = jb.bn5 + 3 * N;
+    w.dy.k3 = jb.bn5 + 4 * N;
+  } else {
+    w.dy.Yin = jb.G;
+  }
   w.KP = (jb.K + 31) & ~31;
   w.partials = jb.partials;
   w.tiles_per_block = jb.tpb;
-  wgrad_body<float, 64, PLAIN, MAXT, PLAIN, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
+  wgrad_body<float, 64, LOADER, MAXT, DYL, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
 }
 
 // dW[i] = sum_b partials[b][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups
@@ -2239,57 +2247,91 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
   return VLP3D_OK;
 }
 
-// vlp3d_linear_wgrad (bf16_mma = 1, defer_reduce = 1) for `count` layers at once: every job writes its own slabs
-// (jobs[i].partials, same layout and slab count as the single entry gives for jobs[i].max_blocks); the caller sums them with
-// vlp3d_slab_reduce_batch afterwards.  Jobs need N % 64 == 0, N <= 512, K <= 256 (the 64-column-block form).
-extern "C" int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int count, void *stream) {
-  if (!jobs || count < 1) return VLP3D_EINVAL;
-  LinWgradBatch tab[3];
-  int n[3] = {0, 0, 0}, gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0}, kp[3] = {0, 0, 0};
+namespace {
+template <int LOADER, int DYL>
+int launch_rows_batch(int maxt, const RowsWgradBatch &t, dim3 grid, size_t lds, hipStream_t s) {
+  switch (maxt) {
+    case 1: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 1>), grid, dim3(256), lds, s, t); break;
+    case 3: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 3>), grid, dim3(256), lds, s, t); break;
+    case 4: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 4>), grid, dim3(256), lds, s, t); break;
+    case 6: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 6>), grid, dim3(256), lds, s, t); break;
+    default: return VLP3D_EINVAL;
+  }
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+}  // namespace
+
+// vlp3d_rows_wgrad (bf16_mma = 1, defer_reduce = 1) for `count` layers at once: jobs of one kernel instantiation (operand
+// loader, dY loader, accumulator tiles per wave) share a launch; every job writes its own slabs (jobs[i].partials, same
+// layout and slab count as the single entry gives for jobs[i].max_blocks); the caller sums them with
+// vlp3d_slab_reduce_batch afterwards.  N % 64 == 0, N <= 512, K as for vlp3d_rows_wgrad (a plain linear layer: K % 4 == 0,
+// K / 4 a power of two, K <= 256).
+extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int count, void *stream) {
+  if (!jobs || count < 1 || count > 1024) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  auto launch = [&](int b) -> int {
-    if (n[b] == 0) return VLP3D_OK;
-    const dim3 grid((unsigned)gx[b], (unsigned)gy[b], (unsigned)n[b]);
-    const size_t lds = (size_t)32 * (64 + kp[b] + 8) * 2;
-    if (b == 0) hipLaunchKernelGGL(linear_wgrad_batch_kernel<1>, grid, dim3(256), lds, s, tab[0]);
-    else if (b == 1) hipLaunchKernelGGL(linear_wgrad_batch_kernel<3>, grid, dim3(256), lds, s, tab[1]);
-    else hipLaunchKernelGGL(linear_wgrad_batch_kernel<4>, grid, dim3(256), lds, s, tab[2]);
-    n[b] = gx[b] = gy[b] = kp[b] = 0;
-    VLP3D_LAUNCH_CHECK();
-    return VLP3D_OK;
-  };
+  static thread_local int key[1024];
+  static thread_local bool done[1024];
   for (int i = 0; i < count; ++i) {
-    const vlp3d_linear_wgrad_job &q = jobs[i];
+    const vlp3d_rows_wgrad_job &q = jobs[i];
     const int K = q.K, N = q.N;
     const long long R = q.R;
-    if (!q.dY || !q.X || !q.partials || q.max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
-        ((K / 4) & (K / 4 - 1)) || (N & 63) || N > 512 || K > 256)
+    if (!q.G || !q.X || !q.partials || q.max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
+        ((K / 4) & (K / 4 - 1)) || (256 % (K / 4)) || K > 288 || N < 64 || (N & 63) || N > 512 || q.ldg < N || q.lda < K ||
+        (q.bn5 && (!q.Ypre || q.with_bias)) || (q.a_scale && !q.a_shift))
       return VLP3D_EINVAL;
     const int KP = (K + 31) & ~31;
     const int per_wave = (2 * (KP / 32) + 3) / 4;  // output tiles per wave of a 64-column block
-    const int b = per_wave <= 1 ? 0 : (per_wave <= 3 ? 1 : 2);
-    const long long ntiles = R / 32;
-    long long tpb = (ntiles + q.max_blocks - 1) / q.max_blocks;
-    if (tpb < 1) tpb = 1;
-    LinWgradJob &j = tab[b].j[n[b]];
-    j.dY = q.dY; j.X = q.X; j.partials = q.partials;
-    j.R = (int)R; j.K = K; j.N = N;
-    j.nblk = (int)((ntiles + tpb - 1) / tpb);
-    j.tpb = (int)tpb;
-    j.colsum = q.with_bias != 0;
-    if (j.nblk > gx[b]) gx[b] = j.nblk;
-    if (N / 64 > gy[b]) gy[b] = N / 64;
-    if (KP > kp[b]) kp[b] = KP;
-    if (++n[b] == LIN_WGRAD_BATCH) {
-      const int st = launch(b);
-      if (st != VLP3D_OK) return st;
-    }
+    const int maxt = per_wave <= 1 ? 1 : (per_wave <= 3 ? 3 : (per_wave <= 4 ? 4 : 6));
+    key[i] = ((q.a_scale ? 1 : 0) << 8) | ((q.bn5 ? 1 : 0) << 4) | maxt;
+    done[i] = false;
   }
-  for (int b = 0; b < 3; ++b) {
-    const int st = launch(b);
+  for (int i = 0; i < count; ++i) {
+    if (done[i]) continue;
+    RowsWgradBatch t;
+    int n = 0, gx = 0, gy = 0, kp = 0;
+    for (int k = i; k < count && n < ROWS_WGRAD_BATCH; ++k) {
+      if (done[k] || key[k] != key[i]) continue;
+      const vlp3d_rows_wgrad_job &q = jobs[k];
+      const long long ntiles = q.R / 32;
+      long long tpb = (ntiles + q.max_blocks - 1) / q.max_blocks;
+      if (tpb < 1) tpb = 1;
+      RowsWgradJob &j = t.j[n];
+      j.G = q.G; j.Ypre = q.Ypre; j.bn5 = q.bn5; j.X = q.X; j.a_scale = q.a_scale; j.a_shift = q.a_shift;
+      j.partials = q.partials;
+      j.R = (int)q.R; j.K = q.K; j.N = q.N; j.ldg = q.ldg; j.lda = q.lda;
+      j.nblk = (int)((ntiles + tpb - 1) / tpb);
+      j.tpb = (int)tpb;
+      j.colsum = q.with_bias != 0;
+      const int KP = (q.K + 31) & ~31;
+      if (j.nblk > gx) gx = j.nblk;
+      if (q.N / 64 > gy) gy = q.N / 64;
+      if (KP > kp) kp = KP;
+      done[k] = true;
+      ++n;
+    }
+    const int relu = key[i] >> 8, bn = (key[i] >> 4) & 1, maxt = key[i] & 15;
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n);
+    const size_t lds = (size_t)32 * (64 + kp + 8) * 2;
+    int st;
+    if (bn) st = relu ? launch_rows_batch<BNRELU, BNBWD>(maxt, t, grid, lds, s) : launch_rows_batch<PLAIN, BNBWD>(maxt, t, grid, lds, s);
+    else st = relu ? launch_rows_batch<BNRELU, PLAIN>(maxt, t, grid, lds, s) : launch_rows_batch<PLAIN, PLAIN>(maxt, t, grid, lds, s);
     if (st != VLP3D_OK) return st;
   }
   return VLP3D_OK;
+}
+
+// The same for plain linear layers given as vlp3d_linear_wgrad's arguments (K <= 256).
+extern "C" int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int count, void *stream) {
+  if (!jobs || count < 1 || count > 1024) return VLP3D_EINVAL;
+  static thread_local vlp3d_rows_wgrad_job r[1024];
+  for (int i = 0; i < count; ++i) {
+    const vlp3d_linear_wgrad_job &q = jobs[i];
+    if (q.K > 256) return VLP3D_EINVAL;
+    r[i] = vlp3d_rows_wgrad_job{q.dY, nullptr, q.N, nullptr, q.X, q.K, nullptr, nullptr, q.R, q.K, q.N, q.partials,
+                                q.max_blocks, q.with_bias};
+  }
+  return vlp3d_rows_wgrad_batch(r, count, stream);
 }
 
 // Weight gradient of a layer of a rows stack (csrc/rows_mlp.hip): dW[:, 0:K] (N x K, row stride ldo) = dY^T A over R rows,

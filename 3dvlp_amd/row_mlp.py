@@ -20,6 +20,7 @@ from . import mfma_linear
 _ext.load()
 _ZEROS = {}
 ROWS_WGRAD_BLOCKS = int(os.environ.get("VLP3D_ROWS_WGRAD_BLOCKS", 64))
+BATCH_WGRAD = os.environ.get("VLP3D_ROWS_WGRAD_BATCH", "1") != "0"  # queue the weight gradients (vlp3d_rows_wgrad_batch)
 WGRAD_K = 256  # K-slice of one weight-gradient launch (the staging of csrc/sa_mlp.hip: wgrad_kernel covers K <= 288)
 
 
@@ -173,6 +174,16 @@ class _RowStack(Function):
                 if q is not None or off == 0:  # deferred: every K-slice keeps its own slabs until the batched sum
                     part = torch.empty((nblk, Np * ks + Np), dtype=torch.float32, device=dev)
                 db_ = dbias if off == 0 else None
+                if q is not None and bf and BATCH_WGRAD and Np <= 512:
+                    # not launched now: the rows-stack and linear weight gradients of the whole backward pass run as a few
+                    # launches when the queue is flushed (vlp3d_rows_wgrad_batch)
+                    q.add_rows_wgrad(dict(G=G, Ypre=Ys[l] if has_bn[l] else None, ldg=Np, bn5=bn5, X=(A, off), lda=lda,
+                                          a_scale=None if pv is None else (pv, off),
+                                          a_shift=None if pv is None else (pv, pv.shape[1] + off), R=R, K=ks, N=Np,
+                                          partials=part, max_blocks=nblk, with_bias=int(db_ is not None)),
+                                     (dW, dbias), (part, _ext.wgrad_slabs(R, nblk), dW[:, off:], Np * ks, ks, K, db_,
+                                                   Np if db_ is not None else 0))
+                    continue
                 _ext.call("vlp3d_rows_wgrad", G, Ys[l] if has_bn[l] else None, Np, bn5, A[:, off:], lda,
                           None if pv is None else pv[0, off:], None if pv is None else pv[1, off:], R, ks, Np,
                           dW[:, off:], K, db_, part, nblk, int(q is not None), bf)

@@ -405,6 +405,26 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
  *             dslope_slabs [nslab][C] fp64 receives the partial sums of its gradient.
  * fp_rows / fp_rows_grad: X = [three_interpolate(known) | unknown] on point-major features (pointnet2_modules.py:393-411,
  *             blend order of interpolate_gpu.cu:103-104) and the adjoint w.r.t. known (m <= 1024). */
+/* One job of vlp3d_rows_wgrad_batch: the operands of vlp3d_rows_wgrad (dW / ldo / dbias are not needed: the batch always
+ * leaves the slabs in `partials`; with_bias asks for the column sums of G in the slabs). */
+typedef struct vlp3d_rows_wgrad_job {
+  const float *G;
+  const float *Ypre;
+  int ldg;
+  const float *bn5;
+  const float *X;
+  int lda;
+  const float *a_scale, *a_shift;
+  long long R;
+  int K, N;
+  float *partials;
+  int max_blocks, with_bias;
+} vlp3d_rows_wgrad_job;
+/* Weight gradients of `count` rows-stack layers (Conv1d + BatchNorm1d + ReLU stacks of the FP / voting / ROI / relation heads,
+ * pointnet2_modules.py:371-416, voting_module.py:33-60, roi_heads.py:15-147) in a few launches: jobs of one kernel
+ * instantiation share a launch (bf16-MFMA configuration).  Slabs as vlp3d_rows_wgrad(..., defer_reduce = 1) writes them. */
+int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int count, void *stream);
+
 /* One weight-gradient job of vlp3d_linear_wgrad_batch: the arguments of vlp3d_linear_wgrad(dY, X, R, K, N, NULL, partials,
  * max_blocks, with_bias, defer_reduce = 1, bf16_mma = 1). */
 typedef struct vlp3d_linear_wgrad_job {
