@@ -555,6 +555,7 @@ class SlabReduceQueue:
         self.wjobs = []    # queued weight-gradient launches of plain linear layers (vlp3d_linear_wgrad_batch) ...
         self.rjobs = []    # ... and of rows-stack layers (vlp3d_rows_wgrad_batch): (field dict incl. tensors, kept tensors) ...
         self.witems = []   # ... and their slab sums, which become due once the batches have run
+        self.deferred = []  # (callable, kept tensors): other launches that feed only the optimiser (run first at the flush)
 
     def add(self, partials, nblk, dst, n_mat, K, ldo, dbias=None, n_bias=0, ncol_out=0, rot=0):
         self.items.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), int(ncol_out), int(rot)))
@@ -582,7 +583,14 @@ class SlabReduceQueue:
         self.witems.append((partials, dst, dbias, int(nblk), int(n_mat), int(n_bias), int(K), int(ldo), 0, 0))
         self.added += 1
 
+    def defer(self, fn, keep=()):
+        """Run fn() at the flush (a launch whose outputs nothing reads before the optimiser); `keep` stays referenced."""
+        self.deferred.append((fn, keep))
+
     def flush_wgrads(self):
+        for fn, _keep in self.deferred:
+            fn()
+        self.deferred = []
         if not self.wjobs and not self.rjobs:
             return
         n = len(self.wjobs) + len(self.rjobs)

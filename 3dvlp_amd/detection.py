@@ -389,8 +389,14 @@ class _RelationBias(torch.autograd.Function):
         n = params.numel()
         dparams = torch.empty_like(params)
         slabs = torch.empty((_RelationBias.SLAB_BLOCKS, n), dtype=torch.float32, device=centre.device)
-        _ext.call("vlp3d_relation_bias_bwd", centre, params, dout.contiguous().float(), B, K, dparams, slabs,
-                  _RelationBias.SLAB_BLOCKS)
+        dout = dout.contiguous().float()
+        run = lambda: _ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dparams, slabs,
+                                _RelationBias.SLAB_BLOCKS)
+        q = _ext.slab_queue()
+        if q is not None:  # only parameter gradients come out of this kernel: it runs with the other optimiser-only launches
+            q.defer(run, (centre, params, dout, dparams, slabs))
+            return None, dparams.view(-1)  # a view: contents arrive at the flush (see _lib.SlabReduceQueue)
+        run()
         return None, dparams
 
 
