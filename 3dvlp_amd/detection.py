@@ -472,7 +472,7 @@ class RelationModule(nn.Module):
 
             cmin, cmax = corners.min(dim=2)[0], corners.max(dim=2)[0]
             box_centre = (cmin + cmax) / 2
-            manual_bbox_feat = torch.cat([box_centre, (corners - box_centre[:, :, None, :]).reshape(B, K, -1)], -1).float()
+            manual_bbox_feat = torch.cat([box_centre, (corners - box_centre[:, :, None, :]).reshape(B, K, -1)], -1).to(features.dtype)
 
         dist_weights = None
         for i in range(self.depth):

@@ -44,6 +44,14 @@ class MatchModule(nn.Module):
         self.temp = nn.Parameter(torch.ones([]) * 0.07)
         self.use_match_con_loss = use_match_con_loss
 
+    def unused_batchnorms(self):
+        """BatchNorm layers that exist for checkpoint compatibility but never run in this configuration: a step driver
+        that increments all `num_batches_tracked` in one launch (grounding_step._deferred_bn_counters) must skip them —
+        the reference's counters only advance for layers whose forward ran."""
+        if self.use_lang_emb:
+            return []
+        return [m for m in self.lang_emb_proj.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+
     @staticmethod
     def _copy_paste(features, objectness_masks):
         """Train-time augmentation (:97-121): background proposals of scene i are overwritten with object
@@ -214,7 +222,7 @@ class ContrastModule(nn.Module):
         gt_size = data_dict["k/ref_size"] if "k/ref_size" in data_dict else \
             mean_size[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
         lang_emb = data_dict["lang_emb"].view(B, -1, data_dict["lang_emb"].shape[-1])[:, :L]
-        obj = data_dict["objectness_scores"].max(2)[1].float()  # (B,K) 1 = takes part
+        obj = data_dict["objectness_scores"].max(2)[1].to(features.dtype)  # (B,K) 1 = takes part
         if self.fused and features.is_cuda and K <= 1024 and L <= 64 and features.shape[-1] % 4 == 0:
             # three launches (csrc/contrast.hip) instead of ~45 + ~45 in autograd's backward
             text = glue.l2norm_rows(_linear(lang_emb.contiguous(), self.text_proj.weight))
@@ -224,12 +232,12 @@ class ContrastModule(nn.Module):
                 text, box, boxi, obj, gt_center, gt_size, pred_center, pred_size, data_dict["lang_num"])
             return data_dict
         P = obj.sum(1)  # (B,) proposals taking part
-        lang_ok = (torch.arange(L, device=features.device)[None, :] < data_dict["lang_num"][:, None]).float()
-        lang_ok = lang_ok * (P > 0).float()[:, None]  # the reference's try/except skips empty scenes
+        lang_ok = (torch.arange(L, device=features.device)[None, :] < data_dict["lang_num"][:, None]).to(features.dtype)
+        lang_ok = lang_ok * (P > 0).to(features.dtype)[:, None]  # the reference's try/except skips empty scenes
 
         ious = axis_aligned_iou(gt_center[:, :, None, :], gt_size[:, :, None, :] + 1e-2, pred_center[:, None, :, :],
                                 pred_size[:, None, :, :])  # (B,L,K)
-        target = (ious > 0.25).float() * obj[:, None, :]
+        target = (ious > 0.25).to(features.dtype) * obj[:, None, :]
         neg_inf = -1e30  # excluded columns; their log-probabilities are zeroed before use (0 * -inf = NaN)
         Psafe = P.clamp(min=1)
 

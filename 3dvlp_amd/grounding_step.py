@@ -120,12 +120,15 @@ class _deferred_bn_counters:
     """While active, training-mode BatchNorm layers with a fixed momentum skip their own
     ``num_batches_tracked.add_(1)`` (the buffer is hidden, torch.nn.modules.batchnorm then leaves the counter
     alone); on exit every hidden counter is restored and all are incremented by ONE fused launch.  Layers with
-    ``momentum=None`` need the counter's value during forward and keep their own increment."""
+    ``momentum=None`` need the counter's value during forward and keep their own increment; layers a module reports
+    as `unused_batchnorms()` (present only so that reference checkpoints load) are left alone, like the reference
+    leaves them (round 3: the whole-step comparison with CpuStep found match.lang_emb_proj's counters advancing)."""
 
     def __init__(self, model):
+        idle = {id(b) for m in model.modules() if hasattr(m, "unused_batchnorms") for b in m.unused_batchnorms()}
         self.mods = [m for m in model.modules()
                      if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats
-                     and m.momentum is not None and m.num_batches_tracked is not None]
+                     and m.momentum is not None and m.num_batches_tracked is not None and id(m) not in idle]
 
     def __enter__(self):
         self.counters = [m.num_batches_tracked for m in self.mods]
@@ -138,6 +141,22 @@ class _deferred_bn_counters:
         if self.counters and exc[0] is None:
             torch._foreach_add_(self.counters, 1)
         return False
+
+
+class _BatchTag:
+    """(tensor object, in-place version); equal only to a tag of the SAME live tensor at the same version."""
+    __slots__ = ("src", "version")
+
+    def __init__(self, t):
+        self.src, self.version = t, t._version
+
+    def __eq__(self, other):
+        return isinstance(other, _BatchTag) and self.src is other.src and self.version == other.version
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
 
 
 class GroundingStep:
@@ -218,10 +237,13 @@ class GroundingStep:
 
     @staticmethod
     def _tag(batch):
-        """Identity of a batch's coordinates: (address, in-place version) of point_clouds.  The prepared geometry is
-        only ever used for the batch it was computed from."""
+        """Identity of a batch's coordinates: the point_clouds tensor OBJECT + its in-place version.  The prepared geometry
+        (and a captured graph's static inputs) are only ever used for the batch they were filled from.  The tag holds a
+        strong reference to the tensor: an address-based identity is unsound, because the caching allocator hands the block
+        of a freed batch to the next upload of the same size (`run(batch_to_device(...))` with a temporary would then look
+        like the previous batch and the replay would silently train on stale data — ADVICE r2)."""
         pc = batch["point_clouds"] if "point_clouds" in batch else batch["k/xyz"]  # (the static inputs keep the split only)
-        return (pc.data_ptr(), pc._version, tuple(pc.shape))
+        return _BatchTag(pc)
 
     def _fwd_bwd(self, batch, next_batch=None):
         """One forward+loss+backward.  With the pipeline on, uses the geometry prepared during the previous call IF

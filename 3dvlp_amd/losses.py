@@ -48,6 +48,20 @@ def _const(key, make, device):
     return _CONST[k]
 
 
+def _mean_size(config, device):
+    """config.mean_size_arr as a device tensor, cached ON the config object (per device).  Round 2 keyed a module-level
+    cache by id(config): a freed config's id is handed to the next one, which then decoded sizes with the previous
+    config's table (found by the direct HIP-vs-oracle tests of round 3)."""
+    cache = config.__dict__.setdefault("_vlp3d_mean_size", {}) if hasattr(config, "__dict__") else {}
+    k = str(device)
+    src = config.mean_size_arr
+    hit = cache.get(k)
+    if hit is None or hit[0] is not src:
+        hit = (src, torch.as_tensor(np.asarray(src, np.float32)).to(device))
+        cache[k] = hit
+    return hit[1]
+
+
 class SoftmaxRankingLoss(nn.Module):
     """loss.py:6-17."""
 
@@ -118,7 +132,7 @@ def recover_assigned_gt_bboxes(data_dict, config, object_assignment):
         gt_heading = torch.zeros((B, K), device=dev)
     scl = torch.gather(data_dict["size_class_label"], 1, object_assignment)
     srl = torch.gather(data_dict["size_residual_label"], 1, a3)
-    mean = _const(("mean_size", id(config)), lambda: torch.as_tensor(np.asarray(config.mean_size_arr, np.float32)), dev)
+    mean = _mean_size(config, dev)
     gt_size = mean[scl] + srl
     half = gt_size / 2
     off = agg - gt_center                                   # carries gradient to the vote centres, as in the reference
@@ -167,7 +181,7 @@ def compute_diou_loss(data_dict, config, no_reference=False, use_reg_head=False,
     B, K = pred_center.shape[:2]
     L = gt_center.shape[1]
     lang_num = data_dict["lang_num"]
-    mean = _const(("mean_size", id(config)), lambda: torch.as_tensor(np.asarray(config.mean_size_arr, np.float32)), dev)
+    mean = _mean_size(config, dev)
     gt_size = mean[data_dict["ref_size_class_label_list"]] + data_dict["ref_size_residual_label_list"]
     cluster_preds = data_dict["cluster_ref"].reshape(B, L, K)
     iou, diou = box3d_diou_batch_tensor(pred_center[:, None, :, :], pred_size[:, None, :, :],
@@ -266,7 +280,7 @@ def _labels(data_dict, config, device):
     d = data_dict
     f = lambda t: t.contiguous().float()
     i32 = lambda t: t.contiguous().to(torch.int32)
-    mean = _const(("mean_size", id(config)), lambda: torch.as_tensor(np.asarray(config.mean_size_arr, np.float32)), device)
+    mean = _mean_size(config, device)
     ref_size = d["k/ref_size"] if "k/ref_size" in d else \
         (mean[d["ref_size_class_label_list"]] + d["ref_size_residual_label_list"]).float().contiguous()
     k = lambda name, conv: d["k/" + name] if ("k/" + name) in d else conv(d[name])  # loader-prepared form when present

@@ -48,8 +48,8 @@ def _sa_cpu(sa, xyz, features):
 
 def _fp_cpu(fp, unknown, known, unknow_feats, known_feats):
     """PointnetFPModule.forward (pointnet2_modules.py:371-416)."""
-    d2, idx = orc.three_nn(_np(unknown), _np(known))
-    dist = torch.from_numpy(np.sqrt(d2))
+    d2, idx = orc.three_nn(np.ascontiguousarray(_np(unknown), np.float32), np.ascontiguousarray(_np(known), np.float32))
+    dist = torch.from_numpy(np.sqrt(d2)).to(known_feats.dtype)
     recip = 1.0 / (dist + 1e-8)
     w = recip / recip.sum(2, keepdim=True)
     idx = torch.from_numpy(idx.astype(np.int64))
@@ -63,16 +63,36 @@ def _fp_cpu(fp, unknown, known, unknow_feats, known_feats):
 class CpuStep:
     """The whole step on the CPU.  `net` is a 3dvlp_amd.grounding_step.GroundingNet built on the CPU."""
 
-    def __init__(self, seed=0, lr=1e-3):
+    def __init__(self, seed=0, lr=1e-3, dtype=torch.float32):
+        """dtype=torch.float64: the dense layers, the loss and AdamW in double precision (geometry stays the fp32 C
+        restatement: indices are defined by fp32 bits) — the yardstick of tests/test_step_parity.py."""
         self.gs = importlib.import_module("3dvlp_amd.grounding_step")
         self.losses = importlib.import_module("3dvlp_amd.losses")
         tr = importlib.import_module("3dvlp_amd.transformer")
         torch.manual_seed(seed)
-        self.net = self.gs.GroundingNet().train()
+        self.net = self.gs.GroundingNet().train().to(dtype)
+        self.dtype = dtype
         for m in self.net.modules():
             if isinstance(m, tr.ScaledDotProductAttention):
                 m.impl = "torch"      # explicit unfused attention: the CPU branch of the module
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=1e-5)
+
+    def trunk(self, batch):
+        """Backbone + voting + L2 norm only (backbone_module.py:76-135, voting_module.py:33-60, jointnet.py:148-149):
+        -> fp2_features (B,C,S), vote_xyz (B,S,3), vote_features (B,C,S).  Everything here is a continuous function of the
+        dense layers' arithmetic (the geometry depends on the input coordinates alone), which the whole step is not."""
+        net = self.net
+        pc = batch["point_clouds"]
+        xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+        bb = net.backbone_net
+        lv = []
+        for sa in (bb.sa1, bb.sa2, bb.sa3, bb.sa4):
+            xyz, feats, inds = _sa_cpu(sa, xyz, feats)
+            lv.append((xyz, feats, inds))
+        f1 = _fp_cpu(bb.fp1, lv[2][0], lv[3][0], lv[2][1], lv[3][1])
+        f = _fp_cpu(bb.fp2, lv[1][0], lv[2][0], lv[1][1], f1)
+        vx, vf = net.vgen(lv[1][0], f)
+        return f, vx, vf.div(torch.norm(vf, p=2, dim=1).unsqueeze(1))
 
     def forward_loss(self, batch):
         net = self.net
@@ -85,16 +105,29 @@ class CpuStep:
         for sa in (bb.sa1, bb.sa2, bb.sa3, bb.sa4):
             xyz, feats, inds = _sa_cpu(sa, xyz, feats)
             lv.append((xyz, feats, inds))
-        f = _fp_cpu(bb.fp1, lv[2][0], lv[3][0], lv[2][1], lv[3][1])
-        f = _fp_cpu(bb.fp2, lv[1][0], lv[2][0], lv[1][1], f)
+        f1 = _fp_cpu(bb.fp1, lv[2][0], lv[3][0], lv[2][1], lv[3][1])
+        f = _fp_cpu(bb.fp2, lv[1][0], lv[2][0], lv[1][1], f1)
+        if getattr(self, "keep", None) is not None:  # tests: intermediate activations with their gradients retained
+            for name, t in (("sa1_features", lv[0][1]), ("sa2_features", lv[1][1]), ("sa3_features", lv[2][1]),
+                            ("sa4_features", lv[3][1]), ("fp1_features", f1), ("fp2_features", f)):
+                t.retain_grad()
+                self.keep[name] = t
         d["seed_inds"], d["seed_xyz"], d["seed_features"] = lv[0][2][:, :lv[1][0].shape[1]].int(), lv[1][0], f
         vx, vf = net.vgen(lv[1][0], f)
         vf = vf.div(torch.norm(vf, p=2, dim=1).unsqueeze(1))
         d["vote_xyz"], d["vote_features"] = vx, vf
+        if getattr(self, "keep", None) is not None:
+            for name, t in (("vote_xyz", vx), ("vote_features", vf)):
+                t.retain_grad()
+                self.keep[name] = t
         prop = net.proposal
         ax, af, ai = _sa_cpu(prop.vote_aggregation, vx, vf)
         d["aggregated_vote_xyz"], d["aggregated_vote_inds"] = ax, ai.int()
         d["aggregated_vote_features"] = af.permute(0, 2, 1).contiguous()
+        if getattr(self, "keep", None) is not None:
+            for name, t in (("aggregated_vote_xyz", ax), ("aggregated_vote_features", d["aggregated_vote_features"])):
+                t.retain_grad()
+                self.keep[name] = t
         d = prop.decode_scores(prop.proposal(af, d))
         d = net.match(net.relation(d))
         d = net.constrast(d)
@@ -109,12 +142,13 @@ class CpuStep:
         return float(loss.detach())
 
 
-def to_torch(batch_np, scenes):
+def to_torch(batch_np, scenes, dtype=torch.float32):
     L = batch_np["lang_fea"].shape[0] // batch_np["point_clouds"].shape[0]
     out = {}
     for k, v in batch_np.items():
         per_sentence = k in ("lang_fea", "lang_emb")
-        out[k] = torch.from_numpy(np.ascontiguousarray(v[:scenes * L] if per_sentence else v[:scenes]))
+        t = torch.from_numpy(np.ascontiguousarray(v[:scenes * L] if per_sentence else v[:scenes]))
+        out[k] = t.to(dtype) if t.is_floating_point() else t
     out["istrain"] = [1]
     out["random"] = torch.tensor(0.75)
     return out

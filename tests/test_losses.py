@@ -3,7 +3,8 @@ HIP kernels.
 
 CPU:  oracle pieces vs the reference fixtures (SoftmaxRankingLoss `ranking_loss`, DIoU `boxes`);
       3dvlp_amd.losses impl="torch" (batched, no loops) == oracle/losses.py (the reference's loops) on every component.
-GPU:  csrc/joint_loss.hip == impl="torch": 15 reported scalars and the gradients of all ten differentiable inputs.
+GPU:  csrc/joint_loss.hip == impl="torch" AND == oracle/losses.py directly: 15 reported scalars, the label tensors and the
+      gradients of all ten differentiable inputs (against the oracle as fp64 directional derivatives of its loss).
 """
 import importlib
 from types import SimpleNamespace
@@ -123,6 +124,23 @@ def test_batched_torch_loss_equals_reference_loops(epoch, coin, NH):
         assert ((ref["smooth_labels"] > 0) & (ref["smooth_labels"] < 0.5)).any()  # label smoothing taken
 
 
+def test_many_configs_in_one_process_do_not_share_cached_tables():
+    """Regression (round 3): the decoded-size table was cached under id(config); short-lived configs reuse ids, so the
+    7th case of a loop decoded its GT sizes with an earlier case's mean_size_arr.  Found by comparing the HIP kernels with
+    the oracle directly.  Twelve configs in a row must each match the oracle."""
+    L = importlib.import_module("3dvlp_amd.losses")
+    for seed in range(20, 32):
+        d, config = _case(seed, NH=12)
+        d["epoch"], d["istrain"], d["random"] = 10, [1], 0.8
+        ref = olosses.get_joint_loss(d, vars(config), use_diou_loss=True, use_con=True)
+        t = _to_torch(d, "cpu")
+        t["epoch"], t["istrain"], t["random"] = 10, [1], torch.tensor(0.8)
+        out = L.get_joint_loss(None, t, config=config, impl="torch")
+        for k in SCALARS:
+            assert abs(float(out[k]) - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (seed, k, float(out[k]), ref[k])
+        del d, config, t, out
+
+
 def test_eval_mode_and_unsupported_switches():
     L = importlib.import_module("3dvlp_amd.losses")
     d, config = _case(5)
@@ -167,3 +185,30 @@ def test_fused_joint_loss_equals_torch_form(shape, epoch, coin, NH):
         if not (k == "heading_scores" and NH == 1):          # a one-bin softmax has zero gradient by construction
             assert scale > 0, k                              # every other input really receives gradient in this case
         assert (ga - gb).abs().max().item() <= 1e-4 * scale + 1e-9, (k, (ga - gb).abs().max().item(), scale)
+    # ... and the HIP kernels DIRECTLY against the literal-loop oracle (loss_joint.py:26-227 restated in oracle/losses.py):
+    # every reported scalar, every label tensor, and each of the ten input gradients as directional derivatives of the
+    # ORACLE's loss (fp64 central differences along the kernel's own gradient and along three random directions).
+    d["epoch"], d["istrain"], d["random"] = epoch, [1], coin
+    cfgd = vars(config)
+    ref = olosses.get_joint_loss(d, cfgd, use_diou_loss=True, use_con=True)
+    for k in SCALARS:
+        assert abs(float(b[0][k]) - ref[k]) <= 1e-4 * max(1e-3, abs(ref[k])), (k, float(b[0][k]), ref[k])
+    assert abs(float(b[0]["max_iou_rate_0.25"]) - ref["max_iou_rate_25"]) < 1e-6
+    assert abs(float(b[0]["max_iou_rate_0.5"]) - ref["max_iou_rate_5"]) < 1e-6
+    for k in ("cluster_labels", "objectness_label", "objectness_mask", "object_assignment"):
+        assert (b[0][k].cpu().numpy() == ref[k]).all(), k
+    rng = np.random.default_rng(epoch + NH)
+    for k in DIFF:
+        g = b[1][k].cpu().numpy().astype(np.float64)
+        n = float(np.linalg.norm(g))
+        if n == 0:
+            continue
+        dirs = [g / n] + [v / np.linalg.norm(v) for v in rng.normal(size=(3,) + g.shape)]
+        for u in dirs:
+            h = 1e-5
+            lp = olosses.get_joint_loss(dict(d, **{k: d[k].astype(np.float64) + h * u}), cfgd, use_diou_loss=True,
+                                        use_con=True)["loss"]
+            lm = olosses.get_joint_loss(dict(d, **{k: d[k].astype(np.float64) - h * u}), cfgd, use_diou_loss=True,
+                                        use_con=True)["loss"]
+            fd, an = (lp - lm) / (2 * h), float((g * u).sum())
+            assert abs(fd - an) <= 2e-4 * n + 1e-7, (k, fd, an, n)

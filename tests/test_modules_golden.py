@@ -224,6 +224,33 @@ def test_contrast_fused_kernel_equals_batched_ops(B, K, L, seed):
     assert float(res[0][0]) > 0 and float(res[0][1]) > 0
     for a, b in zip(res[0], res[1]):
         assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item() + 1e-6
+    # ... and the HIP kernels DIRECTLY against the oracle's literal double loop (constrast_module.py:53-131): both losses,
+    # and — the oracle is forward only — the feature gradient as a directional derivative of the oracle's loss (fp64
+    # central difference along the kernel's own gradient direction and along a random one).
+    from oracle import oracle as orc
+    W = {"pc_proj": cm.pc_proj.weight.detach().cpu().numpy(), "text_proj": cm.text_proj.weight.detach().cpu().numpy(),
+         "pc_proj_iou": cm.pc_proj_iou[0].weight.detach().cpu().numpy()}
+    gt_size = cfg.mean_size_arr[size_class] + size_res
+    lang_num_eff = np.where(obj.argmax(-1).sum(1) > 0, lang_num, 0)
+
+    def oracle_loss(f):
+        occ, osc = orc.contrast_losses(W, pred_center, pred_size, f, obj, ref_center, gt_size, base["lang_emb"],
+                                       lang_num_eff)
+        return occ, osc
+
+    occ, osc = oracle_loss(feat)
+    hip = res[1]
+    assert abs(float(hip[0]) - occ) < 1e-5 * max(1, abs(occ)), (float(hip[0]), occ)
+    assert abs(float(hip[1]) - osc) < 1e-5 * max(1, abs(osc)), (float(hip[1]), osc)
+    g = hip[2].cpu().numpy().astype(np.float64)
+    if K <= 64:  # the literal loop is O(B·L·K²) python: derivative check at the small shape only
+        for direction in (g / np.linalg.norm(g), rng.normal(size=g.shape) / np.sqrt(g.size)):
+            h = 1e-2
+            lp = oracle_loss((feat + h * direction).astype(np.float64))
+            lm = oracle_loss((feat - h * direction).astype(np.float64))
+            fd = (1.3 * (lp[0] - lm[0]) + 0.7 * (lp[1] - lm[1])) / (2 * h)
+            an = float((g * direction).sum())
+            assert abs(fd - an) < 2e-3 * max(abs(an), 1e-3) + 1e-5, (fd, an)
 
 
 def test_copy_paste_device_formulation_equals_reference_loop():
