@@ -14,22 +14,6 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned pcg_hash(unsigned x) {
-  x = x * 747796405u + 2891336453u;
-  const unsigned w = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
-  return (w >> 22u) ^ w;
-}
-
-// keep-probability test of element `e` of call `call_id` under `seed`; 24 random bits against the threshold
-__device__ __forceinline__ bool keep_element(unsigned seed_mix, unsigned e, unsigned thresh24) {
-  return (pcg_hash(e ^ seed_mix) >> 8) >= thresh24;
-}
-
-__device__ __forceinline__ unsigned seed_mix_of(const unsigned long long *__restrict__ seed, int call_id) {
-  const unsigned long long s = *seed;
-  return pcg_hash((unsigned)s ^ pcg_hash((unsigned)(s >> 32) + 0x9E3779B9u * (unsigned)(call_id + 1)));
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);

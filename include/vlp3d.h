@@ -542,6 +542,32 @@ typedef struct {
 } vlp3d_copy_desc;
 int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *stream);
 
+/* Caption head (csrc/caption.hip).  Replaces, for `TransformerDecoderModel(30522)` of models/jointnet/jointnet.py:104:
+ *
+ * cap_attn — `attention()` + the head split/merge of `MultiHeadedAttention.forward`
+ *   (models/caption_module/transformer_captioner.py:32-42, 66-78): softmax(q k^T / 4, masked_fill(mask == 0, -1e9)) ->
+ *   dropout_p -> v for d_k = 16, T <= 64 positions.  qkv: (n*T, ld) rows [q | k | v] of H*16 columns each (the merged
+ *   projection's output, ld >= 3*H*16, ld % 4 == 0); kmask (n, T) bytes, 1 = the key may be attended (NULL = all);
+ *   causal 1 adds j <= i.  out (n*T, H*16), lse (n*H, T) scratch kept for backward; dqkv (n*T, 3*H*16) contiguous.
+ *   Dropout mask: the add & norm hash of (seed word, call_id, ((seq*H + h)*T + i)*T + j), never stored.
+ *
+ * vocab_ce — `Generator.forward` (:106-114, log_softmax(proj(x))) fused with the token cross entropy and arg-max of
+ *   lib/loss_helper/loss_captioning.py:37-71: X (R, 128), W (V, 128), bias (V) -> lse (R), nll (R) = lse - logit[target],
+ *   argmax (R); the (R, V) logits never reach memory.  partials: vlp3d_vocab_ce_partial_bytes(R, V) bytes of scratch.
+ *   bwd: coef (R) = dLoss/d nll; dX (R, 128) (zeroed inside), dW (V, 128), dbias (V); any of the three may be NULL
+ *   (dbias only together with dW).  bf16_mma 1: operands rounded to bf16 (fp32 accumulate, softmax); 0: exact fp32. */
+int vlp3d_cap_attn_fwd(const float *qkv, int ld, const unsigned char *kmask, int n, int T, int H, int causal, float p,
+                       const unsigned long long *seed, int call_id, float *out, float *lse, void *stream);
+int vlp3d_cap_attn_bwd(const float *qkv, int ld, const unsigned char *kmask, int n, int T, int H, int causal, float p,
+                       const unsigned long long *seed, int call_id, const float *out, const float *lse, const float *dout,
+                       float *dqkv, void *stream);
+int vlp3d_vocab_ce_splits(long long R, int V);
+long long vlp3d_vocab_ce_partial_bytes(long long R, int V);
+int vlp3d_vocab_ce_fwd(const float *X, const float *W, const float *bias, const int *target, long long R, int V, int bf16_mma,
+                       void *partials, float *lse, float *nll, int *argmax, void *stream);
+int vlp3d_vocab_ce_bwd(const float *X, const float *W, const float *bias, const int *target, const float *lse,
+                       const float *coef, long long R, int V, int bf16_mma, float *dX, float *dW, float *dbias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

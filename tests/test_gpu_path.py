@@ -291,7 +291,11 @@ def test_sa_module_fused_equals_reference_sequence(training, mode):
 
 
 def test_sa_module_mfma_bf16_close_to_fp32():
-    """bf16 storage + bf16 MFMA variant: reported against the fp32 path with a bf16-sized tolerance."""
+    """bf16 storage + bf16 MFMA variant of one SA module against its fp32 evaluation.  Yardstick (round 3, replaces the flat
+    15 %): the reference's LITERAL op sequence (`fused=False`: group -> 1x1 conv -> BatchNorm2d -> ReLU -> max-pool) under
+    torch.autocast(bfloat16) on the same weights and inputs — output and every gradient of the fused kernels must be within
+    1.5 x that sequence's own error (+ 5e-3)."""
+    import copy
     pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
     synth = importlib.import_module("3dvlp_amd.synth")
     torch.manual_seed(0)
@@ -300,25 +304,40 @@ def test_sa_module_mfma_bf16_close_to_fp32():
     feat = dev(np.stack([s["features"][:, :12].T for s in sc]).copy())
     sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.4, nsample=32, mlp=[12, 64, 64, 128], use_xyz=True,
                                   normalize_xyz=True).cuda().train()
-    f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
-    _, a, _ = sa(xyz, f1)
-    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-        _, b, _ = sa(xyz, f2)
+    lit = copy.deepcopy(sa)
+    lit.fused = False
+    g = None
+
+    def run(mod, amp):
+        nonlocal g
+        f = feat.clone().requires_grad_(True)
+        mod.zero_grad()
+        if amp:
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                _, out, _ = mod(xyz, f)
+        else:
+            _, out, _ = mod(xyz, f)
+        out = out.float()
+        if g is None:
+            g = torch.randn_like(out)
+        (out * g).sum().backward()
+        r = {"out": out.detach(), "dfeat": f.grad.clone()}
+        r.update({n: p.grad.clone() for n, p in mod.named_parameters()})
+        return r
+
     def rel(x, y):
         return ((x - y).norm() / (y.norm() + 1e-20)).item()
 
-    errs = {"out": rel(b.float(), a)}
-    assert errs["out"] < 2e-2, errs
-    g = torch.randn_like(a)
-    (a * g).sum().backward()
-    ga = {n: p.grad.clone() for n, p in sa.named_parameters()}
-    sa.zero_grad()
-    (b * g).sum().backward()
-    for n, p in sa.named_parameters():
-        errs[n] = rel(p.grad, ga[n])
-    errs["dfeat"] = rel(f2.grad, f1.grad)
-    print("bf16 vs fp32 relative (Frobenius) errors:", {k: round(v, 4) for k, v in errs.items()})
-    assert max(errs.values()) < 0.15, errs
+    ref = run(sa, False)
+    fused, literal = run(sa, True), run(lit, True)
+    ef = {k: rel(fused[k], ref[k]) for k in ref}
+    el = {k: rel(literal[k], ref[k]) for k in ref}
+    print("bf16 vs fp32 relative (Frobenius) errors, fused kernels | autocast literal sequence:",
+          {k: (round(ef[k], 4), round(el[k], 4)) for k in ref})
+    assert ef["out"] < 2e-2, ef
+    for k in ref:
+        assert ef[k] <= 1.5 * el[k] + 5e-3, (k, ef[k], el[k])
+
 
 
 def test_relation_bias_fused_forward_backward():
