@@ -44,7 +44,7 @@ class MLP(nn.Module):
         self.linear = nn.Linear(mid_size, out_size)
 
     def forward(self, x):
-        return F.linear(self.fc(x), self.linear.weight, self.linear.bias)  # out_size = glimpses (1): a row dot product
+        return _linear(self.fc(x), self.linear.weight, self.linear.bias)  # out_size = glimpses (1): library GEMV, counted as a fall-back
 
 
 class AttFlat(nn.Module):
@@ -88,5 +88,5 @@ class AnswerModule(nn.Module):
             h = add_norm.act_dropout(h, "gelu", a[2].p, self.training)
         else:
             h = a[2](a[1](h))
-        data_dict["answer_scores"] = F.linear(h, a[3].weight, a[3].bias)
+        data_dict["answer_scores"] = _linear(h, a[3].weight, a[3].bias)  # (B*L, 128) x (num_answers, 128): library GEMM (counted)
         return data_dict

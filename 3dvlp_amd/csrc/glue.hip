@@ -263,6 +263,39 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restri
 
 unsigned blocks_of(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// ---- answer loss (lib/loss_helper/loss_answering.py:11-13): sum of binary_cross_entropy_with_logits(x, t) / rows --------
+// fwd: per-workgroup fp64 partials -> partial[blockIdx.x]; bwd: dx = g * (sigmoid(x) - t) / rows.  The stable form
+// max(x, 0) - x t + log1p(exp(-|x|)) is torch's.
+__global__ __launch_bounds__(256) void bce_logits_fwd_kernel(const float *__restrict__ x, const float *__restrict__ t, long long n,
+                                                             double *__restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float xv = x[i];
+    s += (double)(fmaxf(xv, 0.f) - xv * t[i] + log1pf(__expf(-fabsf(xv))));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void bce_logits_sum_kernel(const double *__restrict__ partial, int nblk, double inv_rows,
+                                                            float *__restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) out[0] = (float)(s * inv_rows);
+}
+__global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float *__restrict__ x, const float *__restrict__ t, long long n,
+                                                             const float *__restrict__ g, float inv_rows, float *__restrict__ dx) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  dx[i] = g[0] * inv_rows * (1.0f / (1.0f + __expf(-xv)) - t[i]);
+}
+
 }  // namespace
 
 extern "C" int vlp3d_roi_split(const float *out, int ld, long long R, int NH, int NC, float res_scale, float *hreg, float *hres,
@@ -613,6 +646,32 @@ extern "C" int vlp3d_rowdot_bwd(const float *dy, const float *x, const float *w,
   if (!dy || !x || !w || !slabs || R < 1 || K < 4 || (K & 3) || K > 128 || rows_per_block < 8) return VLP3D_EINVAL;
   hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((unsigned)((R + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
                      (hipStream_t)stream, dy, x, w, R, K, rows_per_block, dx, slabs);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// sum(binary_cross_entropy_with_logits(x, t)) / rows over (rows, cols) logits / soft targets (loss_answering.py:11-13).
+// partial: (vlp3d_bce_logits_blocks(n)) doubles of scratch; bwd: g = dLoss (1 float on the device).
+extern "C" int vlp3d_bce_logits_blocks(long long n) {
+  const long long b = (n + 2047) / 2048;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+extern "C" int vlp3d_bce_logits_fwd(const float *x, const float *t, long long rows, long long cols, double *partial, float *out,
+                                    void *stream) {
+  if (!x || !t || !partial || !out || rows < 1 || cols < 1) return VLP3D_EINVAL;
+  const int nblk = vlp3d_bce_logits_blocks(rows * cols);
+  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, t, rows * cols, partial);
+  VLP3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_logits_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, 1.0 / (double)rows, out);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+extern "C" int vlp3d_bce_logits_bwd(const float *x, const float *t, long long rows, long long cols, const float *g, float *dx,
+                                    void *stream) {
+  if (!x || !t || !g || !dx || rows < 1 || cols < 1) return VLP3D_EINVAL;
+  const long long n = rows * cols;
+  hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, t, n, g,
+                     1.0f / (float)rows, dx);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -29,7 +29,8 @@ from .grounding import ContrastModule, MatchModule
 
 class GroundingNet(nn.Module):
     def __init__(self, num_class=18, num_heading_bin=1, num_size_cluster=18, mean_size_arr=None,
-                 input_feature_dim=132, num_proposal=256, vote_factor=1, sampling="vote_fps", use_con=True):
+                 input_feature_dim=132, num_proposal=256, vote_factor=1, sampling="vote_fps", use_con=True,
+                 use_answer=False, num_answers=0):
         super().__init__()
         mean_size_arr = synth.mean_size_arr() if mean_size_arr is None else mean_size_arr
         assert mean_size_arr.shape[0] == num_size_cluster
@@ -46,6 +47,10 @@ class GroundingNet(nn.Module):
         if use_con:
             self.constrast = ContrastModule(config=self.dataset_config)
         self.match = MatchModule(num_proposals=num_proposal, lang_size=256, det_channel=128)
+        self.use_answer = use_answer
+        if use_answer:  # the ScanQA head of the joint QA + grounding task (jointnet.py:109-110, 217-218; BASELINE cfg5)
+            from .answer import AnswerModule
+            self.answer = AnswerModule(num_answers=num_answers)
 
     def forward(self, data_dict):
         data_dict = self.backbone_net(data_dict)
@@ -63,6 +68,8 @@ class GroundingNet(nn.Module):
         data_dict = self.match(data_dict)
         if self.use_con:
             data_dict = self.constrast(data_dict)
+        if self.use_answer:
+            data_dict = self.answer(data_dict)
         return data_dict
 
 
@@ -169,10 +176,11 @@ class GroundingStep:
     all-reduce and the optimiser step stay outside the graph."""
 
     def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False,
-                 sa_dtype=None):
+                 sa_dtype=None, use_answer=False, num_answers=0):
         torch.manual_seed(seed)
         self.device = device
-        self.model = GroundingNet().to(device)
+        self.model = GroundingNet(use_answer=use_answer, num_answers=num_answers).to(device)
+        self.loss_args = type("Args", (losses._Args,), {"use_answer": bool(use_answer)})
         self.model.train()
         if torch.device(device).type == "cuda":
             # parameters, gradients and AdamW moments as three flat buffers with one layout: merged projections read their
@@ -222,7 +230,7 @@ class GroundingStep:
                     d = self.model(d)
             else:
                 d = self.model(d)
-        return grounding_loss(d, self.model.dataset_config), d
+        return grounding_loss(d, self.model.dataset_config, self.loss_args), d
 
     @staticmethod
     def _copy_geometry(dst, src):

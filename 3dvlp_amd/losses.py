@@ -18,7 +18,7 @@ Two implementations of the same arithmetic:
 
 Deliberate, documented differences from the reference:
   * the per-(scene, sentence) Python loops with `.cpu()` syncs are batched;
-  * out-of-scope switches (`caption`, `use_reg_head`, `use_kl_loss`, `use_attr_loss`, `use_vote_weight`, `use_answer`,
+  * out-of-scope switches (`caption`, `use_reg_head`, `use_kl_loss`, `use_attr_loss`, `use_vote_weight`,
     `use_mlm`, `orientation`, `distance`) raise NotImplementedError when turned on;
   * the language-classification term reads `lang_scores` of the (out-of-scope) language encoder: it is included when the
     data_dict carries `lang_scores` + `object_cat_list`, else reported as zero.
@@ -294,6 +294,40 @@ def _labels(data_dict, config, device):
             f(d["ref_center_label_list"][..., 0:3]), ref_size, k("lang_num", i32), coin, mean.contiguous())
 
 
+class _BceLogits(torch.autograd.Function):
+    """sum(binary_cross_entropy_with_logits(x, t)) / rows: one reduction launch pair forward, one launch backward
+    (csrc/glue.hip) instead of the op's seven element-wise / reduction launches each way."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = x.contiguous(), t.contiguous().float()
+        rows, cols = x.shape[0], x.numel() // x.shape[0]
+        part = torch.empty((int(_ext.load().vlp3d_bce_logits_blocks(x.numel())),), dtype=torch.float64, device=x.device)
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_bce_logits_fwd", x, t, rows, cols, part, out)
+        ctx.save_for_backward(x, t)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _ext.call("vlp3d_bce_logits_bwd", x, t, x.shape[0], x.numel() // x.shape[0], g.reshape(1).contiguous().float(), dx)
+        return dx, None
+
+
+def compute_answer_classification_loss(data_dict):
+    """lib/loss_helper/loss_answering.py:2-16: soft-score targets -> summed BCE-with-logits per question; class index
+    targets -> cross entropy."""
+    scores = data_dict["answer_scores"]
+    if "answer_cat_scores" in data_dict:
+        if scores.is_cuda and scores.dtype == torch.float32:
+            return _BceLogits.apply(scores, data_dict["answer_cat_scores"])
+        return F.binary_cross_entropy_with_logits(scores, data_dict["answer_cat_scores"].to(scores.dtype),
+                                                  reduction="sum") / scores.shape[0]
+    return F.cross_entropy(scores, data_dict["answer_cat"])
+
+
 class _Args:
     """Defaults of scripts/joint_scripts/train_3dvlp.py:590-770 for the switches get_joint_loss reads, with run.sh:1's
     flags (--use_con --use_diou_loss) on."""
@@ -307,7 +341,7 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
     """loss_joint.py:26-227 (same signature; `impl` is the only addition).  Writes the reference's data_dict keys and
     returns data_dict with data_dict["loss"]."""
     args = _Args if args is None else args
-    for flag in ("use_reg_head", "use_kl_loss", "use_attr_loss", "use_vote_weight", "use_answer", "use_mlm"):
+    for flag in ("use_reg_head", "use_kl_loss", "use_attr_loss", "use_vote_weight", "use_mlm"):
         if getattr(args, flag, False):
             raise NotImplementedError(flag + " is outside the grounding hot path (SURVEY.md §8)")
     if caption or orientation or distance or not detection or not reference:
@@ -370,6 +404,9 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
             loss = loss + d["con_loss"]
     else:
         d["con_loss"] = torch.zeros(1)
+    if getattr(args, "use_answer", False):  # loss_joint.py:118-119, 219-220 (the ScanQA + grounding joint task, cfg5)
+        d["answer_loss"] = compute_answer_classification_loss(d)
+        loss = loss + d["answer_loss"]
     for k in ("cap_loss", "cap_acc", "ori_loss", "ori_acc", "dist_loss", "mlm_loss"):
         d[k] = _const("zero", lambda: torch.zeros(()), dev)
     d["loss"] = loss

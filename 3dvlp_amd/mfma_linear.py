@@ -4,6 +4,7 @@ The projections / FFNs / heads of the grounding path are 2 048..16 384-row by 12
 library runs at ~5 TFLOP/s; here they use the same exact-fp32 MFMA kernels as the grouped MLP.  `linear(x, w, b)`
 has F.linear semantics; shapes the kernels do not cover (rows not a multiple of 32, tiny widths) go to F.linear.
 """
+import collections
 import os
 import torch
 import torch.nn.functional as F
@@ -21,6 +22,15 @@ BATCH_WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BATCH_BLOCKS", 32)) 
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
+
+
+# Library (rocBLAS / hipBLASLt) GEMMs taken for shapes the MFMA kernels do not cover, keyed "R x K -> N".  Nothing falls back
+# silently: bench.py prints the number per step (0 in the cfg2 step), tests assert on it.
+FALLBACKS = collections.Counter()
+
+
+def note_fallback(rows, K, N, where="linear"):
+    FALLBACKS["%s: %d x %d -> %d" % (where, rows, K, N)] += 1
 
 
 def supported(x, weight):
@@ -124,6 +134,8 @@ def linear(x, weight, bias=None, bf16_mma=None, with_residual=False):
     then receives both gradients of x in one place and adds them inside the dX kernel (bf16 configuration)."""
     if supported(x, weight) and not torch.is_autocast_enabled("cuda"):
         return _Linear.apply(x, weight, bias, BF16_MMA if bf16_mma is None else bf16_mma, with_residual)
+    if x.is_cuda:
+        note_fallback(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0])
     if with_residual:
         return F.linear(x, weight, bias), x
     return F.linear(x, weight, bias)

@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import mfma_linear
+
 from . import pointnet2_utils
 from . import row_mlp
 from . import sa_fused
@@ -107,6 +109,8 @@ class PointnetSAModuleVotes(nn.Module):
             if i == 0:
                 w = torch.cat([w[:, 3:], w[:, :3], w.new_zeros(w.shape[0], 1)], dim=1)
             x = F.linear(x, w)
+            if x.is_cuda:
+                mfma_linear.note_fallback(x.shape[0], w.shape[1], w.shape[0], "grouped MLP rows mode")
             bn = layer.bn.bn
             if bn.training and bn.track_running_stats:
                 if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once

@@ -98,8 +98,10 @@ def make_scene(seed, num_points=40000, skip_points=0):
                 sem_cls_label=pad(size_class.astype(np.int64)))
 
 
-def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000):
-    """Batch dict of numpy arrays with the keys the grounding step reads (jointnet.py / loss_joint.py)."""
+def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000, num_answers=0):
+    """Batch dict of numpy arrays with the keys the grounding step reads (jointnet.py / loss_joint.py).  num_answers > 0
+    adds the ScanQA targets of the joint QA + grounding task: `answer_cat_scores` (B*L, num_answers) soft scores (1-3
+    annotated answers per question, VQA-style min(1, 0.3 count)) and `answer_cat` (B*L) the first of them."""
     scenes = [make_scene(seed_base + first_scene + i, num_points) for i in range(batch_size)]
     rng = np.random.default_rng(777 + first_scene)
     pc = np.stack([np.concatenate([s["xyz"], s["features"]], 1) for s in scenes])
@@ -127,4 +129,12 @@ def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_b
         ref_heading_residual_label_list=np.zeros((batch_size, L), np.float32),
     )
     out["lang_emb"] = out["lang_fea"][:, 0].copy()
+    if num_answers:
+        sc = np.zeros((batch_size * L, num_answers), np.float32)
+        first = np.zeros(batch_size * L, np.int64)
+        for q in range(batch_size * L):
+            picks = rng.choice(num_answers, size=int(rng.integers(1, 4)), replace=False)
+            sc[q, picks] = np.minimum(1.0, 0.3 * rng.integers(1, 5, size=len(picks))).astype(np.float32)
+            first[q] = picks[0]
+        out["answer_cat_scores"], out["answer_cat"] = sc, first
     return out

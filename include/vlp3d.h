@@ -568,6 +568,15 @@ int vlp3d_vocab_ce_fwd(const float *X, const float *W, const float *bias, const 
 int vlp3d_vocab_ce_bwd(const float *X, const float *W, const float *bias, const int *target, const float *lse,
                        const float *coef, long long R, int V, int bf16_mma, float *dX, float *dW, float *dbias, void *stream);
 
+/* Answer loss of the joint QA + grounding step (lib/loss_helper/loss_answering.py:11-13):
+ * out[0] = sum(binary_cross_entropy_with_logits(x, t)) / rows for (rows, cols) logits x and soft targets t;
+ * partial: vlp3d_bce_logits_blocks(rows*cols) doubles of scratch.  bwd: dx = g[0] (sigmoid(x) - t) / rows. */
+int vlp3d_bce_logits_blocks(long long n);
+int vlp3d_bce_logits_fwd(const float *x, const float *t, long long rows, long long cols, double *partial, float *out,
+                         void *stream);
+int vlp3d_bce_logits_bwd(const float *x, const float *t, long long rows, long long cols, const float *g, float *dx,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,14 +63,15 @@ def _fp_cpu(fp, unknown, known, unknow_feats, known_feats):
 class CpuStep:
     """The whole step on the CPU.  `net` is a 3dvlp_amd.grounding_step.GroundingNet built on the CPU."""
 
-    def __init__(self, seed=0, lr=1e-3, dtype=torch.float32):
+    def __init__(self, seed=0, lr=1e-3, dtype=torch.float32, use_answer=False, num_answers=0):
         """dtype=torch.float64: the dense layers, the loss and AdamW in double precision (geometry stays the fp32 C
         restatement: indices are defined by fp32 bits) — the yardstick of tests/test_step_parity.py."""
         self.gs = importlib.import_module("3dvlp_amd.grounding_step")
         self.losses = importlib.import_module("3dvlp_amd.losses")
         tr = importlib.import_module("3dvlp_amd.transformer")
         torch.manual_seed(seed)
-        self.net = self.gs.GroundingNet().train().to(dtype)
+        self.net = self.gs.GroundingNet(use_answer=use_answer, num_answers=num_answers).train().to(dtype)
+        self.use_answer = use_answer
         self.dtype = dtype
         for m in self.net.modules():
             if isinstance(m, tr.ScaledDotProductAttention):
@@ -131,7 +132,12 @@ class CpuStep:
         d = prop.decode_scores(prop.proposal(af, d))
         d = net.match(net.relation(d))
         d = net.constrast(d)
-        self.losses.get_joint_loss(None, d, config=net.dataset_config, impl="torch")
+        args = None
+        if self.use_answer:
+            d = net.answer(d)
+            args = type("Args", (self.losses._Args,), {"use_answer": True})
+        self.losses.get_joint_loss(args, d, config=net.dataset_config, impl="torch")
+        self.last = d
         return d["loss"]
 
     def step(self, batch):
@@ -146,7 +152,7 @@ def to_torch(batch_np, scenes, dtype=torch.float32):
     L = batch_np["lang_fea"].shape[0] // batch_np["point_clouds"].shape[0]
     out = {}
     for k, v in batch_np.items():
-        per_sentence = k in ("lang_fea", "lang_emb")
+        per_sentence = k in ("lang_fea", "lang_emb", "answer_cat_scores", "answer_cat")
         t = torch.from_numpy(np.ascontiguousarray(v[:scenes * L] if per_sentence else v[:scenes]))
         out[k] = t.to(dtype) if t.is_floating_point() else t
     out["istrain"] = [1]

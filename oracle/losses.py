@@ -238,3 +238,15 @@ def get_joint_loss(d, config, use_diou_loss=True, use_con=True, use_lang_classif
         loss += out["con_loss"]
     out["loss"] = loss
     return out
+
+
+def answer_classification_loss(answer_scores, answer_cat_scores=None, answer_cat=None):
+    """lib/loss_helper/loss_answering.py:2-16.  Soft scores: sum over (question, answer) of the BCE-with-logits
+    max(x, 0) - x t + log(1 + exp(-|x|)) divided by the number of questions; class indices: mean cross entropy."""
+    x = np.asarray(answer_scores, np.float64)
+    if answer_cat_scores is not None:
+        t = np.asarray(answer_cat_scores, np.float64)
+        return float((np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))).sum() / x.shape[0])
+    m = x.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(x - m).sum(1))
+    return float((lse - x[np.arange(x.shape[0]), np.asarray(answer_cat)]).mean())
