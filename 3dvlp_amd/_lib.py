@@ -103,6 +103,11 @@ SIGNATURES = {
     "vlp3d_probe_read": [_vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],
+    "vlp3d_augment_param_floats": [],
+    "vlp3d_augment_max_instances": [],
+    "vlp3d_augment_points": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "vlp3d_augment_votes": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vlp3d_augment_boxes": [_vp, _i, _i, _vp, _vp, _vp],
     "vlp3d_bce_logits_blocks": [ctypes.c_longlong],
     "vlp3d_bce_logits_fwd": [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
     "vlp3d_bce_logits_bwd": [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],

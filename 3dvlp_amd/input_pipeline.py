@@ -16,6 +16,8 @@ A 40 000-point cfg2 batch is 8 x 40 000 x 135 fp32 = 173 MB: ~3.5 ms of PCIe gen
 import numpy as np
 import torch
 
+from . import synth
+
 
 def sample_scene(point_cloud, num_points, rng, use_height=True, per_point=()):
     """point_cloud (n, C) float array; per_point: label arrays of length n.  Returns (cloud (num_points, C[+1]), labels...)."""
@@ -37,6 +39,7 @@ class Prefetcher:
         self.stream = torch.cuda.Stream(device=self.device)
         self.prepare = prepare
         self._pinned = [{}, {}]  # two sets of staging buffers: the copy of batch t+1 may still read its set while t+2 is staged
+        self._uploaded = [None, None]  # per set: event recorded after its H2D copies; waited for before the set is overwritten
         self._flip = 0
         self.data_dict = None
         self.preload()
@@ -61,10 +64,16 @@ class Prefetcher:
         except StopIteration:
             self.data_dict = None
             return
+        used = self._flip
+        if self._uploaded[used] is not None:
+            self._uploaded[used].synchronize()  # the copies that read this staging set two batches ago have finished
         staged = {k: self._stage(k, v) for k, v in host.items()}
         self._flip ^= 1
         with torch.cuda.stream(self.stream):
             dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in staged.items()}
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._uploaded[used] = ev
             if self.prepare is not None:
                 dev = self.prepare(dev)
         self.data_dict = dev
@@ -79,3 +88,86 @@ class Prefetcher:
                     v.record_stream(torch.cuda.current_stream(self.device))
         self.preload()
         return data_dict
+
+
+# ---- training-time augmentation (lib/joint/dataset.py:653-690, utils/utils_fn.py:28-142) --------------------------------
+def draw_augment_params(rng, batch_size):
+    """The reference's random draws for `batch_size` scenes, in its call order per scene (flip x, flip y, three angles, the
+    3x3 scale draw of which the diagonal is used, three translations): (B, 24) float32 — the layout csrc/augment.hip reads.
+    Host work: 11 numbers and one 3x3 product per scene."""
+    out = np.zeros((batch_size, 24), np.float64)
+    grid = np.arange(-0.5, 0.501, 0.001)
+    for b in range(batch_size):
+        fx, fy = float(rng.random() > 0.7), float(rng.random() > 0.7)
+        ang = [rng.random() * np.pi / 18 - np.pi / 36 for _ in range(3)]
+        sc = np.exp(rng.uniform(-0.1, 0.1, (3, 3)))
+        t = [rng.choice(grid, size=1)[0] for _ in range(3)]
+        (cx, sx), (cy, sy), (cz, sz) = [(np.cos(a), np.sin(a)) for a in ang]
+        rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        out[b, :11] = [fx, fy, *ang, sc[0, 0], sc[1, 1], sc[2, 2], *t]
+        out[b, 12:21] = (rx.T @ ry.T @ rz.T).reshape(-1)
+    return out.astype(np.float32)
+
+
+@torch.no_grad()
+def augment_on_device(batch, params, mean_size_arr=None, height_col=None):
+    """Apply the reference's training-time augmentation to a DEVICE batch in place of the loader workers' numpy code.
+    batch: the reference's keys + `instance_labels` (B,N) int32, `instance_valid` (B,I) uint8, `box_sizes` (B,M,3);
+    params: (B,24) from draw_augment_params (host array or device tensor); height_col: column of point_clouds holding the
+    height channel (negative: from the end; None: no height channel — dataset.py's use_height off).  Rewrites point_clouds (xyz + height column),
+    vote_label, vote_label_mask, center_label, size_residual_label, ref_center_label_list, ref_size_residual_label_list —
+    the votes from the AUGMENTED cloud's per-instance point boxes, the box labels from the augmented GT boxes
+    (dataset.py:653-690).  Three launches over the cloud / boxes + a few label gathers; runs on the caller's stream (the
+    Prefetcher's copy stream)."""
+    from . import _lib as _ext
+    pc = batch["point_clouds"]
+    if not pc.is_cuda:
+        raise RuntimeError("CPU not supported")
+    dev = pc.device
+    B, N, C = pc.shape
+    p = torch.as_tensor(params, dtype=torch.float32, device=dev).contiguous()
+    inst = batch["instance_labels"].to(torch.int32).contiguous()
+    valid = batch["instance_valid"].to(torch.uint8).contiguous()
+    I = valid.shape[1]
+    ibox = torch.empty((B, I, 6), dtype=torch.int32, device=dev)
+    if not pc.is_contiguous():
+        pc = batch["point_clouds"] = pc.contiguous()
+    hcol = -1 if height_col is None else int(height_col) % C
+    _ext.call("vlp3d_augment_points", pc, B, N, C, hcol, p, inst, I, ibox)
+    vote = torch.empty((B, N, 9), dtype=torch.float32, device=dev)
+    vm = batch["vote_label_mask"]
+    mask_i = torch.empty((B, N), dtype=torch.int64, device=dev) if not vm.is_floating_point() else None
+    mask_f = torch.empty((B, N), dtype=torch.float32, device=dev) if vm.is_floating_point() else None
+    _ext.call("vlp3d_augment_votes", pc, B, N, C, inst, I, ibox, valid, vote, mask_f, mask_i)
+    batch["vote_label"], batch["vote_label_mask"] = vote, (mask_f if mask_i is None else mask_i)
+    boxes = torch.cat([batch["center_label"][..., :3].float(), batch["box_sizes"].float()], -1).contiguous()
+    M = boxes.shape[1]
+    out = torch.empty_like(boxes)
+    _ext.call("vlp3d_augment_boxes", boxes, B, M, p, out)
+    mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32, device=dev)
+    present = batch["box_label_mask"].to(torch.float32).unsqueeze(-1)
+    batch["center_label"] = out[..., :3] * present
+    batch["box_sizes"] = out[..., 3:6] * present
+    batch["size_residual_label"] = (out[..., 3:6] - mean[batch["size_class_label"]]) * present
+    tgt = batch["ref_box_label_list"].long().unsqueeze(-1).expand(-1, -1, 6)
+    ref = torch.gather(out, 1, tgt)
+    batch["ref_center_label_list"] = ref[..., :3].contiguous()
+    batch["ref_size_residual_label_list"] = (ref[..., 3:6] - mean[batch["ref_size_class_label_list"]]).contiguous()
+    return batch
+
+
+AUGMENT_ONLY_KEYS = ("instance_labels", "instance_valid", "box_sizes")
+
+
+def augmenting_prepare(rng, prepare=None, mean_size_arr=None, height_col=-1):
+    """-> a `prepare` callable for Prefetcher: draw this batch's parameters (host, reference call order), augment on the
+    device, drop the loader-only arrays the step never reads, then `prepare` (grounding_step.prepare_batch)."""
+    def run(batch):
+        B = batch["point_clouds"].shape[0]
+        batch = augment_on_device(batch, draw_augment_params(rng, B), mean_size_arr, height_col)
+        for k in AUGMENT_ONLY_KEYS:
+            batch.pop(k, None)
+        return prepare(batch) if prepare is not None else batch
+    return run

@@ -90,7 +90,11 @@ def make_scene(seed, num_points=40000, skip_points=0):
     # per-object GT arrays padded to MAX_NUM_OBJ, as lib/joint/dataset.py:826-840 hands them to the losses
     # (ScanNet: axis-aligned boxes, heading class / residual 0; semantic class == size class)
     pad = lambda a: np.concatenate([a, np.zeros((MAX_NUM_OBJ - NUM_BOXES,) + a.shape[1:], a.dtype)], 0)
+    # instance ids per point as the loader sees them (lib/joint/dataset.py:592): boxes 0..11, everything else one
+    # un-annotated instance (id NUM_BOXES) — the augmentation recomputes the votes from these (dataset.py:653-679)
+    instance_labels = np.where(inst >= 0, inst, NUM_BOXES).astype(np.int32)
     return dict(xyz=xyz, features=feats, vote_label=vote_label, vote_label_mask=vote_mask, center_label=center_label,
+                instance_labels=instance_labels,
                 box_label_mask=box_mask, box_centers=centers.astype(np.float32), box_sizes=sizes,
                 size_class=size_class, size_residual=size_residual,
                 heading_class_label=np.zeros(MAX_NUM_OBJ, np.int64), heading_residual_label=np.zeros(MAX_NUM_OBJ, np.float32),
@@ -98,10 +102,12 @@ def make_scene(seed, num_points=40000, skip_points=0):
                 sem_cls_label=pad(size_class.astype(np.int64)))
 
 
-def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000, num_answers=0):
+def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000, num_answers=0, instances=False):
     """Batch dict of numpy arrays with the keys the grounding step reads (jointnet.py / loss_joint.py).  num_answers > 0
     adds the ScanQA targets of the joint QA + grounding task: `answer_cat_scores` (B*L, num_answers) soft scores (1-3
-    annotated answers per question, VQA-style min(1, 0.3 count)) and `answer_cat` (B*L) the first of them."""
+    annotated answers per question, VQA-style min(1, 0.3 count)) and `answer_cat` (B*L) the first of them.
+    instances=True adds what the training-time augmentation needs (input_pipeline.augment_on_device): `instance_labels`
+    (B,N) int32, `instance_valid` (B, NUM_BOXES + 1) uint8 and `box_sizes` (B, MAX_NUM_OBJ, 3)."""
     scenes = [make_scene(seed_base + first_scene + i, num_points) for i in range(batch_size)]
     rng = np.random.default_rng(777 + first_scene)
     pc = np.stack([np.concatenate([s["xyz"], s["features"]], 1) for s in scenes])
@@ -129,6 +135,14 @@ def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_b
         ref_heading_residual_label_list=np.zeros((batch_size, L), np.float32),
     )
     out["lang_emb"] = out["lang_fea"][:, 0].copy()
+    if instances:
+        out["instance_labels"] = np.stack([s["instance_labels"] for s in scenes])
+        valid = np.ones((batch_size, NUM_BOXES + 1), np.uint8)
+        valid[:, NUM_BOXES] = 0
+        out["instance_valid"] = valid
+        sizes = np.zeros((batch_size, MAX_NUM_OBJ, 3), np.float32)
+        sizes[:, :NUM_BOXES] = np.stack([s["box_sizes"] for s in scenes])
+        out["box_sizes"] = sizes
     if num_answers:
         sc = np.zeros((batch_size * L, num_answers), np.float32)
         first = np.zeros(batch_size * L, np.int64)

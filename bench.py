@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--host-batches", action="store_true",
                     help="feed every step a batch that starts in (pinned) HOST memory through input_pipeline.Prefetcher: the "
                          "PCIe-inclusive rate (never the headline `value`; reported in DESIGN.md)")
+    ap.add_argument("--augment", action="store_true",
+                    help="with --host-batches: the reference's training-time augmentation (flip / rotate / scale / translate, "
+                         "votes recomputed after it; lib/joint/dataset.py:653-690) on the device, on the copy stream")
     ap.add_argument("--scenes-per-gpu", type=int, default=B_PER_GPU,
                     help="scenes per GPU and step (default 8 = BASELINE cfg2, the headline; 32 = cfg3's per-GPU batch)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
@@ -286,7 +289,7 @@ def main():
         ip = importlib.import_module("3dvlp_amd.input_pipeline")
         host = []
         for j in range(3):
-            hb = synth.make_batch(first + 8 * j * world, B_PER_GPU, NUM_POINTS, LANG_NUM)
+            hb = synth.make_batch(first + 8 * j * world, B_PER_GPU, NUM_POINTS, LANG_NUM, instances=args.augment)
             host.append({k: torch.from_numpy(v).pin_memory() for k, v in hb.items()})
 
         def endless():
@@ -294,7 +297,11 @@ def main():
             while True:
                 yield host[i % 3]
                 i += 1
-        feed = ip.Prefetcher(endless(), device=device, prepare=gs.prepare_batch)
+        prep = gs.prepare_batch
+        if args.augment:
+            import numpy as np
+            prep = ip.augmenting_prepare(np.random.default_rng(rank), gs.prepare_batch)
+        feed = ip.Prefetcher(endless(), device=device, prepare=prep)
 
     def one_step():
         nonlocal cur_b, nxt_b
@@ -362,7 +369,8 @@ def main():
                        "geometry": "inline" if args.no_pipeline else
                        "backbone FPS/ball-query/three_nn of the next batch on a side stream (executed every step)",
                        "input": ("every step's batch starts in pinned host memory (PCIe-inclusive; 3 batches cycled, "
-                                 "input_pipeline.Prefetcher)" if args.host_batches else "resident in HBM before the timed region"),
+                                 "input_pipeline.Prefetcher" + (", device-side training augmentation" if args.augment else "") + ")"
+                                 if args.host_batches else "resident in HBM before the timed region"),
                        "loss": float(loss.detach())},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
                         "how": "events on the launch stream between consecutive steps (this rank)"},

@@ -577,6 +577,24 @@ int vlp3d_bce_logits_fwd(const float *x, const float *t, long long rows, long lo
 int vlp3d_bce_logits_bwd(const float *x, const float *t, long long rows, long long cols, const float *g, float *dx,
                          void *stream);
 
+/* Training-time scene augmentation on the device (csrc/augment.hip) — lib/joint/dataset.py:653-690 with
+ * utils/utils_fn.py:28-142 (flip_augment, rotate_augment, scale_augment, translate) and
+ * data/scannet/model_util_scannet.py:48-80 (rotate_aligned_boxes_along_axis); votes recomputed AFTER augmentation.
+ * params: (B, vlp3d_augment_param_floats()) device floats per scene: flipx, flipy, ax, ay, az, sx, sy, sz, tx, ty, tz, 0,
+ * M[9] = rotx(ax)^T roty(ay)^T rotz(az)^T row-major, 0, 0, 0 (host-drawn, reference call order).
+ * augment_points: pc (B,N,C) in place (xyz; column height_col *= sz when >= 0); with inst (B,N) int32 ids in [0, I),
+ *   I <= vlp3d_augment_max_instances(), also the per-instance point bounding boxes into ibox (B,I,6) int32 (ordered keys).
+ * augment_votes: vote (B,N,9) = 3 copies of 0.5 (min + max) of the point's instance - x where valid[b][id], else 0;
+ *   mask_f (B,N) float and / or mask_i (B,N) int64 (either may be NULL).
+ * augment_boxes: boxes (B,M,6) [centre | lengths] -> out (B,M,6). */
+int vlp3d_augment_param_floats(void);
+int vlp3d_augment_max_instances(void);
+int vlp3d_augment_points(float *pc, int B, int N, int C, int height_col, const float *params, const int *inst, int I, int *ibox,
+                         void *stream);
+int vlp3d_augment_votes(const float *pc, int B, int N, int C, const int *inst, int I, const int *ibox, const unsigned char *valid,
+                        float *vote, float *mask_f, long long *mask_i, void *stream);
+int vlp3d_augment_boxes(const float *boxes, int B, int M, const float *params, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  The reference's training-time scene augmentation, restated in numpy.
+
+Follows, statement by statement (fp64 like numpy's defaults there):
+  flip_augment / rotate_augment / scale_augment / translate   utils/utils_fn.py:28-142
+  rotate_aligned_boxes_along_axis                             data/scannet/model_util_scannet.py:48-80
+  rotx / roty / rotz                                          utils/pc_utils.py:285-299 (+ rotz)
+  votes computed AFTER augmentation from the instance labels  lib/joint/dataset.py:653-679
+  box-derived labels (centre, size residual, referred box)    lib/joint/dataset.py:681-690 (+ the ref_* lists built from
+                                                              the same augmented boxes further down)
+The reference draws its random numbers inside these functions; here the draws are made first, in the reference's call
+order (`draw_params`), and handed to both this restatement and the device kernels.  PARITY UNPINNED for the composition
+(the dataset class needs the ScanNet files); utils_fn.py itself imports data.scannet.model_util_scannet (easydict): an
+ordinary ImportError in this image.
+"""
+import numpy as np
+
+PARAM_FLOATS = 24  # per scene: flipx, flipy, ax, ay, az, sx, sy, sz, tx, ty, tz, 0, M (9, row-major), 0, 0, 0
+
+
+def rotx(t):
+    c, s = np.cos(t), np.sin(t)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def roty(t):
+    c, s = np.cos(t), np.sin(t)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def rotz(t):
+    c, s = np.cos(t), np.sin(t)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def draw_params(rng):
+    """The random draws of flip_augment (:30, :35), rotate_augment (:83, :89, :95), scale_augment (:114) and translate
+    (:134-136), in that order, as one vector (layout: PARAM_FLOATS)."""
+    fx = float(rng.random() > 0.7)
+    fy = float(rng.random() > 0.7)
+    ax = rng.random() * np.pi / 18 - np.pi / 36
+    ay = rng.random() * np.pi / 18 - np.pi / 36
+    az = rng.random() * np.pi / 18 - np.pi / 36
+    scale = np.exp(rng.uniform(-0.1, 0.1, (3, 3)))
+    grid = np.arange(-0.5, 0.501, 0.001)
+    t = [rng.choice(grid, size=1)[0] for _ in range(3)]
+    M = np.dot(np.dot(np.transpose(rotx(ax)), np.transpose(roty(ay))), np.transpose(rotz(az)))  # utils_fn.py:101-102
+    p = np.zeros(PARAM_FLOATS, np.float64)
+    p[:11] = [fx, fy, ax, ay, az, scale[0, 0], scale[1, 1], scale[2, 2], t[0], t[1], t[2]]
+    p[12:21] = M.reshape(-1)
+    return p
+
+
+def identity_params():
+    p = np.zeros(PARAM_FLOATS, np.float64)
+    p[5:8] = 1.0
+    p[12:21] = np.eye(3).reshape(-1)
+    return p
+
+
+def rotate_aligned_boxes_along_axis(input_boxes, rot_mat, axis):
+    """model_util_scannet.py:48-80."""
+    centers, lengths = input_boxes[:, 0:3], input_boxes[:, 3:6]
+    new_centers = np.dot(centers, np.transpose(rot_mat))
+    if axis == "x":
+        d1, d2 = lengths[:, 1] / 2.0, lengths[:, 2] / 2.0
+    elif axis == "y":
+        d1, d2 = lengths[:, 0] / 2.0, lengths[:, 2] / 2.0
+    else:
+        d1, d2 = lengths[:, 0] / 2.0, lengths[:, 1] / 2.0
+    new_1 = np.zeros((d1.shape[0], 4))
+    new_2 = np.zeros((d1.shape[0], 4))
+    for i, crnr in enumerate([(-1, -1), (1, -1), (1, 1), (-1, 1)]):
+        crnrs = np.zeros((d1.shape[0], 3))
+        crnrs[:, 0] = crnr[0] * d1
+        crnrs[:, 1] = crnr[1] * d2
+        crnrs = np.dot(crnrs, np.transpose(rot_mat))
+        new_1[:, i] = crnrs[:, 0]
+        new_2[:, i] = crnrs[:, 1]
+    new_d1 = 2.0 * np.max(new_1, 1)
+    new_d2 = 2.0 * np.max(new_2, 1)
+    if axis == "x":
+        new_lengths = np.stack((lengths[:, 0], new_d1, new_d2), axis=1)
+    elif axis == "y":
+        new_lengths = np.stack((new_d1, lengths[:, 1], new_d2), axis=1)
+    else:
+        new_lengths = np.stack((new_d1, new_d2, lengths[:, 2]), axis=1)
+    return np.concatenate([new_centers, new_lengths], axis=1)
+
+
+def augment_scene(point_cloud, target_bboxes, params, height_col=None):
+    """flip -> rotate -> scale (+ height) -> translate on one scene.  point_cloud (n, C), target_bboxes (M, 6) -> copies."""
+    pc = np.array(point_cloud, np.float64)
+    bb = np.array(target_bboxes, np.float64)
+    fx, fy, ax, ay, az, sx, sy, sz, tx, ty, tz = params[:11]
+    if fx:  # utils_fn.py:30-33
+        pc[:, 0] = -1 * pc[:, 0]
+        bb[:, 0] = -1 * bb[:, 0]
+    if fy:  # :35-38
+        pc[:, 1] = -1 * pc[:, 1]
+        bb[:, 1] = -1 * bb[:, 1]
+    rx, ry, rz = rotx(ax), roty(ay), rotz(az)  # :83-104
+    bb = rotate_aligned_boxes_along_axis(bb, rx, "x")
+    bb = rotate_aligned_boxes_along_axis(bb, ry, "y")
+    bb = rotate_aligned_boxes_along_axis(bb, rz, "z")
+    rot = np.dot(np.dot(np.transpose(rx), np.transpose(ry)), np.transpose(rz))
+    pc[:, 0:3] = np.dot(pc[:, 0:3], rot)
+    scale = np.diag([sx, sy, sz])  # :114-122
+    pc[:, 0:3] = np.dot(pc[:, 0:3], scale)
+    if height_col is not None:
+        pc[:, height_col] = pc[:, height_col] * float(scale[2, 2])
+    bb[:, 0:3] = np.dot(bb[:, 0:3], scale)
+    bb[:, 3:6] = np.dot(bb[:, 3:6], scale)
+    pc[:, :3] += [tx, ty, tz]  # :126-141
+    bb[:, :3] += [tx, ty, tz]
+    return pc, bb
+
+
+def votes_after_augmentation(xyz, instance_labels, instance_valid):
+    """dataset.py:653-679: every point of an annotated instance votes for the centre of the instance's POINT bounding box
+    (0.5 (min + max) over its points in the augmented cloud), three identical copies.  instance_valid[i]: the reference's
+    `semantic_labels[ind[0]] in DC.nyu40ids` test for instance i."""
+    n = xyz.shape[0]
+    point_votes = np.zeros([n, 3])
+    point_votes_mask = np.zeros(n)
+    for i_instance in np.unique(instance_labels):
+        ind = np.where(instance_labels == i_instance)[0]
+        if instance_valid[int(i_instance)]:
+            x = xyz[ind, :3]
+            center = 0.5 * (x.min(0) + x.max(0))
+            point_votes[ind, :] = center - x
+            point_votes_mask[ind] = 1.0
+    return np.tile(point_votes, (1, 3)), point_votes_mask
+
+
+def augment_batch(batch, params, mean_size_arr, height_col):
+    """The whole loader-side effect on a batch dict of numpy arrays (keys of 3dvlp_amd.synth.make_batch + `instance_labels`
+    (B,N), `instance_valid` (B,I), `box_sizes` (B,M,3), `box_classes` (B,M)): returns the updated copies of
+    point_clouds, vote_label, vote_label_mask, center_label, size_residual_label, ref_center_label_list,
+    ref_size_residual_label_list."""
+    B = batch["point_clouds"].shape[0]
+    out = {k: np.array(batch[k]) for k in ("point_clouds", "vote_label", "vote_label_mask", "center_label",
+                                            "size_residual_label", "ref_center_label_list", "ref_size_residual_label_list")}
+    for b in range(B):
+        boxes = np.concatenate([batch["center_label"][b], batch["box_sizes"][b]], 1)
+        pc, bb = augment_scene(batch["point_clouds"][b], boxes, params[b], height_col)
+        votes, mask = votes_after_augmentation(pc[:, :3], batch["instance_labels"][b], batch["instance_valid"][b])
+        out["point_clouds"][b] = pc
+        out["vote_label"][b], out["vote_label_mask"][b] = votes, mask
+        nb = int(batch["box_label_mask"][b].sum())
+        out["center_label"][b] = 0
+        out["center_label"][b, :nb] = bb[:nb, :3]
+        cls = batch["size_class_label"][b, :nb]
+        out["size_residual_label"][b] = 0
+        out["size_residual_label"][b, :nb] = bb[:nb, 3:6] - mean_size_arr[cls]          # dataset.py:688-689
+        tgt = batch["ref_box_label_list"][b]
+        out["ref_center_label_list"][b] = bb[tgt, :3]
+        out["ref_size_residual_label_list"][b] = bb[tgt, 3:6] - mean_size_arr[batch["ref_size_class_label_list"][b]]
+    return out

@@ -41,3 +41,85 @@ def test_prefetcher_uploads_in_order_and_prepares_on_copy_stream():
         assert torch.equal(d["k/lang_kv"], d["lang_fea"][:, 1:])
         seen.append(d)
     assert pf.next() is None
+
+
+# ---- training-time augmentation (lib/joint/dataset.py:653-690, utils/utils_fn.py:28-142) -------------
+def test_augment_oracle_invariants():
+    """The numpy restatement: identity parameters change nothing except that votes point to the instance's POINT box
+    centre (dataset.py:676-679); a pure flip / translation moves points, boxes and votes consistently; the rotated
+    aligned box follows model_util_scannet.py's enclosing-box rule (lengths never shrink below the projection)."""
+    from oracle import augment as oa
+    synth = importlib.import_module("3dvlp_amd.synth")
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    b = synth.make_batch(0, 2, 4096, 2, instances=True)
+    mean = synth.mean_size_arr()
+    ident = np.stack([oa.identity_params()] * 2)
+    o = oa.augment_batch(b, ident, mean, -1)
+    assert np.array_equal(o["point_clouds"], b["point_clouds"]) and np.allclose(o["center_label"], b["center_label"])
+    assert np.allclose(o["size_residual_label"], b["size_residual_label"], atol=1e-6)
+    assert (o["vote_label_mask"] == b["vote_label_mask"]).all()
+    x = b["point_clouds"][0, :, :3]
+    for i in range(synth.NUM_BOXES):
+        ind = b["instance_labels"][0] == i
+        c = 0.5 * (x[ind].min(0) + x[ind].max(0))
+        assert np.allclose(o["vote_label"][0][ind][:, :3], c - x[ind], atol=1e-6)
+        assert np.allclose(o["vote_label"][0][ind][:, 3:6], o["vote_label"][0][ind][:, :3])
+    p = ident.copy()
+    p[:, 0] = 1.0            # flip x
+    p[:, 8:11] = [0.25, -0.1, 0.05]
+    f = oa.augment_batch(b, p, mean, -1)
+    assert np.allclose(f["point_clouds"][..., 0], -b["point_clouds"][..., 0] + 0.25, atol=1e-6)
+    assert np.allclose(f["center_label"][:, :12, 0], -b["center_label"][:, :12, 0] + 0.25, atol=1e-6)
+    assert np.allclose(f["vote_label"][..., 0], -o["vote_label"][..., 0], atol=1e-5)       # votes are translation invariant
+    assert np.allclose(f["ref_center_label_list"][..., 1], b["ref_center_label_list"][..., 1] - 0.1, atol=1e-6)
+    # the host-side draw of the product is the oracle's draw, call for call
+    assert np.allclose(ip.draw_augment_params(np.random.default_rng(3), 1)[0], oa.draw_params(np.random.default_rng(3)), atol=1e-7)
+    box = np.array([[1.0, 2.0, 0.5, 2.0, 1.0, 0.6]])
+    r = oa.rotate_aligned_boxes_along_axis(box, oa.rotz(0.3), "z")
+    assert r[0, 3] >= 2.0 * np.cos(0.3) - 1e-9 and r[0, 5] == 0.6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [4096, 40000])
+def test_augment_on_device_equals_oracle(N):
+    """csrc/augment.hip (points + per-instance point boxes, votes, GT boxes) and the label derivation of
+    input_pipeline.augment_on_device against the numpy restatement of the reference's loader code, drawn parameters shared."""
+    from oracle import augment as oa
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    B = 3
+    host = synth.make_batch(4, B, N, 4, instances=True)
+    params = ip.draw_augment_params(np.random.default_rng(11), B)
+    params[0, 0], params[1, 1], params[2, :2] = 1.0, 1.0, 0.0     # every flip branch taken at least once
+    want = oa.augment_batch(host, params.astype(np.float64), synth.mean_size_arr(), -1)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    got = ip.augment_on_device(dev, params, height_col=-1)
+    for k, tol in (("point_clouds", 2e-6), ("center_label", 2e-6), ("size_residual_label", 5e-6), ("ref_center_label_list", 2e-6),
+                   ("ref_size_residual_label_list", 5e-6), ("vote_label", 5e-6)):
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=0, atol=tol * 10, err_msg=k)
+    assert got["vote_label_mask"].dtype == dev["vote_label_mask"].dtype   # int64 like the loader's array
+    assert np.array_equal(got["vote_label_mask"].cpu().numpy(), want["vote_label_mask"])
+    assert np.abs(got["point_clouds"].cpu().numpy()[..., :3] - host["point_clouds"][..., :3]).max() > 0.05  # it did something
+
+
+@pytest.mark.gpu
+def test_prefetcher_with_augmentation_feeds_the_step():
+    """prepare = augmentation + prepare_batch on the copy stream; the step trains on the augmented batches (finite loss,
+    the loader-split cloud is the AUGMENTED one)."""
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    rng = np.random.default_rng(0)
+    host = [synth.make_batch(2 * i, 2, 8192, 2, instances=True) for i in range(3)]
+
+    def prepare(d):
+        return gs.prepare_batch(ip.augment_on_device(d, ip.draw_augment_params(rng, 2), height_col=-1))
+
+    pf = ip.Prefetcher(iter(host), device="cuda", prepare=prepare)
+    step = gs.GroundingStep(torch.device("cuda:0"), sa_dtype=torch.bfloat16)
+    for i in range(3):
+        d = pf.next()
+        assert torch.equal(d["k/xyz"], d["point_clouds"][..., :3])
+        assert not np.allclose(d["point_clouds"][..., :3].cpu().numpy(), host[i]["point_clouds"][..., :3], atol=1e-3)
+        loss = step.run(d)
+        assert torch.isfinite(loss)
