@@ -165,14 +165,23 @@ class FlatGradBucket:
             torch._foreach_copy_(dst, src)
 
     def all_reduce(self):
-        """Sum over ranks then average. No-op without an initialised process group."""
+        """Average over ranks with ONE collective on the flat buffer.  RCCL (backend "nccl"): ReduceOp.AVG — the division
+        rides inside the all-reduce, no second launch; gloo (CPU rehearsals) has no AVG: SUM, then one in-place division.
+        No-op without an initialised process group."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(dist.get_world_size(self.group))
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.div_(dist.get_world_size(self.group))
 
 
 class FlatAdamW:
-    """torch.optim.AdamW over (FlatParams, FlatGradBucket with the same layout) in one launch (csrc/glue.hip)."""
+    """torch.optim.AdamW over (FlatParams, FlatGradBucket with the same layout), one launch per run of parameters that share
+    a step count (csrc/glue.hip) — ONE launch in the steady state.  Like torch.optim.AdamW the step count that enters the
+    bias correction is PER PARAMETER and starts when the parameter first receives a gradient (a parameter that becomes
+    active later — the contrast projections at epoch 50, a restart with a different touched set — gets its own count, and
+    the launch splits at the boundaries).  `state_dict()` / `load_state_dict()` carry m, v and the step counts."""
 
     def __init__(self, layout, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         assert bucket.flat.numel() == layout.flat.numel()
@@ -182,7 +191,13 @@ class FlatAdamW:
         self.v = torch.zeros_like(layout.flat)
         self.active = torch.zeros(layout.numel, dtype=torch.uint8, device=layout.flat.device)
         self._active_key = None
-        self.t = 0
+        self.steps = [0] * len(layout.params)   # per parameter, like torch.optim's state[p]["step"]
+        self._runs = None
+
+    @property
+    def t(self):
+        """Largest step count (the only one in the steady state)."""
+        return max(self.steps) if self.steps else 0
 
     def _set_active(self):
         key = tuple(self.bucket.touched)
@@ -193,23 +208,84 @@ class FlatAdamW:
                     a[o:o + p.numel()] = 1
             self.active.copy_(a)
             self._active_key = key
+            self._runs = None
+
+    def _step_runs(self):
+        """[(start, end, index of one touched parameter of the run)] over the flat buffer: maximal runs of consecutive
+        touched parameters with one step count (untouched parameters are masked by `active` and join a neighbouring run).
+        All touched parameters advance together, so the partition only changes with the touched set."""
+        runs = []
+        for i, (p, o, got) in enumerate(zip(self.layout.params, self.layout.offsets, self.bucket.touched)):
+            if not got:
+                continue
+            if runs and self.steps[runs[-1][2]] == self.steps[i]:
+                runs[-1][1] = o + p.numel()
+            else:
+                runs.append([o, o + p.numel(), i])
+        if runs:
+            runs[0][0] = 0
+            runs[-1][1] = self.layout.numel
+            for a, b in zip(runs, runs[1:]):
+                a[1] = b[0]
+        return runs
 
     def step(self):
         from . import _lib as _ext
         self._set_active()
-        self.t += 1
+        if self._runs is None:
+            self._runs = self._step_runs()
+        for i, got in enumerate(self.bucket.touched):
+            if got:
+                self.steps[i] += 1
         b1, b2 = self.betas
-        _ext.call("vlp3d_adamw_flat", self.layout.flat, self.bucket.flat, self.m, self.v, self.active, self.layout.numel,
-                  float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay), 1.0 - b1 ** self.t,
-                  math.sqrt(1.0 - b2 ** self.t))
+        L, G = self.layout.flat, self.bucket.flat
+        for a, b, i in self._runs:
+            t = self.steps[i]
+            _ext.call("vlp3d_adamw_flat", L[a:b], G[a:b], self.m[a:b], self.v[a:b], self.active[a:b], b - a,
+                      float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay), 1.0 - b1 ** t,
+                      math.sqrt(1.0 - b2 ** t))
+
+    def state_dict(self):
+        return {"m": self.m.clone(), "v": self.v.clone(), "steps": list(self.steps), "lr": self.lr, "betas": self.betas,
+                "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.steps = list(sd["steps"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        self._runs = None
 
 
-def broadcast_parameters(module, src=0, process_group=None):
-    """One-time parameter + buffer broadcast from rank `src` so that all replicas start identical."""
+def _flat_broadcast(tensors, src, group):
+    """One broadcast for a list of same-dtype tensors: pack, broadcast, unpack."""
+    if not tensors:
+        return
+    flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+def broadcast_parameters(module, src=0, process_group=None, layout=None):
+    """One-time parameter + buffer broadcast from rank `src` so that all replicas start identical: ONE collective for the
+    parameters (the FlatParams buffer itself when `layout` is given — every parameter is a view of it — else a packed copy)
+    and one per buffer dtype (BatchNorm statistics, counters) instead of one per tensor (~300 at this model)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
+    if layout is not None:
+        dist.broadcast(layout.flat, src=src, group=process_group)
+        rest = [p for p in module.parameters() if not p.requires_grad]  # (not re-homed by FlatParams)
+    else:
+        rest = list(module.parameters())
+    by_dtype = {}
+    for t in rest + list(module.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for ts in by_dtype.values():
+        _flat_broadcast(ts, src, process_group)
 
 
 def shard_range(num_scenes, rank, world_size):

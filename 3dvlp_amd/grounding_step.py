@@ -214,6 +214,7 @@ class GroundingStep:
         self._geom_for = None      # graph pipeline: the batch _geom_next was prepared for
         self._static_tag = self._next_src_tag = None  # sources the static graph buffers were last filled from
         self._graph = None
+        self._regime = None        # epoch < 50 at capture: the loss configuration the captured graph holds
         self._static_batch = self._static_next = None
         self._static_loss = None
         self._last_out = self._static_out = None
@@ -291,9 +292,15 @@ class GroundingStep:
             torch.cuda.current_stream().wait_stream(self._side)  # join
         return loss.detach()
 
-    @staticmethod
-    def _backward(loss):
-        """backward with every weight-gradient slab sum of the pass deferred into one launch (51 -> 2 at cfg2)."""
+    def _backward(self, loss):
+        """backward with every weight-gradient slab sum of the pass deferred into one launch (51 -> 2 at cfg2).
+        The deferred queue hands autograd VIEWS of buffers that are filled at the flush: that is only sound while
+        AccumulateGrad steals the view, i.e. while the parameter has no gradient yet — checked here."""
+        stale = [n for n, p in self.model.named_parameters() if p.grad is not None]
+        if stale:
+            raise RuntimeError("GroundingStep._backward: parameters still hold a gradient (%s, ...): call bucket.zero() first — "
+                               "accumulating into an existing .grad would read the deferred buffers before they are filled"
+                               % stale[0])
         with _ext.deferred_slab_reduce():
             loss.backward()
 
@@ -390,7 +397,13 @@ class GroundingStep:
 
     def run(self, batch, next_batch=None):
         if self.use_graph:
+            if self._graph is not None and (self.epoch < 50) != self._regime:
+                # the loss configuration baked into the captured graph (reference-loss weight 0.3 / 1.0, label smoothing below
+                # epoch 50, OCC / OSC from epoch 50 on; loss_joint.py:208, loss_grounding.py) no longer matches: recapture
+                self._graph = self._gC = self._gS = self._gM = None
+                self._static_out = None
             if self._graph is None:
+                self._regime = self.epoch < 50
                 self._capture(batch, next_batch)
             else:
                 # static buffers are refilled whenever the caller's batch is not the one they currently hold

