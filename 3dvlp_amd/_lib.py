@@ -103,6 +103,8 @@ SIGNATURES = {
     "vlp3d_probe_read": [_vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],
+    "vlp3d_stamp": [_vp, _vp],
+    "vlp3d_probe_empty": [_i, _i, _vp, _vp],
     "vlp3d_augment_param_floats": [],
     "vlp3d_augment_max_instances": [],
     "vlp3d_augment_points": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -685,3 +687,70 @@ def call(name, *args):
     Tensors are passed as pointers, None as NULL; ints/floats as they are."""
     conv = [(_opt(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
     _check(getattr(load(), name)(*conv, _stream()), name)
+
+
+# ---- in-step kernel timing (bench.py: roofline.ms) ---------------------------------------------------------------------
+class Stamps:
+    """While active, every call of one of the named C entry points is bracketed by two one-thread stamp kernels
+    (csrc/hwprobe.hip) writing the 100 MHz device clock into consecutive slots of a device buffer — also when the calls
+    are being captured into a HIP graph: replaying the graph then refreshes the slots, and `durations()` gives each
+    stamped launch's duration INSIDE the step (its neighbours running, caches in their in-step state), not in isolation.
+    A bracket reads  gap + duration + gap  (stamp -> kernel -> stamp); `back_to_back()` records one gap (two stamps with
+    nothing between), so duration = bracket - 2 x gap.  Used on an instrumented copy of the step after bench.py's timed
+    region; tools/stamp_vs_rocprof.py compares the result with rocprofv3's per-dispatch durations."""
+
+    TICK_US = 0.01
+
+    def __init__(self, names, device, capacity=512):
+        self.names = set(names)
+        self.buf = torch.zeros((capacity,), dtype=torch.int64, device=device)
+        self.log = []          # slot pair k -> (entry point, positional-argument summary)
+        self._saved = {}
+        self.calibrate_pending = False   # set True (e.g. at capture begin): the next call of `calibrate_on` is preceded by the calibration pairs
+        self.calibrate_on = "vlp3d_sa_fwd_gather"   # first stamped kernel of the main-stream graph
+
+    def __enter__(self):
+        lib = load()
+        for name in self.names:
+            fn = getattr(lib, name)
+            self._saved[name] = fn
+
+            def wrapped(*args, _fn=fn, _name=name):
+                if self.calibrate_pending and _name == self.calibrate_on:
+                    # the calibration pairs go in front of the first stamped call, on ITS stream (so that they are captured
+                    # into the same graph): one bare gap, and a bracketed empty kernel
+                    self.calibrate_pending = False
+                    self.back_to_back(args[-1])
+                    getattr(lib, "vlp3d_probe_empty")(1, 64, ctypes.c_void_p(0), args[-1])
+                k = len(self.log)
+                if 2 * k + 1 >= self.buf.numel():
+                    return _fn(*args)
+                stream = args[-1]
+                self.log.append((_name, tuple(a for a in args if isinstance(a, (int, float)))))
+                lib.vlp3d_stamp(ctypes.c_void_p(self.buf.data_ptr() + 16 * k), stream)
+                rc = _fn(*args)
+                lib.vlp3d_stamp(ctypes.c_void_p(self.buf.data_ptr() + 16 * k + 8), stream)
+                return rc
+            setattr(lib, name, wrapped)
+        return self
+
+    def back_to_back(self, stream=None):
+        """Two stamps with nothing between them (slot pair logged as "stamp_gap"): one dispatch gap + the stamp kernel."""
+        lib = load()
+        stream = _stream() if stream is None else stream
+        k = len(self.log)
+        self.log.append(("stamp_gap", ()))
+        lib.vlp3d_stamp(ctypes.c_void_p(self.buf.data_ptr() + 16 * k), stream)
+        lib.vlp3d_stamp(ctypes.c_void_p(self.buf.data_ptr() + 16 * k + 8), stream)
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, fn in self._saved.items():
+            setattr(lib, name, fn)
+        self._saved = {}
+        return False
+
+    def durations(self):
+        """[(entry point, int/float args, microseconds)] for every stamped launch, from the slots' current contents."""
+        t = self.buf.cpu().tolist()
+        return [(n, a, (t[2 * k + 1] - t[2 * k]) * self.TICK_US) for k, (n, a) in enumerate(self.log)]

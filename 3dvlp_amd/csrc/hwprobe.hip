@@ -78,3 +78,30 @@ extern "C" int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *str
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
+
+
+// ---- in-step timing and the launch floor --------------------------------------------------------------------------------
+// vlp3d_stamp: ONE thread writes the constant-rate (100 MHz) device clock to *slot.  Captured into the step's graph right
+// before and right after a kernel, the difference of the two slots is that kernel's duration INSIDE the replayed step
+// (plus one dispatch gap, which the same pair around vlp3d_probe_empty calibrates) — bench.py's `roofline.ms`.
+// vlp3d_probe_empty: a kernel that does nothing, on an arbitrary grid: a chain of them in a graph is the launch floor.
+namespace {
+__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+__global__ void empty_kernel(int *sink) {
+  if (sink && blockIdx.x == 0x7fffffff) *sink = 0;
+}
+}  // namespace
+
+extern "C" int vlp3d_stamp(unsigned long long *slot, void *stream) {
+  if (!slot) return -22;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vlp3d_probe_empty(int blocks, int threads, int *sink, void *stream) {
+  if (blocks < 1 || threads < 1 || threads > 1024) return -22;
+  hipLaunchKernelGGL(empty_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, sink);
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}

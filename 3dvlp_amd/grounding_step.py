@@ -176,7 +176,7 @@ class GroundingStep:
     all-reduce and the optimiser step stay outside the graph."""
 
     def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False,
-                 sa_dtype=None, use_answer=False, num_answers=0):
+                 sa_dtype=None, use_answer=False, num_answers=0, side_stream=None):
         torch.manual_seed(seed)
         self.device = device
         self.model = GroundingNet(use_answer=use_answer, num_answers=num_answers).to(device)
@@ -208,13 +208,16 @@ class GroundingStep:
         # geometry pipeline: the backbone's coordinate-only stage (FPS / ball query / three_nn) of the NEXT batch
         # runs on a side stream while the dense layers of the current batch run (one workgroup per scene = 8 CUs)
         self.pipeline = pipeline
-        self._side = torch.cuda.Stream(device=device) if pipeline else None
+        # (side_stream: reuse another step's stream — every new HIP stream takes one of the few hardware queues, and a side
+        # stream that lands on the main stream's queue serialises the two: a THIRD step object in one process ran 9.8 ms)
+        self._side = (side_stream or torch.cuda.Stream(device=device)) if pipeline else None
         self._geom_cur = self._geom_next = None
         self._geom_tag = None      # eager pipeline: the batch _geom_next was prepared for
         self._geom_for = None      # graph pipeline: the batch _geom_next was prepared for
         self._static_tag = self._next_src_tag = None  # sources the static graph buffers were last filled from
         self._graph = None
         self._regime = None        # epoch < 50 at capture: the loss configuration the captured graph holds
+        self.on_capture = None     # optional callable run right before the graphs are captured (after the warm-up passes)
         self._static_batch = self._static_next = None
         self._static_loss = None
         self._last_out = self._static_out = None
@@ -332,6 +335,8 @@ class GroundingStep:
                 self._fwd_bwd(self._static_batch, self._static_next)
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
+        if self.on_capture is not None:   # instrumentation hook (bench.py: reset the in-step stamp log / fall-back counters)
+            self.on_capture()
         if not self.pipeline:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):

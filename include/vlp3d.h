@@ -506,6 +506,10 @@ int vlp3d_adamw_flat(float *p, const float *g, float *m, float *v, const unsigne
 int vlp3d_probe_read(const void *buf, long long bytes, int blocks, float *sink, void *stream);
 int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
+/* vlp3d_stamp: one thread writes the 100 MHz device clock to *slot (in-stream time stamps bracketing a kernel inside a
+ * captured step); vlp3d_probe_empty: a kernel that does nothing on a (blocks, threads) grid — the launch floor. */
+int vlp3d_stamp(unsigned long long *slot, void *stream);
+int vlp3d_probe_empty(int blocks, int threads, int *sink, void *stream);
 
 /* data_dict's reporting tensors from vlp3d_joint_loss_fwd's compact outputs, in the reference's dtypes: object_assignment
  * i64 (B,K), objectness_label i64 (B,K), objectness_mask f32 (B,K) (loss_detection.py:101-108), cluster_labels f32 (B,L,K)

@@ -199,6 +199,7 @@ def cpu_baseline(batch_np, scenes=1):
         pass
     return {"value": round(scenes / t_all, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
             "single_thread_value": round(scenes / t_one, 4), "cpu_model": model,
-            "sample": f"{scenes} scene(s) of the same workload (40k pts, 256 proposals, 8 sentences), ONE full training "
-                      f"step each (fwd + reference loss + bwd + AdamW): C/OpenMP geometry + PyTorch-CPU autograd; "
+            "sample": f"{scenes} scene(s) of the same workload (40k pts, 256 proposals, 8 sentences) as ONE B = {scenes} training "
+                      f"step (fwd + reference loss + bwd + AdamW; BatchNorm statistics over that one scene — not the B = 8 step "
+                      f"of the GPU line, whose per-scene cost it approximates): C/OpenMP geometry + PyTorch-CPU autograd; "
                       f"{t_all:.2f} s on {cores} threads, {t_one:.2f} s on 1 thread"}

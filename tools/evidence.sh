@@ -1,5 +1,5 @@
 # Round evidence: PMC traffic of the roofline kernels, bench JSON lines, rocprofv3 kernel stats + one steady-state step.
-# Usage (on the GPU box): bash tools/evidence.sh r02_e
+# Usage (on the GPU box): bash tools/evidence.sh r03_a
 set -e
 tag=$1
 cd $GRAFT_REPO_ROOT
@@ -13,7 +13,7 @@ done
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pmc_f_self /tmp/pmc_w_self $out/${tag}_pmc_traffic.json /tmp/pmc_f_cross /tmp/pmc_w_cross > $out/${tag}_pmc_traffic.txt
 cp /tmp/pmc_f_self/*/*counter_collection.csv $out/${tag}_pmc_fetch_size_counter_collection.csv
 cp /tmp/pmc_w_self/*/*counter_collection.csv $out/${tag}_pmc_write_size_counter_collection.csv
-cp $out/${tag}_pmc_traffic.json $GRAFT_REPO_ROOT/profiles/r02_pmc_traffic.json   # bench.py reads the table of THIS run
+cp $out/${tag}_pmc_traffic.json $GRAFT_REPO_ROOT/profiles/r03_pmc_traffic.json   # bench.py reads the table of THIS run
 cd $GRAFT_REPO_ROOT
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 python bench.py --no-cpu-baseline --no-kernels --host-batches > $out/${tag}_bench_host_batches.json 2>/dev/null
