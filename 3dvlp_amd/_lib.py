@@ -105,6 +105,10 @@ SIGNATURES = {
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],
     "vlp3d_stamp": [_vp, _vp],
     "vlp3d_probe_empty": [_i, _i, _vp, _vp],
+    "vlp3d_gather_xyz": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "vlp3d_gather_xyz_grad": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "vlp3d_three_nn_weights": [_vp, ctypes.c_longlong, _vp, _vp, _vp],
+    "vlp3d_sa_bn_fold_shift": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp, _vp],
     "vlp3d_augment_param_floats": [],
     "vlp3d_augment_max_instances": [],
     "vlp3d_augment_points": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -312,6 +316,39 @@ def three_nn(unknowns, knows):
     with torch.cuda.device(unknowns.device):
         _check(load().vlp3d_three_nn(_p(unknowns), _p(knows), B, n, m, _p(dist2), _p(idx), _stream()), "three_nn")
     return dist2, idx
+
+
+def gather_xyz(xyz, idx):
+    """xyz (B,N,3) f32, idx (B,M) i32 -> (B,M,3): the sampled coordinates, without the two transposes around gather_points."""
+    _chk_float(xyz, "xyz")
+    _chk_int(idx, "idx")
+    _chk_dev(xyz, ("idx", idx))
+    B, N, _ = xyz.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(load().vlp3d_gather_xyz(_p(xyz), _p(idx), B, N, M, _p(out), _stream()), "gather_xyz")
+    return out
+
+
+def gather_xyz_grad(g, idx, N):
+    _chk_float(g, "grad_out")
+    _chk_int(idx, "idx")
+    B, M, _ = g.shape
+    out = torch.empty((B, int(N), 3), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(load().vlp3d_gather_xyz_grad(_p(g), _p(idx), B, int(N), M, _p(out), _stream()), "gather_xyz_grad")
+    return out
+
+
+def three_nn_weights(dist2):
+    """dist2 (B,n,3) squared distances of three_nn -> inverse-distance weights (B,n,3) (pointnet2_modules.py:393-397)."""
+    _chk_float(dist2, "dist2")
+    _chk_dev(dist2)
+    w = torch.empty_like(dist2)
+    with torch.cuda.device(dist2.device):
+        _check(load().vlp3d_three_nn_weights(_p(dist2), dist2.numel() // 3, _p(w), ctypes.c_void_p(0), _stream()), "three_nn_weights")
+    return w
 
 
 def three_interpolate(points, idx, weight):

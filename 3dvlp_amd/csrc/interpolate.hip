@@ -181,3 +181,71 @@ extern "C" int vlp3d_three_interpolate_grad(const float *grad_out, const int *id
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
+
+
+// ---- loader-side glue of the geometry stream (no gradient, coordinates only) ----------------------------------------------
+// gather_xyz: new_xyz[b,j,:] = xyz[b, idx[b,j], :] on the (B,N,3) layout the geometry kernels use — replaces
+//   gather_operation(xyz.transpose(1,2).contiguous(), idx).transpose(1,2).contiguous() (two 480 KB transposes + a gather per
+//   backbone level; pointnet2_modules.py:233-236 does exactly that).
+// three_nn_weights: the inverse-distance weights of PointnetFPModule.forward (pointnet2_modules.py:393-397) from three_nn's
+//   squared distances in one launch: dist = sqrt(d2); r = 1/(dist + 1e-8); w = r / (r0 + r1 + r2)  (five element-wise
+//   launches in the reference's op sequence); `dist` (optional) receives sqrt(d2) like ThreeNN.forward returns it.
+namespace {
+__global__ __launch_bounds__(256) void gather_xyz_kernel(const float *__restrict__ xyz, const int *__restrict__ idx, int N, int M,
+                                                         long long total, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / M;
+  const float *p = xyz + (b * N + idx[i]) * 3;
+  out[i * 3] = p[0]; out[i * 3 + 1] = p[1]; out[i * 3 + 2] = p[2];
+}
+__global__ __launch_bounds__(256) void three_nn_weights_kernel(const float *__restrict__ d2, long long n, float *__restrict__ w,
+                                                               float *__restrict__ dist) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float a = sqrtf(d2[3 * i]), b = sqrtf(d2[3 * i + 1]), c = sqrtf(d2[3 * i + 2]);
+  const float ra = 1.0f / (a + 1e-8f), rb = 1.0f / (b + 1e-8f), rc = 1.0f / (c + 1e-8f);
+  const float norm = (ra + rb) + rc;
+  w[3 * i] = ra / norm; w[3 * i + 1] = rb / norm; w[3 * i + 2] = rc / norm;
+  if (dist) { dist[3 * i] = a; dist[3 * i + 1] = b; dist[3 * i + 2] = c; }
+}
+}  // namespace
+
+extern "C" int vlp3d_gather_xyz(const float *xyz, const int *idx, int B, int N, int M, float *out, void *stream) {
+  if (!xyz || !idx || !out || B < 1 || N < 1 || M < 1) return -22;
+  const long long total = (long long)B * M;
+  hipLaunchKernelGGL(gather_xyz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, idx, N, M,
+                     total, out);
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void gather_xyz_grad_kernel(const float *__restrict__ g, const int *__restrict__ idx, int N, int M,
+                                                              long long total, float *__restrict__ dxyz) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float *p = dxyz + ((i / M) * N + idx[i]) * 3;
+  unsafeAtomicAdd(p, g[i * 3]); unsafeAtomicAdd(p + 1, g[i * 3 + 1]); unsafeAtomicAdd(p + 2, g[i * 3 + 2]);
+}
+}  // namespace
+
+// adjoint of vlp3d_gather_xyz: dxyz (B,N,3) = 0, then dxyz[b, idx[b,j], :] += g[b,j,:] (duplicated indices accumulate)
+extern "C" int vlp3d_gather_xyz_grad(const float *g, const int *idx, int B, int N, int M, float *dxyz, void *stream) {
+  if (!g || !idx || !dxyz || B < 1 || N < 1 || M < 1) return -22;
+  hipError_t e = vlp3d_zero_words(dxyz, (size_t)B * N * 3, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)B * M;
+  hipLaunchKernelGGL(gather_xyz_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, idx, N, M,
+                     total, dxyz);
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vlp3d_three_nn_weights(const float *dist2, long long n, float *weight, float *dist, void *stream) {
+  if (!dist2 || !weight || n < 1) return -22;
+  hipLaunchKernelGGL(three_nn_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dist2, n,
+                     weight, dist);
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}

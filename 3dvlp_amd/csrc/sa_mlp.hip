@@ -1659,7 +1659,7 @@ __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int
 __global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, const float *__restrict__ gamma,
                                const float *__restrict__ beta, float *__restrict__ running_mean,
                                float *__restrict__ running_var, int C, double R, float eps, float momentum,
-                               int training, float *__restrict__ vec) {
+                               int training, float *__restrict__ vec, const float *__restrict__ mean_shift) {
   double s = 0.0, q = 0.0;
   if (training) slab_sum16(stats, nslab, C, s, q);
   const int c = blockIdx.x * SUMC + (threadIdx.x & (SUMC - 1));
@@ -1670,7 +1670,8 @@ __global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, cons
     var = q / R - mean * mean;
     if (var < 0.0) var = 0.0;
     if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      // mean_shift: a conv bias in front of the BatchNorm shifts the batch mean the running estimate tracks (and nothing else)
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + (mean_shift ? mean_shift[c] : 0.f));
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (R / (R > 1.0 ? R - 1.0 : 1.0)));
     }
   } else {
@@ -2058,7 +2059,20 @@ extern "C" int vlp3d_sa_bn_fold(const double *stats, int nslab, const float *gam
   if (nslab < 1 || !gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
     return VLP3D_EINVAL;
   hipLaunchKernelGGL(bn_fold_kernel, dim3((C + SUMC - 1) / SUMC), dim3(256), 0, (hipStream_t)stream, stats, nslab, gamma, beta,
-                     running_mean, running_var, C, (double)R, eps, momentum, training, vec);
+                     running_mean, running_var, C, (double)R, eps, momentum, training, vec, (const float *)nullptr);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// as vlp3d_sa_bn_fold, the running mean additionally tracking `mean_shift` (C): the bias of a Conv1d in front of a
+// train-mode BatchNorm1d (voting_module.py:41-44), which the rows kernels leave out of Y because it cancels in the output.
+extern "C" int vlp3d_sa_bn_fold_shift(const double *stats, int nslab, const float *gamma, const float *beta,
+                                      float *running_mean, float *running_var, int C, long long R, float eps, float momentum,
+                                      int training, float *vec, const float *mean_shift, void *stream) {
+  if (nslab < 1 || !gamma || !beta || !vec || C < 1 || R < 1 || (training && !stats) || (!training && (!running_mean || !running_var)))
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + SUMC - 1) / SUMC), dim3(256), 0, (hipStream_t)stream, stats, nslab, gamma, beta,
+                     running_mean, running_var, C, (double)R, eps, momentum, training, vec, mean_shift);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

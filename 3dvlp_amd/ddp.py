@@ -13,6 +13,7 @@ concatenated weight as a VIEW (`merge_adjacent`, no torch.cat per step), and Ada
 (`FlatAdamW`, csrc/glue.hip) instead of the multi-tensor optimiser's six.
 """
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -37,6 +38,41 @@ def adjacency_groups(module):
             for fc in m.self_attn_fc:
                 groups.append(list(fc.parameters()))
     return groups
+
+
+def padding_requests(module):
+    """[(first parameter, last parameter, row multiple)]: parameter runs (one tensor, or an adjacency group from first to
+    last) whose LEADING dimension a kernel wants rounded up to a multiple — FlatParams then reserves zero rows behind the
+    run, so that the kernel reads a padded weight straight from the parameter storage instead of F.pad-ing it every step
+    (the final plain layers of the voting module: 259 -> 320 rows, and of the merged ROI predictors: 28 -> 64)."""
+    req = []
+    for m in module.modules():
+        name = type(m).__name__
+        if name == "VotingModule":
+            req += [(m.conv3.weight, m.conv3.weight, 64), (m.conv3.bias, m.conv3.bias, 64)]
+        elif name == "StandardROIHeads":
+            heads = [m.heading_reg_predictor, m.heading_cls_predictor, m.box_predictor, m.objectness_predictor]
+            if m.num_class:
+                heads.append(m.sem_cls_predictor)
+            req += [(heads[0].weight, heads[-1].weight, 64), (heads[0].bias, heads[-1].bias, 64)]
+    return req
+
+
+PADDED_ROWS = {}  # data_ptr of a run's first parameter -> (rows available incl. the reserved zero rows, weakref to the flat buffer)
+
+
+def padded_rows(t):
+    """Rows readable at t's address when t starts a padded parameter run of a LIVE FlatParams buffer (else 0).  The entry
+    is trusted only while the flat buffer it was made for is alive and t really lives in that buffer's storage — an
+    address alone says nothing once a model has been freed."""
+    hit = PADDED_ROWS.get(t.data_ptr())
+    if hit is None:
+        return 0
+    rows, ref = hit
+    flat = ref()
+    if flat is None or t.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+        return 0
+    return rows
 
 
 def ordered_parameters(module):
@@ -65,12 +101,23 @@ class FlatParams:
         self.params = ordered_parameters(module)
         starts = {id(g[0]) for g in adjacency_groups(module)}
         members = {id(p) for g in adjacency_groups(module) for p in g}
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        pad_after, run_first = {}, {}
+        for first, last, mult in padding_requests(module):
+            if id(first) not in pos or id(last) not in pos:
+                continue
+            run = self.params[pos[id(first)]:pos[id(last)] + 1]
+            rows = sum(q.shape[0] for q in run)
+            row_elems = first.numel() // first.shape[0]
+            want = (rows + mult - 1) // mult * mult
+            pad_after[id(last)] = (want - rows) * row_elems
+            run_first[id(first)] = want
         offs, off = [], 0
         for p in self.params:
             if id(p) in starts or id(p) not in members:
                 off = (off + 3) // 4 * 4
             offs.append(off)
-            off += p.numel()
+            off += p.numel() + pad_after.get(id(p), 0)   # reserved rows stay zero: no gradient, masked out of AdamW
         self.numel = (off + 3) // 4 * 4
         ref = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
@@ -80,6 +127,8 @@ class FlatParams:
                 view = self.flat[o:o + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
+                if id(p) in run_first:
+                    PADDED_ROWS[p.data_ptr()] = (run_first[id(p)], weakref.ref(self.flat))
 
 
 class _MergeAdjacent(Function):

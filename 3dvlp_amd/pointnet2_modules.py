@@ -67,7 +67,7 @@ class PointnetSAModuleVotes(nn.Module):
         coordinates, so a step driver may compute it ahead of time on a side stream (grounding_step.py).
         fps_ordered: xyz is the previous level's new_xyz (FPS samples in sampling order) — a hint, see _lib."""
         inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, fps_ordered)
-        new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        new_xyz = sa_fused_ext.gather_xyz(xyz.contiguous(), inds)  # == gather_operation on the transposed cloud, one launch
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         if self._use_compact(xyz):
             return (inds, new_xyz, idx) + tuple(sa_fused_ext.sa_compact(idx, xyz.shape[1]))  # + (rowptr, crow)
@@ -90,8 +90,7 @@ class PointnetSAModuleVotes(nn.Module):
             inds, new_xyz, idx = geometry[:3]
             cmap = tuple(geometry[3:5]) if len(geometry) >= 5 else None
         else:
-            xyz_flipped = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_xyz(xyz, inds)  # gather_operation on the transposed cloud, without the transposes
             idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
         feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
         dtype = self.mlp_dtype or (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
@@ -177,6 +176,9 @@ class PointnetFPModule(nn.Module):
     @torch.no_grad()
     def compute_geometry(unknown, known):
         """Weight-independent part: three_nn indices + inverse-distance weights (:393-397)."""
+        if unknown.is_cuda and unknown.dtype == torch.float32:
+            dist2, idx = sa_fused_ext.three_nn(unknown.contiguous(), known.contiguous())
+            return idx, sa_fused_ext.three_nn_weights(dist2)   # sqrt, reciprocal, sum, divide: one launch
         dist, idx = pointnet2_utils.three_nn(unknown, known)
         dist_recip = 1.0 / (dist + 1e-8)
         return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)

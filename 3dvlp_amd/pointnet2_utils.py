@@ -52,6 +52,25 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
+class GatherXYZ(Function):
+    """xyz (B,N,3), idx (B,M) i32 -> (B,M,3) = gather_operation(xyz^T, idx)^T on the point-major layout (no transposes);
+    gradient to xyz (the vote coordinates of the proposal module's aggregation: proposal_module_fcos.py:76)."""
+
+    @staticmethod
+    def forward(ctx, xyz, idx):
+        ctx.save_for_backward(idx)
+        ctx.N = xyz.shape[1]
+        return _ext.gather_xyz(xyz.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_xyz_grad(g.contiguous(), idx, ctx.N), None
+
+
+gather_xyz = GatherXYZ.apply
+
+
 class ThreeNN(Function):
     @staticmethod
     def forward(ctx, unknown, known):

@@ -15,7 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as _ext
-from . import mfma_linear
+from . import ddp, mfma_linear
 
 _ext.load()
 _ZEROS = {}
@@ -72,8 +72,13 @@ class _RowStack(Function):
             w = W[l].contiguous()
             b = bias[l]
             if Np != N:  # only a final plain layer (259 = 3 + 256 vote channels, 28 ROI predictor channels)
-                w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
-                b = None if b is None else torch.nn.functional.pad(b, (0, Np - N))
+                if ddp.padded_rows(w) >= Np and (b is None or ddp.padded_rows(b) >= Np):
+                    # the parameter storage itself carries the zero rows (ddp.FlatParams reserved them): no per-step pad
+                    w = w.as_strided((Np, K), (K, 1))
+                    b = None if b is None else b.as_strided((Np,), (1,))
+                else:
+                    w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
+                    b = None if b is None else torch.nn.functional.pad(b, (0, Np - N))
             Wp.append(w)
             y = torch.empty((R, Np), dtype=torch.float32, device=dev)
             bn = bns[l]
@@ -92,10 +97,10 @@ class _RowStack(Function):
                         mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
                     else:
                         mom = 0.0
-                    _ext.call("vlp3d_sa_bn_fold", st, nslab, gam[l], bet[l], bn.running_mean if track else None,
-                              bn.running_var if track else None, Np, R, float(bn.eps), float(mom), 1, vec)
-                    if track and b is not None:  # the bias shifts the batch mean (and nothing else)
-                        bn.running_mean.add_(b.detach(), alpha=mom)
+                    # (the bias shifts the batch mean the running estimate tracks, and nothing else: folded into the same launch)
+                    _ext.call("vlp3d_sa_bn_fold_shift", st, nslab, gam[l], bet[l], bn.running_mean if track else None,
+                              bn.running_var if track else None, Np, R, float(bn.eps), float(mom), 1, vec,
+                              b.detach() if (track and b is not None) else None)
                 else:  # eval: y includes the bias, the running statistics normalise it
                     _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None, bf)
                     _ext.call("vlp3d_sa_bn_fold", None, 1, gam[l], bet[l], bn.running_mean, bn.running_var, Np, R,

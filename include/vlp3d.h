@@ -599,6 +599,17 @@ int vlp3d_augment_votes(const float *pc, int B, int N, int C, const int *inst, i
                         float *vote, float *mask_f, long long *mask_i, void *stream);
 int vlp3d_augment_boxes(const float *boxes, int B, int M, const float *params, float *out, void *stream);
 
+/* Geometry-stream glue (csrc/interpolate.hip): gather_xyz — new_xyz (B,M,3) = xyz (B,N,3)[idx (B,M)] (replaces the
+ * transpose / gather_operation / transpose of pointnet2_modules.py:233-236); three_nn_weights — the inverse-distance weights
+ * of pointnet2_modules.py:393-397 from three_nn's dist2 (n rows of 3): w = r / sum(r), r = 1/(sqrt(d2) + 1e-8); dist
+ * (optional) = sqrt(d2).  vlp3d_sa_bn_fold_shift: vlp3d_sa_bn_fold whose running mean also tracks mean_shift (C). */
+int vlp3d_gather_xyz(const float *xyz, const int *idx, int B, int N, int M, float *out, void *stream);
+int vlp3d_gather_xyz_grad(const float *g, const int *idx, int B, int N, int M, float *dxyz, void *stream);
+int vlp3d_three_nn_weights(const float *dist2, long long n, float *weight, float *dist, void *stream);
+int vlp3d_sa_bn_fold_shift(const double *stats, int nslab, const float *gamma, const float *beta, float *running_mean,
+                           float *running_var, int C, long long R, float eps, float momentum, int training, float *vec,
+                           const float *mean_shift, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
