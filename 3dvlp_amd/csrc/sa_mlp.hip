@@ -2108,9 +2108,16 @@ extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const flo
 
 // Y (R x N) = X (R x K) W^T + bias;  W (N x K) row-major, bias (N) or NULL.  R % 32 == 0, K % 8 == 0,
 // N in {32, 64, 128, 160, 256, 288}.
+// csrc/linear_tile.hip: LDS-tiled form for many rows (bf16 operands)
+int vlp3d_internal_linear_tile(const float *X, int ldx, const float *W, int ldw, int kdim, int ncols, const float *bias,
+                               const float *base, long long R, float *Y, int ldy, int transposed_weight, hipStream_t stream);
+static const long long LINEAR_TILE_MIN_ROWS = 8192;  // below: a wave per 32 x 32 tile fills the chip better (latency bound)
+
 extern "C" int vlp3d_linear_fwd(const float *X, const float *W, const float *bias, long long R, int K, int N, float *Y,
                                 int bf16_mma, void *stream) {
   if (!X || !W || !Y || R < 32 || (R & 31) || K < 8 || (K & 7)) return VLP3D_EINVAL;
+  if (bf16_mma && R >= LINEAR_TILE_MIN_ROWS && N % 64 == 0 && K % 16 == 0)
+    return vlp3d_internal_linear_tile(X, K, W, K, K, N, bias, nullptr, R, Y, N, 0, (hipStream_t)stream);
   if (bf16_mma && R <= 65536 && N % 32 == 0 && N >= 32 && K % 16 == 0) {
     hipLaunchKernelGGL((linear_bf16_kernel<false>), dim3(grid_tiles(R), N / 32), dim3(256), 0, (hipStream_t)stream, X, K, W, K, 0,
                        bias, nullptr, R, Y, N);
@@ -2193,6 +2200,8 @@ extern "C" int vlp3d_linear_dgrad(const float *dY, const float *W, long long R, 
                                   int bf16_mma, void *stream) {
   if (!dY || !W || !dX || R < 32 || (R & 31) || N < 8 || (N & 7) || K < 32 || (K & 31)) return VLP3D_EINVAL;
   if (base && !(bf16_mma && N % 16 == 0)) return VLP3D_EINVAL;  // the exact-fp32 form has no fused add: add it yourself
+  if (bf16_mma && N % 16 == 0 && R >= LINEAR_TILE_MIN_ROWS && K % 64 == 0)
+    return vlp3d_internal_linear_tile(dY, N, W, K, N, K, nullptr, base, R, dX, K, 1, (hipStream_t)stream);
   if (bf16_mma && N % 16 == 0) {
     hipLaunchKernelGGL((linear_bf16_kernel<true>), dim3(grid_tiles(R), K / 32), dim3(256), 0, (hipStream_t)stream, dY, N, W, N, K,
                        nullptr, base, R, dX, K);
