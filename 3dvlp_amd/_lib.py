@@ -69,6 +69,8 @@ SIGNATURES = {
     "vlp3d_add_norm_blocks": [ctypes.c_longlong],
     "vlp3d_add_norm_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_add_norm_bwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "vlp3d_add_norm_rep_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _f, _vp, _i, _f, _vp, _vp, _vp, _vp],
+    "vlp3d_rep_sum2": [_vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp],
     "vlp3d_sum_norm_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_sum_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "vlp3d_act_dropout": [_vp, _vp, ctypes.c_longlong, _i, _f, _vp, _i, _vp, _vp, _vp],

@@ -77,6 +77,56 @@ def add_norm(x, y, norm, p=0.0, training=True, mask_out=None):
     return _AddNorm.apply(x, y, norm.weight, norm.bias, p, norm.eps, _CALLS[0], state(x.device), mask_out)
 
 
+class _AddNormRep(Function):
+    """LayerNorm(x + dropout(y)) on `rep` replicas of every group of `seq` rows of x / y (csrc/add_norm.hip
+    vlp3d_add_norm_rep_fwd): (G*seq, D) -> (G*rep*seq, D); backward = the plain add & norm backward on the replicated rows,
+    then ONE launch sums the replicas' dx and dy back onto the source rows."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, rep, seq, p, eps, call_id, seed):
+        D = x.shape[-1]
+        x2, y2 = x.reshape(-1, D).contiguous(), y.reshape(-1, D).contiguous()
+        Rs = x2.shape[0]
+        R = Rs * rep
+        out = torch.empty((R, D), dtype=torch.float32, device=x.device)
+        xhat = torch.empty_like(out)
+        rstd = torch.empty((R,), dtype=torch.float32, device=x.device)
+        _ext.call("vlp3d_add_norm_rep_fwd", x2, y2, gamma.contiguous(), beta.contiguous(), R, D, int(rep), int(seq), float(p),
+                  seed, call_id, float(eps), out, xhat, rstd)
+        ctx.save_for_backward(xhat, rstd, gamma, seed)
+        ctx.cfg = (R, Rs, D, float(p), call_id, int(rep), int(seq), x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, gamma, seed = ctx.saved_tensors
+        R, Rs, D, p, call_id, rep, seq, shape = ctx.cfg
+        d2 = dout.reshape(R, D).contiguous()
+        dx, dy = torch.empty_like(d2), torch.empty_like(d2)
+        nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
+        part = torch.empty((nblk, 2, D), dtype=torch.float32, device=dout.device)
+        dgb = torch.empty((2, D), dtype=torch.float32, device=dout.device)
+        q = _ext.slab_queue()
+        _ext.call("vlp3d_sum_norm_bwd", d2, None, xhat, rstd, None, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
+                  dgb, int(q is not None))
+        if q is not None:
+            q.add(part, nblk, dgb, 2 * D, 2 * D, 2 * D)
+        sx = torch.empty((Rs, D), dtype=torch.float32, device=dout.device)
+        sy = torch.empty_like(sx)
+        _ext.call("vlp3d_rep_sum2", dx, dy, Rs, D, rep, seq, sx, sy)
+        return sx.view(shape), sy.view(shape), dgb[0], dgb[1], None, None, None, None, None, None
+
+
+def add_norm_rep(x, y, norm, rep, p=0.0, training=True):
+    """x, y (G, seq, D) -> (G*rep, seq, D): every group replicated `rep` times, then LayerNorm(x + dropout_p(y)) with an
+    independent dropout mask per replica (== add_norm(x.repeat_interleave(rep, 0), y.repeat_interleave(rep, 0), ...))."""
+    p = float(p) if training else 0.0
+    G, seq, D = x.shape
+    _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
+    out = _AddNormRep.apply(x, y, norm.weight, norm.bias, int(rep), int(seq), p, norm.eps, _CALLS[0], state(x.device))
+    return out.view(G * rep, seq, D)
+
+
 class _SumNorm(Function):
     """(s, n) = (x + dropout_p(y), norm(s)) — the pre-norm residual stream of the caption decoder (csrc/add_norm.hip
     vlp3d_sum_norm_*).  y None: s = x (first norm of a stack; s is then x itself, no copy)."""

@@ -28,11 +28,15 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
                                                            float eps, float *__restrict__ out,
                                                            float *__restrict__ xhat, float *__restrict__ rstd,
                                                            unsigned char *__restrict__ mask, int std_mode,
-                                                           float *__restrict__ sum_out, float *__restrict__ kappa) {
+                                                           float *__restrict__ sum_out, float *__restrict__ kappa, int rep,
+                                                           int seq) {
   constexpr int D = 64 * EPL;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
+  // rep > 1: x and y hold ONE copy of every group of `seq` rows, the R output rows are `rep` consecutive copies of each
+  // group (output row (g, l, k) reads source row (g, k)); the dropout mask is drawn per OUTPUT element
+  const long long srow = rep > 1 ? (row / ((long long)rep * seq)) * seq + row % seq : row;
   const int c0 = lane * EPL;
   const unsigned thresh = (unsigned)(p * 16777216.0f);
   const unsigned mix = p > 0.f ? seed_mix_of(seed, call_id) : 0u;
@@ -41,14 +45,14 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(const float *__restri
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
-    const long long e = row * D + c0 + i;
-    float yv = y ? y[e] : 0.f;
+    const long long e = row * D + c0 + i, es = srow * D + c0 + i;
+    float yv = y ? y[es] : 0.f;
     if (p > 0.f) {
       const bool keep = keep_element(mix, (unsigned)e, thresh);
       yv = keep ? yv * inv_keep : 0.f;
       if (mask) mask[e] = keep ? 1 : 0;
     }
-    r[i] = x[e] + yv;
+    r[i] = x[es] + yv;
     if (sum_out) sum_out[e] = r[i];
     s += r[i];
   }
@@ -244,7 +248,8 @@ extern "C" int vlp3d_add_norm_blocks(long long R) {  // workgroups (= partial sl
 
 static int add_norm_fwd_any(const float *x, const float *y, const float *gamma, const float *beta, long long R, int D,
                             float p, const unsigned long long *seed, int call_id, float eps, float *out, float *xhat,
-                            float *rstd, unsigned char *mask, int std_mode, float *sum_out, float *kappa, void *stream) {
+                            float *rstd, unsigned char *mask, int std_mode, float *sum_out, float *kappa, void *stream,
+                            int rep = 1, int seq = 0) {
   if (!x || !gamma || !beta || !out || !xhat || !rstd || R < 1 || p < 0.f || p >= 1.f || (p > 0.f && (!seed || !y)) ||
       (std_mode && !kappa) || R * (long long)D >= (1ll << 32))
     return VLP3D_EINVAL;
@@ -252,7 +257,7 @@ static int add_norm_fwd_any(const float *x, const float *y, const float *gamma, 
   hipStream_t s = (hipStream_t)stream;
 #define ADD_NORM_FWD(EPL) \
   hipLaunchKernelGGL(add_norm_fwd_kernel<EPL>, grid, block, 0, s, x, y, gamma, beta, R, p, seed, call_id, eps, out, xhat, rstd, \
-                     mask, std_mode, sum_out, kappa)
+                     mask, std_mode, sum_out, kappa, rep, seq)
   switch (D) {
     case 64: ADD_NORM_FWD(1); break;
     case 128: ADD_NORM_FWD(2); break;
@@ -269,6 +274,48 @@ extern "C" int vlp3d_add_norm_fwd(const float *x, const float *y, const float *g
                                   float *xhat, float *rstd, unsigned char *mask, void *stream) {
   if (!y) return VLP3D_EINVAL;
   return add_norm_fwd_any(x, y, gamma, beta, R, D, p, seed, call_id, eps, out, xhat, rstd, mask, 0, nullptr, nullptr, stream);
+}
+
+// out (R rows) = LayerNorm(x + dropout_p(y)) where x, y hold R / rep rows: every group of `seq` source rows is used by `rep`
+// consecutive output groups (match_module.py:127 tiles the proposals over the sentences BEFORE the first decoder layer,
+// whose attention block — attention.py:41-78 has no dropout inside — is therefore identical for all copies; only this
+// dropout + add & norm differs per copy).  R % (rep * seq) == 0.
+extern "C" int vlp3d_add_norm_rep_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R,
+                                      int D, int rep, int seq, float p, const unsigned long long *seed, int call_id, float eps,
+                                      float *out, float *xhat, float *rstd, void *stream) {
+  if (!y || rep < 1 || seq < 1 || R % ((long long)rep * seq)) return VLP3D_EINVAL;
+  return add_norm_fwd_any(x, y, gamma, beta, R, D, p, seed, call_id, eps, out, xhat, rstd, nullptr, 0, nullptr, nullptr, stream,
+                          rep, seq);
+}
+
+namespace {
+// sx[g,k,:] = sum_l a[g,l,k,:], sy likewise for b: the adjoint of the row replication above, both tensors in one launch
+__global__ __launch_bounds__(256) void rep_sum2_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, long long n4,
+                                                       int rep, long long group4, float4 *__restrict__ sa, float4 *__restrict__ sb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over the (R / rep) * D / 4 output float4s
+  if (i >= n4) return;
+  const long long g = i / group4, k = i - g * group4;
+  const float4 *pa = a + g * rep * group4 + k, *pb = b + g * rep * group4 + k;
+  float4 ta = make_float4(0.f, 0.f, 0.f, 0.f), tb = ta;
+  for (int l = 0; l < rep; ++l) {
+    const float4 va = pa[(long long)l * group4], vb = pb[(long long)l * group4];
+    ta.x += va.x; ta.y += va.y; ta.z += va.z; ta.w += va.w;
+    tb.x += vb.x; tb.y += vb.y; tb.z += vb.z; tb.w += vb.w;
+  }
+  sa[i] = ta;
+  sb[i] = tb;
+}
+}  // namespace
+
+extern "C" int vlp3d_rep_sum2(const float *a, const float *b, long long rows_out, int D, int rep, int seq, float *sa, float *sb,
+                              void *stream) {
+  if (!a || !b || !sa || !sb || rows_out < 1 || D < 4 || (D & 3) || rep < 1 || seq < 1 || rows_out % seq) return VLP3D_EINVAL;
+  const long long n4 = rows_out * D / 4, group4 = (long long)seq * D / 4;
+  hipLaunchKernelGGL(rep_sum2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), n4, rep, group4,
+                     reinterpret_cast<float4 *>(sa), reinterpret_cast<float4 *>(sb));
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
 }
 
 // Pre-norm residual stream (transformer_captioner.py:132-145 SublayerConnection: x + dropout(sublayer(norm(x)))): ONE

@@ -92,12 +92,15 @@ class MatchModule(nn.Module):
             else:
                 feature0 = torch.where(coin < 0.5, self._copy_paste(features, obj_mask.float().unsqueeze(2)), features)
 
-        feature1 = feature0[:, None, :, :].expand(B, L, K, feature0.shape[-1]).reshape(B * L, K, -1)
         # K/V = the tokens after [CLS]; the loader may hand over the contiguous copy (grounding_step.batch_to_device)
         lang_fea = data_dict["k/lang_kv"] if "k/lang_kv" in data_dict else data_dict["lang_fea"][:, 1:]
 
-        for layer in self.grounding_cross_attn:
-            feature1 = layer(feature1, lang_fea, lang_fea)  # (B*L, K, hidden)
+        # the proposals are tiled over the L sentences of their scene (:127); the first layer takes the UN-tiled features and
+        # tiles after its (copy-independent) self-attention block — same values, see CrossAttentionDecoderLayer.forward_tiled
+        layers = list(self.grounding_cross_attn)
+        feature1 = layers[0].forward_tiled(feature0.contiguous(), L, lang_fea, lang_fea)  # (B*L, K, hidden)
+        for layer in layers[1:]:
+            feature1 = layer(feature1, lang_fea, lang_fea)
         data_dict["cross_box_feature"] = feature1
 
         feature1_agg = feature1.reshape(B * L * K, -1)

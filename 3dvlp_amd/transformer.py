@@ -165,8 +165,29 @@ class CrossAttentionDecoderLayer(nn.Module):
 
     def forward(self, query, key, value, src_mask=None, src_trg_mask=None):
         x = self.self_attention(query, query, query, attention_mask=src_mask)
+        return self._after_self_attention(x, key, value, src_trg_mask)
+
+    def _after_self_attention(self, x, key, value, src_trg_mask):
         x = self.enc_dec_attention(x, key, value, attention_mask=src_trg_mask)
         f, x_res = self.ffn(x, with_residual=True)
         if self.fused_norm and add_norm.supported(x, f, self.norm):
             return add_norm.add_norm(x_res, f, self.norm, self.dropout.p, self.training)
         return self.norm(self.dropout(f) + x_res)
+
+    def forward_tiled(self, query, rep, key, value, src_trg_mask=None):
+        """== forward(query tiled `rep` times along the batch, key, value) for a query (B, K, C) that `rep` consecutive
+        key / value sequences share (match_module.py:127-137 tiles the proposals over a scene's sentences and feeds the copies
+        to the first decoder layer).  The attention block of the self-attention sublayer (attention.py:41-78: projections,
+        softmax, fc_o — no dropout inside) is identical for all copies, so it runs ONCE on the B sequences; what differs per
+        copy is the dropout mask of the add & norm that follows (attention.py:128-130), which a replicating add & norm kernel
+        draws per copy.  8x fewer rows through q|k|v, the attention core and fc_o (forward and backward) at L = 8, and the
+        16.8 MB tiled copy of the proposal features is never made."""
+        mha = self.self_attention
+        B, K, C = query.shape
+        if (rep == 1 or not self.fused_norm or not mha.fused_norm or mha.identity_map_reordering or not query.is_cuda
+                or query.dtype != torch.float32 or C not in (64, 128, 256) or torch.is_autocast_enabled("cuda")):
+            tiled = query[:, None].expand(B, rep, K, C).reshape(B * rep, K, C)
+            return self.forward(tiled, key, value, src_trg_mask=src_trg_mask)
+        out, _, q_res = mha.attention(query, query, query, need_att=False, with_residual=True)
+        x = add_norm.add_norm_rep(q_res, out, mha.layer_norm, rep, mha.dropout.p, mha.training)
+        return self._after_self_attention(x, key, value, src_trg_mask)

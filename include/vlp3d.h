@@ -327,6 +327,16 @@ int vlp3d_add_norm_bwd(const float *dout, const float *xhat, const float *rstd, 
                        float p, const unsigned long long *seed, int call_id, float *dx, float *dy, float *partials,
                        float *dgamma_dbeta, void *stream);
 
+/* add & norm over REPLICATED rows: x, y hold R / rep rows; every group of `seq` source rows feeds `rep` consecutive output
+ * groups (the proposals tiled over the sentences, match_module.py:127) with independent dropout masks per output element.
+ * vlp3d_rep_sum2: the adjoint of the replication for two gradients at once: sa[g,k,:] = sum_l a[g,l,k,:] (rows_out =
+ * R / rep rows out). */
+int vlp3d_add_norm_rep_fwd(const float *x, const float *y, const float *gamma, const float *beta, long long R, int D, int rep,
+                           int seq, float p, const unsigned long long *seed, int call_id, float eps, float *out, float *xhat,
+                           float *rstd, void *stream);
+int vlp3d_rep_sum2(const float *a, const float *b, long long rows_out, int D, int rep, int seq, float *sa, float *sb,
+                   void *stream);
+
 /* Pre-norm residual stream of the caption decoder (models/caption_module/transformer_captioner.py:132-145
  * SublayerConnection: x + dropout(sublayer(norm(x))); :117-129 its own LayerNorm = a*(x-mean)/(std+eps)+b with the
  * unbiased std): one launch gives the new stream value sum_out = x + dropout_p(y) (y NULL: = x) AND out = norm(sum_out).

@@ -996,6 +996,59 @@ def test_captured_step_recaptures_when_the_epoch_crosses_50():
     assert abs(res["graph"][1] - res["eager"][1]) <= 1e-5 * abs(res["eager"][1])
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_decoder_layer_tiled_queries_equal_explicit_tiling(p):
+    """CrossAttentionDecoderLayer.forward_tiled(query (B,K,C), rep, ...) == forward(query tiled rep times, ...): the first
+    decoder layer of the match module runs its self-attention block once per scene instead of once per (scene, sentence).
+    p = 0: outputs and every gradient equal (reassociated sums only).  p = 0.1: the replicas draw INDEPENDENT masks (rows of
+    different replicas differ) at the expected keep rate, and the backward is the derivative of that forward."""
+    tr = importlib.import_module("3dvlp_amd.transformer")
+    an = importlib.import_module("3dvlp_amd.add_norm")
+    torch.manual_seed(3)
+    B, L, K, C, T = 3, 4, 64, 128, 17
+    layer = tr.CrossAttentionDecoderLayer(hidden_size=C).cuda().train()
+    for m in layer.modules():
+        if hasattr(m, "fused_norm"):
+            m.fused_norm = True
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    layer.self_attention.dropout.p = p
+    q = torch.randn(B, K, C, device="cuda")
+    kv = torch.randn(B * L, T, C, device="cuda")
+    g = torch.randn(B * L, K, C, device="cuda")
+    res = []
+    for tiled in (False, True):
+        layer.zero_grad()
+        x = q.clone().requires_grad_(True)
+        an._CALLS[0] = 100   # same call ids -> same masks for the layers that follow in both evaluations
+        out = layer.forward_tiled(x, L, kv, kv) if tiled else layer(x[:, None].expand(B, L, K, C).reshape(B * L, K, C), kv, kv)
+        (out * g).sum().backward()
+        res.append((out.detach(), x.grad.clone(), {n: p_.grad.clone() for n, p_ in layer.named_parameters()}))
+    (oa, ga, pa), (ob, gb, pb) = res
+    if p == 0.0:
+        assert _rel(ob, oa) < 1e-5 and _rel(gb, ga) < 1e-4
+        scale = max(float(v.norm()) for v in pa.values())
+        for n in pa:  # (the key bias has an exactly zero gradient — softmax is shift invariant: absolute floor)
+            assert float((pb[n] - pa[n]).norm()) < 2e-4 * float(pa[n].norm()) + 1e-6 * scale, (n, _rel(pb[n], pa[n]))
+    else:
+        o4 = ob.view(B, L, K, C)
+        assert float((o4[:, 0] - o4[:, 1]).abs().max()) > 1e-3            # replicas differ: independent masks
+        layer.zero_grad()
+        x = q.clone().requires_grad_(True)
+        f = lambda v: (layer.forward_tiled(v, L, kv, kv) * g).sum()
+        an._CALLS[0] = 100
+        f(x).backward()
+        u = torch.randn_like(q)
+        u /= u.norm()
+        h = 1e-2
+        an._CALLS[0] = 100
+        lp = float(f(q + h * u))
+        an._CALLS[0] = 100
+        lm = float(f(q - h * u))
+        fd, an_ = (lp - lm) / (2 * h), float((x.grad * u).sum())
+        assert abs(fd - an_) < 2e-2 * abs(an_) + 1e-2, (fd, an_)
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_deferred_slab_reduce_equals_immediate(bf16):
     """bf16=True additionally queues the weight-gradient LAUNCHES of the plain linear layers (vlp3d_linear_wgrad_batch; same
@@ -1032,7 +1085,8 @@ def test_deferred_slab_reduce_equals_immediate(bf16):
     for n, g0 in grads[0].items():
         noise = _rel(grads[1][n], g0)
         g1 = grads[2][n]
-        assert _rel(g1, g0) <= max(2e-5, 3 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
+        # (one pair of runs is itself a noisy estimate of the atomics' run-to-run noise, bf16 storage amplifies it: x5)
+        assert _rel(g1, g0) <= max(2e-5, 5 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
 
 
 def test_linear_wgrad_batch_equals_single_launches():
