@@ -39,6 +39,8 @@ SIGNATURES = {
     "vlp3d_group_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vlp3d_group_rows_grad": [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "vlp3d_sa_compact": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vlp3d_sa_inverse": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_sa_bwd_gather_csr": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "vlp3d_sa_fwd_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_fwd_layer": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_pool": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
@@ -390,6 +392,21 @@ def sa_compact(idx, N):
     with torch.cuda.device(idx.device):
         _check(load().vlp3d_sa_compact(_p(idx), B, int(N), M, S, _p(rowptr), _p(crow), _stream()), "sa_compact")
     return rowptr, crow
+
+
+def sa_inverse(idx, N, cmap=None):
+    """point -> rows map of a grouped MLP's gather (csrc/sa_compact.hip vlp3d_sa_inverse): idx (B,M,S) i32, cmap = (rowptr,
+    crow) of sa_compact or None -> (inv_start (B*N+1) i32, inv_rows (B*M*S) i32)."""
+    _chk_int(idx, "idx")
+    B, M, S = idx.shape
+    start = torch.empty((B * int(N) + 1,), dtype=torch.int32, device=idx.device)
+    rows = torch.empty((B * M * S,), dtype=torch.int32, device=idx.device)
+    cursor = torch.empty((B * int(N),), dtype=torch.int32, device=idx.device)
+    rowptr, crow = cmap if cmap is not None else (None, None)
+    with torch.cuda.device(idx.device):
+        _check(load().vlp3d_sa_inverse(_p(idx), _opt(crow), _opt(rowptr), B, int(N), M, S, _p(start), _p(rows), _p(cursor),
+                                       _stream()), "sa_inverse")
+    return start, rows
 
 
 def three_interpolate_grad_asshipped(grad_out, idx, weight, m):

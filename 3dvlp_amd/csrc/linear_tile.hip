@@ -46,7 +46,8 @@ __device__ __forceinline__ bf16x4 pack4(const float4 &v) {
 //   WT = true : op(W) = W,   W (kdim x ncols) row-major with row stride ldw        (input gradient: kdim = N, ncols = K)
 // TR = rows per workgroup block: 64 (waves 2 x 2, two accumulators each) or 32 (waves 1 x 4, one accumulator each: twice the
 // workgroups — two per CU at 16 384 rows — for the same LDS weight traffic per workgroup)
-template <bool WT, int TR>
+// WB (with WT = false only): W already holds bf16 (a prepared weight of a grouped-MLP stack): staged without conversion.
+template <bool WT, int TR, bool WB = false>
 __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
                                                           int kdim, int ncols, const float *__restrict__ bias,
                                                           const float *__restrict__ base, long long R, float *__restrict__ Y, int ldy) {
@@ -81,7 +82,15 @@ __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restric
           const long long rr = min(row0 + row, R - 1);  // clamped: unconditional loads (rows past R are never stored)
           va[j] = ld4(X + rr * ldx + k0 + 4 * c4);
         }
-        if (!WT) {
+        uint2 vb[WB ? TC * (KC / 4) / 256 : 1];
+        if (WB) {
+          const short *Wb = reinterpret_cast<const short *>(W);
+#pragma unroll
+          for (int j = 0; j < TC * (KC / 4) / 256; ++j) {
+            const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
+            vb[j] = *reinterpret_cast<const uint2 *>(Wb + (long long)min(c0 + col, ncols - 1) * ldw + k0 + 4 * c4);
+          }
+        } else if (!WT) {
 #pragma unroll
           for (int j = 0; j < TC * (KC / 4) / 256; ++j) {
             const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
@@ -99,7 +108,13 @@ __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restric
           const int e = threadIdx.x + 256 * j, row = e >> 5, c4 = e & 31;
           *reinterpret_cast<bf16x4 *>(sA + row * LD + 4 * c4) = pack4(va[j]);
         }
-        if (!WT) {
+        if (WB) {
+#pragma unroll
+          for (int j = 0; j < TC * (KC / 4) / 256; ++j) {
+            const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
+            *reinterpret_cast<uint2 *>(sW + col * LD + 4 * c4) = vb[j];
+          }
+        } else if (!WT) {
 #pragma unroll
           for (int j = 0; j < TC * (KC / 4) / 256; ++j) {
             const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
@@ -121,7 +136,15 @@ __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restric
         *reinterpret_cast<bf16x4 *>(sA + row * LD + 4 * c4) = pack4(v);
       }
       // ---- weight block: [column][k]
-      if (!WT) {
+      if (WB) {
+        const short *Wb = reinterpret_cast<const short *>(W);
+        for (int e = threadIdx.x; e < TC * q; e += 256) {
+          const int col = e / q, c4 = e - col * q;
+          uint2 v = make_uint2(0u, 0u);
+          if (c0 + col < ncols) v = *reinterpret_cast<const uint2 *>(Wb + (long long)(c0 + col) * ldw + k0 + 4 * c4);
+          *reinterpret_cast<uint2 *>(sW + col * LD + 4 * c4) = v;
+        }
+      } else if (!WT) {
         for (int e = threadIdx.x; e < TC * q; e += 256) {
           const int col = e / q, c4 = e - col * q;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,6 +218,18 @@ int vlp3d_internal_linear_tile(const float *X, int ldx, const float *W, int ldw,
   if (transposed_weight) { if (TRr == 32) VLP3D_LT(true, 32); else VLP3D_LT(true, 64); }
   else { if (TRr == 32) VLP3D_LT(false, 32); else VLP3D_LT(false, 64); }
 #undef VLP3D_LT
+  VLP3D_LAUNCH_CHECK();
+  return 0;
+}
+
+// Y (R x ncols) = X (R x kdim) W^T with W (ncols x kdim) ALREADY bf16 (row stride ldw elements): csrc/sa_gather_sum.hip.
+int vlp3d_internal_linear_tile_w16(const float *X, int ldx, const void *Wbf16, int ldw, int kdim, int ncols, long long R,
+                                   float *Y, int ldy, hipStream_t stream) {
+  if (kdim % 16 || ncols % 4 || ldw % 4 || R < 1) return -22;
+  const long long nblk = (R + 63) / 64;
+  const dim3 grid((unsigned)(nblk < 4096 ? nblk : 4096), (unsigned)((ncols + TC - 1) / TC));
+  hipLaunchKernelGGL((linear_tile_kernel<false, 64, true>), grid, dim3(256), 0, stream, X, ldx, (const float *)Wbf16, ldw, kdim, ncols,
+                     (const float *)nullptr, (const float *)nullptr, R, Y, ldy);
   VLP3D_LAUNCH_CHECK();
   return 0;
 }

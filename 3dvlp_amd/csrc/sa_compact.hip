@@ -82,7 +82,52 @@ __global__ __launch_bounds__(256) void sa_fill_kernel(const int *__restrict__ id
   crow[r0 + s] = make_int4(b * N + idx[t], (bm << 8) | s, __float_as_int(w), 0);
 }
 
+// ---- inverse map: for every source point the rows that gather it (CSR) ---------------------------------------------------
+// The backward of a gather layer adds each row's input gradient to its source point.  With this map the sum is a GATHER
+// per point (no atomics, csrc/sa_gather_sum.hip).  rows = compact rows u < P (crow given) or all B*M*S padded rows.
+__global__ __launch_bounds__(256) void sa_inv_count_kernel(const int *__restrict__ idx, const int4 *__restrict__ crow,
+                                                           const int *__restrict__ rowptr, int nb, int N, long long MS,
+                                                           long long R, int *__restrict__ cnt) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = crow ? (long long)rowptr[nb] : R;
+  if (t >= n) return;
+  const int p = crow ? crow[t].x : (int)((t / MS) * N) + idx[t];
+  atomicAdd(cnt + p, 1);
+}
+__global__ __launch_bounds__(256) void sa_inv_fill_kernel(const int *__restrict__ idx, const int4 *__restrict__ crow,
+                                                          const int *__restrict__ rowptr, int nb, int N, long long MS,
+                                                          long long R, const int *__restrict__ start, int *__restrict__ cursor,
+                                                          int *__restrict__ rows) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = crow ? (long long)rowptr[nb] : R;
+  if (t >= n) return;
+  const int p = crow ? crow[t].x : (int)((t / MS) * N) + idx[t];
+  rows[start[p] + atomicAdd(cursor + p, 1)] = (int)t;
+}
+
 }  // namespace
+
+// inv_start (B*N + 1), inv_rows (B*M*S), cursor (B*N) scratch.  crow / rowptr: the compact map of vlp3d_sa_compact or NULL.
+// The order of a point's rows follows the atomics (any order: the consumer sums them).
+extern "C" int vlp3d_sa_inverse(const int *idx, const void *crow, const int *rowptr, int B, int N, int M, int S, int *inv_start,
+                                int *inv_rows, int *cursor, void *stream) {
+  if (!idx || !inv_start || !inv_rows || !cursor || (crow && !rowptr) || B < 1 || N < 1 || M < 1 || S < 1 ||
+      (long long)B * N >= (1ll << 30) || (long long)B * M * S >= (1ll << 31))
+    return VLP3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int np = B * N, nb = B * M;
+  const long long R = (long long)nb * S, MS = (long long)M * S;
+  hipError_t e = vlp3d_zero_words(inv_start, (size_t)np + 1, s);
+  if (e == hipSuccess) e = vlp3d_zero_words(cursor, (size_t)np, s);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((unsigned)((R + 255) / 256));
+  hipLaunchKernelGGL(sa_inv_count_kernel, grid, dim3(256), 0, s, idx, (const int4 *)crow, rowptr, nb, N, MS, R, inv_start);
+  hipLaunchKernelGGL(sa_scan_kernel, dim3(1), dim3(1024), 0, s, inv_start, np);
+  hipLaunchKernelGGL(sa_inv_fill_kernel, grid, dim3(256), 0, s, idx, (const int4 *)crow, rowptr, nb, N, MS, R, inv_start, cursor,
+                     inv_rows);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
 
 // rowptr: (B*M + 1) ints; crow: (B*M*S) int4 (worst case: every row distinct).  S <= 255, B*M < 2^23, B*N < 2^31.
 extern "C" int vlp3d_sa_compact(const int *idx, int B, int N, int M, int S, int *rowptr, void *crow, void *stream) {

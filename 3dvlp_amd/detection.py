@@ -43,6 +43,8 @@ class Pointnet2Backbone(nn.Module):
                                          use_xyz=True, normalize_xyz=True)
         self.sa4 = PointnetSAModuleVotes(npoint=256, radius=1.2, nsample=16, mlp=[256, 128, 128, 256],
                                          use_xyz=True, normalize_xyz=True)
+        for sa in (self.sa2, self.sa3, self.sa4):  # their input features take a gradient, their coordinates do not
+            sa.csr_backward = True
         self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
         self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
 

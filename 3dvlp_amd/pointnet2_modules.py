@@ -60,6 +60,9 @@ class PointnetSAModuleVotes(nn.Module):
         # else fp32); torch.bfloat16 selects the bf16 kernels explicitly while the rest of the model stays fp32
         self.mlp_dtype = None
         self.compact = os.environ.get("VLP3D_SA_COMPACT", "1") != "0"
+        # True (set by the backbone for sa2..sa4): also build the point -> rows map, and sum the gather layer's input
+        # gradient per point through it instead of scattering it with float atomics (csrc/sa_gather_sum.hip)
+        self.csr_backward = False
 
     @torch.no_grad()
     def compute_geometry(self, xyz, fps_ordered=False):
@@ -70,7 +73,10 @@ class PointnetSAModuleVotes(nn.Module):
         new_xyz = sa_fused_ext.gather_xyz(xyz.contiguous(), inds)  # == gather_operation on the transposed cloud, one launch
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         if self._use_compact(xyz):
-            return (inds, new_xyz, idx) + tuple(sa_fused_ext.sa_compact(idx, xyz.shape[1]))  # + (rowptr, crow)
+            cmap = tuple(sa_fused_ext.sa_compact(idx, xyz.shape[1]))                       # + (rowptr, crow)
+            if self.csr_backward and os.environ.get("VLP3D_SA_CSR", "1") != "0":
+                return (inds, new_xyz, idx) + cmap + tuple(sa_fused_ext.sa_inverse(idx, xyz.shape[1], cmap))  # + (inv_start, inv_rows)
+            return (inds, new_xyz, idx) + cmap
         return inds, new_xyz, idx
 
     def _use_compact(self, xyz):
@@ -85,10 +91,11 @@ class PointnetSAModuleVotes(nn.Module):
         (B, npoint, nsample); the first layer's weight columns are permuted to [features | xyz | 0]."""
         B, N, _ = xyz.shape
         M, S = self.npoint, self.nsample
-        cmap = None
+        cmap = inv = None
         if geometry is not None:
             inds, new_xyz, idx = geometry[:3]
             cmap = tuple(geometry[3:5]) if len(geometry) >= 5 else None
+            inv = tuple(geometry[5:7]) if len(geometry) >= 7 else None
         else:
             new_xyz = pointnet2_utils.gather_xyz(xyz, inds)  # gather_operation on the transposed cloud, without the transposes
             idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
@@ -99,8 +106,11 @@ class PointnetSAModuleVotes(nn.Module):
         if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S, M):
             if cmap is None and geometry is None and self._use_compact(xyz):
                 cmap = sa_fused_ext.sa_compact(idx, N)
+                if self.csr_backward and os.environ.get("VLP3D_SA_CSR", "1") != "0" and torch.is_grad_enabled():
+                    inv = sa_fused_ext.sa_inverse(idx, N, cmap)
+            bf = dtype == torch.bfloat16
             pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm.float(), self.radius if self.normalize_xyz else 1.0,
-                                          self.mlp_module, dtype == torch.bfloat16, cmap if dtype == torch.bfloat16 else None)
+                                          self.mlp_module, bf, cmap if bf else None, inv if bf else None)
             return new_xyz, pooled.transpose(1, 2), inds
         x = pointnet2_utils.group_rows(xyz, new_xyz, idx, feat_pm, self.radius if self.normalize_xyz else 1.0, dtype)
         for i, layer in enumerate(self.mlp_module):

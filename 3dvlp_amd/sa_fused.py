@@ -45,8 +45,11 @@ class FusedSAMLP(Function):
     """(xyz, new_xyz, idx, feat_pm, W1,g1,b1, W2,g2,b2, W3,g3,b3) -> pooled (B*M, C3) fp32."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, *params):
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, inv, *params):
         W, gam, bet = params[0::3], params[1::3], params[2::3]
+        # inv = (inv_start, inv_rows) of _lib.sa_inverse: backward sums the gather layer's input gradient per point through
+        # this map (no atomics, csrc/sa_gather_sum.hip) — bf16 rows, feature gradients only
+        ctx.inv = inv if (inv is not None and use_bf16) else None
         # cmap = (rowptr, crow) of _lib.sa_compact: the stack then runs on the DISTINCT rows of every ball (bf16 only)
         cm = (cmap[1], cmap[0], idx.shape[0] * idx.shape[1]) if (cmap is not None and use_bf16) else (None, None, 0)
         B, N, _ = xyz.shape
@@ -118,7 +121,8 @@ class FusedSAMLP(Function):
         nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))
         # ONE zero-filled arena per backward (one fill launch): [t3 (2 x C3 fp64) | d(features) | d(xyz) | d(new_xyz)]
         n_t3 = 4 * cout[2]
-        n_df = B * N * C if need[3] else 0
+        csr = ctx.inv is not None and need[3] and not need[0] and not need[1] and cout[0] in (64, 128)
+        n_df = B * N * C if (need[3] and not csr) else 0
         n_dx = B * N * 3 if need[0] else 0
         n_dn = B * M * 3 if need[1] else 0
         arena = torch.zeros((n_t3 + n_df + n_dx + n_dn,), dtype=torch.float32, device=dev)
@@ -163,7 +167,12 @@ class FusedSAMLP(Function):
                     dparams[0] = dW.view(cout[0], C + 3, 1, 1)
                 else:
                     dparams[0] = torch.cat([dW[:, C:C + 3], dW[:, :C]], dim=1).view(cout[0], C + 3, 1, 1)
-                if need[0] or need[1] or need[3]:
+                if csr:  # d(features) by a per-point gather of the layer-1 rows + one product: every element written once
+                    dfeat = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+                    gsum = torch.empty((B * N, cout[0]), dtype=torch.float32, device=dev)
+                    _ext.call("vlp3d_sa_bwd_gather_csr", G, Y[0], cout[0], c5, WTs[0], cm[0], ctx.inv[0], ctx.inv[1], B, N, C,
+                              gsum, dfeat)
+                elif need[0] or need[1] or need[3]:
                     kpad = WTs[0].shape[0]
                     o = n_t3
                     dfeat = arena[o:o + n_df].view(B, N, C) if need[3] else None
@@ -171,16 +180,17 @@ class FusedSAMLP(Function):
                     dnew = arena[o + n_df + n_dx:].view(B, M, 3) if need[1] else None
                     _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
                               dxyz, dnew, bf, *cm)
-        return (dxyz, dnew, None, dfeat, None, None, None, None, None, *dparams)
+        return (dxyz, dnew, None, dfeat, None, None, None, None, None, None, *dparams)
 
 
-def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None):
+def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None, inv=None):
     """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32.
-    cmap: (rowptr, crow) of _lib.sa_compact(idx, N) — evaluate the stack on the distinct rows only (bf16 configuration)."""
+    cmap: (rowptr, crow) of _lib.sa_compact(idx, N) — evaluate the stack on the distinct rows only (bf16 configuration);
+    inv: (inv_start, inv_rows) of _lib.sa_inverse(idx, N, cmap) — atomic-free backward of the gather (bf16 configuration)."""
     bns = [layer.bn.bn for layer in mlp_module]
     params = []
     for layer in mlp_module:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
     B, M = new_xyz.shape[:2]
-    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, *params)
+    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, inv, *params)
     return out.view(B, M, -1)

@@ -620,6 +620,17 @@ int vlp3d_sa_bn_fold_shift(const double *stats, int nslab, const float *gamma, c
                            float *running_var, int C, long long R, float eps, float momentum, int training, float *vec,
                            const float *mean_shift, void *stream);
 
+/* Atomic-free backward of a grouped MLP's gather layer (bf16 configuration; pointnet2_modules.py:233-267 backward through
+ * grouping_operation): vlp3d_sa_inverse builds, next to the ball query, the point -> rows map (inv_start (B*N+1), inv_rows
+ * (B*M*S); cursor (B*N) scratch; crow / rowptr = the compact map or NULL); vlp3d_sa_bwd_gather_csr sums the layer-1
+ * BatchNorm-backward rows of every point (Gsum (B*N, c0) scratch) and multiplies by the prepared W1^T (kpad x c0 bf16):
+ * d(features) (B*N, C), every element written once. */
+int vlp3d_sa_inverse(const int *idx, const void *crow, const int *rowptr, int B, int N, int M, int S, int *inv_start,
+                     int *inv_rows, int *cursor, void *stream);
+int vlp3d_sa_bwd_gather_csr(const void *G, const void *Y, int c0, const float *bn5, const void *WT, const void *crow,
+                            const int *inv_start, const int *inv_rows, int B, int N, int C, float *Gsum, float *dfeat_pm,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

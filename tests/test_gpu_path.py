@@ -1263,7 +1263,7 @@ def test_row_stack_final_prelu_equals_fp64_formula(training):
         assert _rel(b.grad, bd.grad) < 2e-4
 
 
-@pytest.mark.parametrize("S,need_xyz_grad,C", [(64, False, 60), (32, True, 60), (16, True, 256)])
+@pytest.mark.parametrize("S,need_xyz_grad,C", [(64, False, 60), (32, True, 60), (16, True, 256), (16, False, 256), (32, False, 128)])
 def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad, C):
     """The grouped MLP on the DISTINCT rows of every ball (csrc/sa_compact.hip: ball-query padding removed, multiplicities
     in the BatchNorm sums and the BatchNorm-backward term) equals the padded evaluation: pooled output, running
@@ -1296,6 +1296,22 @@ def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad, C):
         res.append(dict(out=out.detach(), df=f.grad, dx=x.grad if need_xyz_grad else None,
                         params=[p.grad for p in m.parameters()], bufs=[b.clone() for b in m.buffers()]))
     a, b = res
+    if not need_xyz_grad:
+        # ... and the atomic-free backward of the gather layer (csrc/sa_gather_sum.hip: per-point gather of the layer-1 rows
+        # through the inverse map + one product) against the scatter form, same compact rows: d(features) to bf16 rounding
+        torch.manual_seed(5)
+        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=S, mlp=[C, 64, 64, 128] if C < 128 else [C, 128, 128, 256], use_xyz=True,
+                                     normalize_xyz=True).cuda().train()
+        m.mlp_dtype, m.compact, m.csr_backward = torch.bfloat16, True, True
+        f = feats0.clone().requires_grad_(True)
+        geo = m.compute_geometry(xyz)
+        assert len(geo) == 7 and int(geo[5][-1]) == int(geo[3][-1])      # every compact row is listed under exactly one point
+        _, out, _ = m(xyz, f, geometry=geo)
+        out.backward(g)
+        assert _rel(out.detach(), b["out"]) < 1e-6
+        assert _rel(f.grad, b["df"]) < 6e-3, _rel(f.grad, b["df"])
+        for pc, pb in zip([p.grad for p in m.parameters()], b["params"]):
+            assert _rel(pc, pb) < 1e-5
     assert _rel(b["out"], a["out"]) < 2e-3
     assert _rel(b["df"], a["df"]) < 2e-2
     if need_xyz_grad:
