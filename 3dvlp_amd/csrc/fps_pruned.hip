@@ -184,10 +184,13 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
 }
 
 // NS = slots per lane: a wave holds 64 * NS slots of 64 points, i.e. N <= 65536 * NS (NS = 2: cfg5's 80 000-point scenes).
-template <int NS>
+// PROF: thread 0 of every workgroup accumulates s_memtime deltas of the iteration's phases into prof[blockIdx.x][0..5]
+// (tools/fps_phases.py; the production instantiation PROF = false carries no trace of it).
+template <int NS, bool PROF = false>
 __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restrict__ xyz_all, float4 *__restrict__ pts_all,
                                                            const int *__restrict__ perm_all, int *__restrict__ idx_all,
-                                                           int N, int m, int log2P, int L, int m_lds) {
+                                                           int N, int m, int log2P, int L, int m_lds,
+                                                           unsigned long long *__restrict__ prof = nullptr) {
   extern __shared__ float4 lpts[];  // [L][1024]: slots 0..L-1 of every wave; then int s_out[m_lds]: sorted positions
   int *s_out = reinterpret_cast<int *>(lpts + (size_t)L * 1024);  // of the samples (idx = perm[pos], written at the end)
   __shared__ unsigned s_val[2][16], s_pos[2][16];
@@ -261,6 +264,14 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   int par = 0;
   __syncthreads();
 
+  unsigned long long ph[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tq = 0ull;
+#define FPS_MARK(k)                                        \
+  if (PROF) {                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ph[k] += now_ - tq;                                    \
+    tq = now_;                                             \
+  }
+  if (PROF) tq = __builtin_readcyclecounter();
   for (int j = 1; j < m; ++j) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
@@ -270,6 +281,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
       const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
       const bool active = (lane + 64 * q < nslots) && (sval[q] != 0u) && (lb2 < __uint_as_float(sval[q] - 1u));
       unsigned long long todo = __ballot(active);
+      FPS_MARK(0)  // bounding-box test of the cached slots + ballot
       while (todo != 0ull) {  // wave-uniform loop over this wave's active slots, four at a time
         int si[4];
         float4 p[4];
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
         }
       }
     }
+    FPS_MARK(1)  // distance updates of the active slots (+ their slot maxima)
     // this lane's better slot (NS = 2): larger value; an exact tie is decided by the reference's order of the two winners
     unsigned lv = sval[0];
     int lsl = lane, lwl = swl[0];
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     if (vw != 0u) cl = winner_lane(mine, vw, min(lsl * 1024 + wave * 64 + lwl, N - 1));
     const int cwl = __builtin_amdgcn_readlane(lwl, cl), csl = __builtin_amdgcn_readlane(lsl, cl);
     const float cx = readlane_f32(lx, cl), cy = readlane_f32(ly, cl), cz = readlane_f32(lz, cl);
+    FPS_MARK(2)  // wave candidate: reduction over the lanes' cached slot maxima, winner's coordinates by readlane
     if (lane == 0) {
       s_val[par][wave] = vw;
       s_pos[par][wave] = (unsigned)(csl * 1024 + wave * 64 + cwl);
@@ -340,6 +354,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait ~1 us for the acknowledgement of the
     // temp stores of global slots and of the sample list — nobody else reads those before the kernel ends
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FPS_MARK(3)  // LDS write of the candidate + the workgroup barrier (= waiting for the slowest wave)
     // block winner, computed redundantly by every wave from the 16 candidates (no second barrier)
     const unsigned bv = lane < 16 ? s_val[par][lane] : 0u;
     const unsigned bpos = lane < 16 ? s_pos[par][lane] : 0u;
@@ -359,7 +374,11 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
       }
     }
     par ^= 1;
+    FPS_MARK(4)  // block reduction over the 16 wave candidates, next sample's coordinates from LDS
   }
+#undef FPS_MARK
+  if (PROF && tid == 0)
+    for (int k = 0; k < 5; ++k) prof[(size_t)b * 8 + k] = ph[k];
   if (m_lds) {  // sorted position -> original index, all threads
     __syncthreads();
     for (int j = 1 + tid; j < m; j += 1024) idx[j] = s_out[j] < 0 ? 0 : perm[s_out[j]];
@@ -386,8 +405,25 @@ extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
 // Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
 // Requires N <= 131072 (64 slots per wave and lane-slot; two lane-slots above 65536); same output as
 // vlp3d_furthest_point_sampling.
+static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
+                             unsigned long long *prof, void *stream);
+
 extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
                                                     long long workspace_bytes, int *idx, void *stream) {
+  return fps_pruned_launch(xyz, B, N, m, workspace, workspace_bytes, idx, nullptr, stream);
+}
+
+// Same sampling with the main kernel's per-phase cycle counts: phases (B x 8) u64, entries 0..4 of scene b = shader-clock
+// cycles thread 0 spent in [slot test | slot updates | wave candidate | LDS + barrier | block reduction] summed over the
+// m - 1 iterations (tools/fps_phases.py).  N <= 65536.
+extern "C" int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes,
+                                        int *idx, unsigned long long *phases, void *stream) {
+  if (!phases || N > 65536) return VLP3D_EINVAL;
+  return fps_pruned_launch(xyz, B, N, m, workspace, workspace_bytes, idx, phases, stream);
+}
+
+static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
+                             unsigned long long *prof, void *stream) {
   if (!xyz || !workspace || !idx || B < 1 || N < 1 || N > 131072 || m < 0 ||
       workspace_bytes < vlp3d_fps_workspace_bytes(B, N))
     return VLP3D_EINVAL;
@@ -418,10 +454,15 @@ extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int
     hipError_t e = hipFuncSetAttribute((const void *)fps_pruned_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)fps_pruned_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)fps_pruned_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  if (nslots <= 64)
+  if (prof)
+    hipLaunchKernelGGL((fps_pruned_kernel<1, true>), dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N),
+                       L, m_lds, prof);
+  else if (nslots <= 64)
     hipLaunchKernelGGL(fps_pruned_kernel<1>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N), L,
                        m_lds);
   else

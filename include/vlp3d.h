@@ -518,6 +518,10 @@ int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
 /* vlp3d_stamp: one thread writes the 100 MHz device clock to *slot (in-stream time stamps bracketing a kernel inside a
  * captured step); vlp3d_probe_empty: a kernel that does nothing on a (blocks, threads) grid — the launch floor. */
+/* vlp3d_fps_pruned_profile: vlp3d_furthest_point_sampling_pruned + per-phase shader-clock counts of the main kernel's
+ * iteration (phases: (B, 8) u64, entries 0..4: slot test | slot updates | wave candidate | LDS + barrier | block reduction). */
+int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
+                             unsigned long long *phases, void *stream);
 int vlp3d_stamp(unsigned long long *slot, void *stream);
 int vlp3d_probe_empty(int blocks, int threads, int *sink, void *stream);
 
