@@ -193,8 +193,11 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
                                                            unsigned long long *__restrict__ prof = nullptr) {
   extern __shared__ float4 lpts[];  // [L][1024]: slots 0..L-1 of every wave; then int s_out[m_lds]: sorted positions
   int *s_out = reinterpret_cast<int *>(lpts + (size_t)L * 1024);  // of the samples (idx = perm[pos], written at the end)
-  __shared__ unsigned s_val[2][16], s_pos[2][16];
-  __shared__ float s_xyz[2][16][3];
+  // per parity and wave: the wave's candidate (value, sorted position) and its coordinates.  Lanes 0..15 fetch BOTH for
+  // "their" wave right after the barrier (independent reads, in flight together); the winner's coordinates then come from
+  // the winner LANE by v_readlane instead of a second, dependent LDS round trip (round 3: -150 cycles of the 670-cycle tail)
+  __shared__ uint2 s_vp[2][16];
+  __shared__ float4 s_xyz4[2][16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
@@ -314,12 +317,21 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
             const float t = vmin(d, p[u].w);
             if (si[u] < L) lpts[si[u] * 1024 + tid].w = t;
             else if (valid) pts[pos].w = t;
-            const unsigned v = value_of(t, valid);
-            const unsigned vmax = wave_max_u32(v);
-            int wl = 0;
-            if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
-            const float wx = readlane_f32(p[u].x, wl), wy = readlane_f32(p[u].y, wl), wz = readlane_f32(p[u].z, wl);
-            if (lane + 64 * q == si[u]) { sval[q] = vmax; swl[q] = wl; sx[q] = wx; sy[q] = wy; sz[q] = wz; }
+            // The slot's cached maximum is still right unless the point that HOLDS it moved (values only decrease): only
+            // then is the slot reduced again (round 3: the reduction + winner + three readlanes were ~2/3 of an update's
+            // work, and the workgroup waits at the barrier for its slowest wave — tools/fps_phases.py).  Tried and rejected:
+            // issuing the four slots of a batch as straight-line code with interleaved reductions (absent slots as
+            // dummies): 2.79 -> 4.83 ms — most batches hold ONE slot, and 16 waves on one CU are bound by instruction issue,
+            // not by the latency of a wave's own chain.
+            const int wl_old = __builtin_amdgcn_readlane(swl[q], si[u] - 64 * q);
+            if (__ballot(lane == wl_old && t < p[u].w) != 0ull) {  // wave-uniform
+              const unsigned v = value_of(t, valid);
+              const unsigned vmax = wave_max_u32(v);
+              int wl = 0;
+              if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
+              const float wx = readlane_f32(p[u].x, wl), wy = readlane_f32(p[u].y, wl), wz = readlane_f32(p[u].z, wl);
+              if (lane + 64 * q == si[u]) { sval[q] = vmax; swl[q] = wl; sx[q] = wx; sy[q] = wy; sz[q] = wz; }
+            }
           }
         }
       }
@@ -347,24 +359,26 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     const float cx = readlane_f32(lx, cl), cy = readlane_f32(ly, cl), cz = readlane_f32(lz, cl);
     FPS_MARK(2)  // wave candidate: reduction over the lanes' cached slot maxima, winner's coordinates by readlane
     if (lane == 0) {
-      s_val[par][wave] = vw;
-      s_pos[par][wave] = (unsigned)(csl * 1024 + wave * 64 + cwl);
-      s_xyz[par][wave][0] = cx; s_xyz[par][wave][1] = cy; s_xyz[par][wave][2] = cz;
+      s_vp[par][wave] = make_uint2(vw, (unsigned)(csl * 1024 + wave * 64 + cwl));
+      s_xyz4[par][wave] = make_float4(cx, cy, cz, 0.f);
     }
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait ~1 us for the acknowledgement of the
     // temp stores of global slots and of the sample list — nobody else reads those before the kernel ends
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     FPS_MARK(3)  // LDS write of the candidate + the workgroup barrier (= waiting for the slowest wave)
     // block winner, computed redundantly by every wave from the 16 candidates (no second barrier)
-    const unsigned bv = lane < 16 ? s_val[par][lane] : 0u;
-    const unsigned bpos = lane < 16 ? s_pos[par][lane] : 0u;
+    const uint2 vp = s_vp[par][lane & 15];
+    const float4 cxyz = s_xyz4[par][lane & 15];
+    const unsigned bv = lane < 16 ? vp.x : 0u;
+    const unsigned bpos = lane < 16 ? vp.y : 0u;
     const unsigned bmax = wave_max_u32(bv);
     if (bmax != 0u) {
       const int wi = winner_lane(bv, bmax, (int)min(bpos, (unsigned)(N - 1)));
-      x1 = s_xyz[par][wi][0]; y1 = s_xyz[par][wi][1]; z1 = s_xyz[par][wi][2];
+      x1 = readlane_f32(cxyz.x, wi); y1 = readlane_f32(cxyz.y, wi); z1 = readlane_f32(cxyz.z, wi);
       if (tid == 0) {
-        if (m_lds) s_out[j] = (int)s_pos[par][wi];
-        else idx[j] = perm[s_pos[par][wi]];
+        const unsigned wpos = (unsigned)__builtin_amdgcn_readlane((int)vp.y, wi);
+        if (m_lds) s_out[j] = (int)wpos;
+        else idx[j] = perm[wpos];
       }
     } else {  // no candidate left (every point skipped): the reference returns index 0
       x1 = xyz[0]; y1 = xyz[1]; z1 = xyz[2];

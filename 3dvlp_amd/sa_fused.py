@@ -15,11 +15,14 @@ from . import _lib as _ext
 
 _ext.load()
 
-WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 512))  # most workgroups (= partial dW slabs) of the weight-gradient kernel
+# most workgroups (= partial dW slabs) of the weight-gradient kernel.  Round 3: 512 / no slab cap -> 2048 / 32 MB: layers with a
+# small dW (SA1: 16-36 KB) get up to 2048 workgroups (their tiles are staging-latency bound: 4.5 us per 32-row tile at two
+# workgroups per CU), layers with a large dW (131-147 KB) fewer than before; 5.34 -> 5.30 ms per step
+WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 2048))
 WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
 
 
-WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 1024))  # cap on the partial-dW slabs of one launch
+WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 32))  # cap on the partial-dW slabs of one launch
 
 
 def _wgrad_blocks(R, cout, K):
