@@ -1126,29 +1126,61 @@ __device__ __forceinline__ float4 load_dy4(const RowGemmArgs &a, int row, int co
 }
 
 // bf16 storage: 8 consecutive columns per staging element — ONE 16-byte load per operand (8-byte loads run at 0.54-0.70
-// of the 16-byte rate, MI355X_MICROARCH.md) — returned packed as bf16 for the LDS tile.
+// of the 16-byte rate, MI355X_MICROARCH.md), staged packed as bf16 in the LDS tile.
+// Split loader of the weight-gradient kernel: `issue` only requests the operands (they stay in registers
+// while the previous tile is contracted), `finish` does the arithmetic when the tile is written to LDS.  meta = words 1, 2
+// of the row's compact-map entry ((ball << 8) | position in the ball, multiplicity), fetched ONE TILE FURTHER AHEAD, so
+// that no request of a tile waits for another: the one-piece loader sat through up to eight dependent memory round trips
+// per tile (map entry -> pooled gradient -> multiplicity, per staging element, each behind s_waitcnt vmcnt(0)) — 9.7 us per
+// 32-row tile of SA1's last layer, 1.2 TB/s.
+struct DyRaw8 {
+  uint4 y, g;   // g: the gradient chunk, or the bits of dP[0..3] of the row's ball (pooled form)
+  float4 dp1;   // pooled form: dP[4..7]
+  uint2 sel;    // pooled form: the arg-max sample of the 8 channels
+};
+
 template <int DYL>
-__device__ __forceinline__ uint4 load_dy8_bf(const RowGemmArgs &a, int row, int col0, const DyConsts<bf16> &klo,
-                                             const DyConsts<bf16> &khi) {
-  const uint4 yr = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
-  if (DYL == PLAIN) return yr;
-  float y[8], g[8];
-  unpack8(yr, y);
+__device__ __forceinline__ void dy8_issue(const RowGemmArgs &a, int row, int col0, int2 meta, DyRaw8 &w) {
+  w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
+  if (DYL == PLAIN) return;
   if (a.pool_g != nullptr) {  // kernel-uniform
-    int bm, sidx;
-    ball_of_row(a, row, bm, sidx);
+    const int bm = a.crow ? (meta.x >> 8) : (a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S));
     const long long off = (long long)bm * a.ldin + col0;
-    const float4 d0 = ld4(a.pool_g + off), d1 = ld4(a.pool_g + off + 4);
-    const uint2 sl = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
-    g[0] = (int)(sl.x & 255u) == sidx ? d0.x : 0.f;         g[1] = (int)((sl.x >> 8) & 255u) == sidx ? d0.y : 0.f;
-    g[2] = (int)((sl.x >> 16) & 255u) == sidx ? d0.z : 0.f; g[3] = (int)(sl.x >> 24) == sidx ? d0.w : 0.f;
-    g[4] = (int)(sl.y & 255u) == sidx ? d1.x : 0.f;         g[5] = (int)((sl.y >> 8) & 255u) == sidx ? d1.y : 0.f;
-    g[6] = (int)((sl.y >> 16) & 255u) == sidx ? d1.z : 0.f; g[7] = (int)(sl.y >> 24) == sidx ? d1.w : 0.f;
+    const float4 d0 = ld4(a.pool_g + off);
+    w.g = make_uint4(__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z), __float_as_uint(d0.w));
+    w.dp1 = ld4(a.pool_g + off + 4);
+    w.sel = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
   } else {
-    unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0), g);
+    w.g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Gin) + (long long)row * a.ldin + col0);
   }
-  if (a.crow) {  // compact rows: dY summed over the copies = k1 G + w (cb y + cc)  (bf16 folded constants: k1, k2 = cb, k3 = cc)
-    const float mult = row_weight(a, row);
+}
+
+template <int DYL>
+__device__ __forceinline__ uint4 dy8_finish(const RowGemmArgs &a, int row, int2 meta, const DyRaw8 &w,
+                                            const DyConsts<bf16> &klo, const DyConsts<bf16> &khi) {
+  if (DYL == PLAIN) return w.y;
+  float y[8], g[8];
+  unpack8(w.y, y);
+  if (a.pool_g != nullptr) {  // kernel-uniform
+    int sidx;
+    if (a.crow) {
+      sidx = meta.x & 255;
+    } else {
+      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+      sidx = row - bm * a.pool_S;
+    }
+    const float d0[4] = {__uint_as_float(w.g.x), __uint_as_float(w.g.y), __uint_as_float(w.g.z), __uint_as_float(w.g.w)};
+    const float d1[4] = {w.dp1.x, w.dp1.y, w.dp1.z, w.dp1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g[i] = (int)((w.sel.x >> (8 * i)) & 255u) == sidx ? d0[i] : 0.f;
+      g[4 + i] = (int)((w.sel.y >> (8 * i)) & 255u) == sidx ? d1[i] : 0.f;
+    }
+  } else {
+    unpack8(w.g, g);
+  }
+  if (a.crow) {  // compact rows: dY summed over the copies = k1 G + w (cb y + cc)
+    const float mult = __int_as_float(meta.y);
     float o[8];
     const float ca[8] = {klo.k1.x, klo.k1.y, klo.k1.z, klo.k1.w, khi.k1.x, khi.k1.y, khi.k1.z, khi.k1.w};
     const float cb[8] = {klo.k2.x, klo.k2.y, klo.k2.z, klo.k2.w, khi.k2.x, khi.k2.y, khi.k2.z, khi.k2.w};
@@ -1231,7 +1263,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[ST16 ? 1 : NE_DY], va[A8 ? 1 : MAXE_A], vt;
   constexpr int MAXE_A8 = (MAXE_A + 1) / 2;
-  uint4 pdy[ST16 ? NE_DY8 : 1], pa8[A8 ? MAXE_A8 : 1];
+  uint4 pa8[A8 ? MAXE_A8 : 1];         // bf16 storage: RAW operands of the next tile (arithmetic at the LDS store)
+  DyRaw8 rdy[ST16 ? NE_DY8 : 1];
+  int2 mc[ST16 ? NE_DY8 : 1], mn[ST16 ? NE_DY8 : 1];  // compact-map words of the rows in rdy / of the tile after it
   const int kf8 = KF / 8, nef8 = 32 * kf8, kfs8 = A8 ? __builtin_ctz(kf8 > 0 ? kf8 : 1) : 0;
 
   // column-block mode (gy > 1): this workgroup owns columns [coff, coff + COUT) of a wider dY — a 256-wide layer
@@ -1290,7 +1324,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
 #pragma unroll
       for (int j = 0; j < NE_DY8; ++j) {
         const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
-        pdy[j] = load_dy8_bf<DYL>(w.dy, row0 + e / (COUT / 8), coff + (e % (COUT / 8)) * 8, dyk, dyk2);
+        dy8_issue<DYL>(w.dy, row0 + e / (COUT / 8), coff + (e % (COUT / 8)) * 8, mc[j], rdy[j]);
       }
     } else {
 #pragma unroll
@@ -1304,18 +1338,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
       for (int j = 0; j < MAXE_A8; ++j) {
         const int e = min((int)threadIdx.x + 256 * j, nef8 - 1);
         const int row = e >> kfs8, k0 = (e - (row << kfs8)) * 8;
-        const uint4 yr = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(w.src.Yin) +
-                                                          (long long)(row0 + row) * w.src.ldin + k0);
-        if (LOADER == BNRELU) {
-          float y[8];
-          unpack8(yr, y);
-          pa8[j] = pack8(make_float4(fmaxf(0.f, y[0] * a_sc.x + a_sh.x), fmaxf(0.f, y[1] * a_sc.y + a_sh.y),
-                                     fmaxf(0.f, y[2] * a_sc.z + a_sh.z), fmaxf(0.f, y[3] * a_sc.w + a_sh.w)),
-                         make_float4(fmaxf(0.f, y[4] * a_sc2.x + a_sh2.x), fmaxf(0.f, y[5] * a_sc2.y + a_sh2.y),
-                                     fmaxf(0.f, y[6] * a_sc2.z + a_sh2.z), fmaxf(0.f, y[7] * a_sc2.w + a_sh2.w)));
-        } else {
-          pa8[j] = yr;
-        }
+        pa8[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(w.src.Yin) +
+                                                  (long long)(row0 + row) * w.src.ldin + k0);
       }
     }
 #pragma unroll
@@ -1345,10 +1369,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
     }
   };
 
+  auto fetch_meta = [&](long long tile) {  // -> mn
+    if constexpr (ST16) {
+      const int row0 = (int)(tile * 32);
+#pragma unroll
+      for (int j = 0; j < NE_DY8; ++j) {
+        const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
+        mn[j] = make_int2(0, 0);
+        if (DYL == BNBWD && w.dy.crow) {  // kernel-uniform
+          const int4 c = w.dy.crow[row0 + e / (COUT / 8)];
+          mn[j] = make_int2(c.y, c.z);
+        }
+      }
+    }
+  };
+  auto take_meta = [&]() {
+    if constexpr (ST16) {
+#pragma unroll
+      for (int j = 0; j < NE_DY8; ++j) mc[j] = mn[j];
+    }
+  };
   if (t0 < t1) {
     fetch_idx(t0);
+    fetch_meta(t0);
+    take_meta();
     fetch(t0);
     fetch_idx(min(t0 + 1, t1 - 1));
+    fetch_meta(min(t0 + 1, t1 - 1));
   }
   for (long long tile = t0; tile < t1; ++tile) {
     __syncthreads();  // the previous tile's MFMA reads are done
@@ -1359,9 +1406,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         for (int j = 0; j < NE_DY8; ++j) {
           const int e = threadIdx.x + 256 * j;
           if (e < 32 * COUT / 8) {
+            const uint4 v = dy8_finish<DYL>(w.dy, (int)(tile * 32) + e / (COUT / 8), mc[j], rdy[j], dyk, dyk2);
             short *q = ldb_dy + (e / (COUT / 8)) * RSD + (e % (COUT / 8)) * 8;
-            *reinterpret_cast<uint2 *>(q) = make_uint2(pdy[j].x, pdy[j].y);
-            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pdy[j].z, pdy[j].w);
+            *reinterpret_cast<uint2 *>(q) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(v.z, v.w);
           }
         }
       } else {  // fp32 storage, bf16 MFMA: 4-column (16-byte) elements rounded here
@@ -1377,9 +1425,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
           const int e = threadIdx.x + 256 * j;
           if (e < nef8) {
             const int row = e >> kfs8;
+            uint4 v = pa8[j];
+            if (LOADER == BNRELU) {
+              float y[8];
+              unpack8(v, y);
+              v = pack8(make_float4(fmaxf(0.f, y[0] * a_sc.x + a_sh.x), fmaxf(0.f, y[1] * a_sc.y + a_sh.y),
+                                    fmaxf(0.f, y[2] * a_sc.z + a_sh.z), fmaxf(0.f, y[3] * a_sc.w + a_sh.w)),
+                        make_float4(fmaxf(0.f, y[4] * a_sc2.x + a_sh2.x), fmaxf(0.f, y[5] * a_sc2.y + a_sh2.y),
+                                    fmaxf(0.f, y[6] * a_sc2.z + a_sh2.z), fmaxf(0.f, y[7] * a_sc2.w + a_sh2.w)));
+            }
             short *q = ldb_a + row * RSA + (e - (row << kfs8)) * 8;
-            *reinterpret_cast<uint2 *>(q) = make_uint2(pa8[j].x, pa8[j].y);
-            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pa8[j].z, pa8[j].w);
+            *reinterpret_cast<uint2 *>(q) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2 *>(q + 4) = make_uint2(v.z, v.w);
           }
         }
       }
@@ -1413,8 +1470,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
     }
     __syncthreads();
     if (tile + 1 < t1) {
+      take_meta();
       fetch(tile + 1);
       fetch_idx(min(tile + 2, t1 - 1));
+      fetch_meta(min(tile + 2, t1 - 1));
     }
     if (!ST16 && w.colsum && (int)threadIdx.x < COUT) {
       if (BFM) {  // the staged tile is bf16: the bias gradient sums the rounded values

@@ -215,7 +215,7 @@ class GroundingStep:
         self._geom_tag = None      # eager pipeline: the batch _geom_next was prepared for
         self._geom_for = None      # graph pipeline: the batch _geom_next was prepared for
         self._static_tag = self._next_src_tag = None  # sources the static graph buffers were last filled from
-        self._graph = None
+        self._graph = self._gD = self._gM2 = None
         self._regime = None        # epoch < 50 at capture: the loss configuration the captured graph holds
         self.on_capture = None     # optional callable run right before the graphs are captured (after the warm-up passes)
         self._static_batch = self._static_next = None
@@ -299,13 +299,16 @@ class GroundingStep:
         """backward with every weight-gradient slab sum of the pass deferred into one launch (51 -> 2 at cfg2).
         The deferred queue hands autograd VIEWS of buffers that are filled at the flush: that is only sound while
         AccumulateGrad steals the view, i.e. while the parameter has no gradient yet — checked here."""
+        self._check_no_stale_grads()
+        with _ext.deferred_slab_reduce():
+            loss.backward()
+
+    def _check_no_stale_grads(self):
         stale = [n for n, p in self.model.named_parameters() if p.grad is not None]
         if stale:
             raise RuntimeError("GroundingStep._backward: parameters still hold a gradient (%s, ...): call bucket.zero() first — "
                                "accumulating into an existing .grad would read the deferred buffers before they are filled"
                                % stale[0])
-        with _ext.deferred_slab_reduce():
-            loss.backward()
 
     def _persistent_state(self):
         """Everything a forward pass mutates besides the parameters: BatchNorm running statistics / counters and the
@@ -355,14 +358,54 @@ class GroundingStep:
             with torch.cuda.graph(self._gS, stream=self._side):
                 nxt = backbone.compute_geometry(self._coords(self._static_next))
                 self._copy_geometry(self._geom_next, nxt)
-            with torch.cuda.graph(self._gM):
-                self.bucket.zero()
-                loss, out = self.forward_loss(self._static_batch, self._geom_cur)
-                self._backward(loss)
-                self._static_out = _detached(out)
-                self.bucket.collect()
-                add_norm.advance(self.device)
-                self._static_loss = loss.detach()
+            self._gD = self._gM2 = None
+            boundary_keys = ("sa2_features",)
+            if os.environ.get("VLP3D_SPLIT_BACKWARD", "1") != "0":
+                # Backward in two autograd passes with the weight-gradient-only work between them on the side stream.
+                # Everything the deferred queue holds when backward reaches the backbone's second set-abstraction level (the
+                # batched weight gradients of the rows stacks and plain linear layers, the relation bias MLP's backward,
+                # the slab sums: ~0.5 ms of launches that feed nothing but the optimiser) used to run at the END of the
+                # main stream.  The side stream has finished the next batch's geometry by then and idles; so:
+                #   gM  (main): forward + loss + backward down to d(sa2_features)   -> event
+                #   gD  (side): flush of the deferred queue, concurrent with ...
+                #   gM2 (main): ... the backward of SA2 and SA1 (d(sa2_features) as root), their slab sums, collect.
+                # sa2_features is a CUT of the autograd graph (everything below it reaches the loss only through it; sa3 /
+                # sa4 are not: `inputs=` does not stop the engine at a tensor, and d(sa3) already contains the path through
+                # sa4), so the two passes run every node once and the gradients are those of the one-pass backward.  Still
+                # LINEAR graphs only: ROCm walks a forked graph node by node (see above).
+                self._gD, self._gM2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                head = [p for n, p in self.model.named_parameters()
+                        if p.requires_grad and not n.startswith(("backbone_net.sa1.", "backbone_net.sa2."))]
+                qctx = _ext.deferred_slab_reduce()
+                with torch.cuda.graph(self._gM):
+                    self.bucket.zero()
+                    loss, out = self.forward_loss(self._static_batch, self._geom_cur)
+                    boundary = [out[k] for k in boundary_keys]
+                    self._check_no_stale_grads()
+                    queue = qctx.__enter__()
+                    # (retain_graph: without it the engine releases the saved tensors of the nodes it did NOT run as well)
+                    torch.autograd.backward([loss], inputs=head + boundary, retain_graph=True)
+                with torch.cuda.graph(self._gD, stream=self._side):
+                    queue.flush()
+                with torch.cuda.graph(self._gM2):
+                    torch.autograd.backward(boundary, [t.grad for t in boundary])
+                    qctx.__exit__(None, None, None)
+                    for t in boundary:
+                        t.grad = None
+                    self._static_out = _detached(out)
+                    self.bucket.collect()
+                    add_norm.advance(self.device)
+                    self._static_loss = loss.detach()
+                del boundary, out, loss
+            else:
+                with torch.cuda.graph(self._gM):
+                    self.bucket.zero()
+                    loss, out = self.forward_loss(self._static_batch, self._geom_cur)
+                    self._backward(loss)
+                    self._static_out = _detached(out)
+                    self.bucket.collect()
+                    add_norm.advance(self.device)
+                    self._static_loss = loss.detach()
             self._graph = self._gM
             # _geom_next currently holds the geometry of _static_next (computed by the warm-up passes)
             self._geom_for = self._next_src_tag
@@ -386,6 +429,11 @@ class GroundingStep:
             self._gS.replay()
         self._geom_for = self._next_src_tag
         self._gM.replay()
+        if self._gD is not None:
+            self._side.wait_stream(cur)      # the deferred weight-gradient work reads what gM left behind
+            with torch.cuda.stream(self._side):
+                self._gD.replay()
+            self._gM2.replay()
         cur.wait_stream(self._side)          # join
 
     @staticmethod
@@ -405,7 +453,7 @@ class GroundingStep:
             if self._graph is not None and (self.epoch < 50) != self._regime:
                 # the loss configuration baked into the captured graph (reference-loss weight 0.3 / 1.0, label smoothing below
                 # epoch 50, OCC / OSC from epoch 50 on; loss_joint.py:208, loss_grounding.py) no longer matches: recapture
-                self._graph = self._gC = self._gS = self._gM = None
+                self._graph = self._gC = self._gS = self._gM = self._gD = self._gM2 = None
                 self._static_out = None
             if self._graph is None:
                 self._regime = self.epoch < 50
