@@ -1139,13 +1139,12 @@ struct DyRaw8 {
   uint2 sel;    // pooled form: the arg-max sample of the 8 channels
 };
 
-template <int DYL>
+template <int DYL, bool POOL>
 __device__ __forceinline__ void dy8_issue(const RowGemmArgs &a, int row, int col0, int2 meta, DyRaw8 &w) {
   w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
   if (DYL == PLAIN) return;
-  if (a.pool_g != nullptr) {  // kernel-uniform
-    const int bm = a.crow ? (meta.x >> 8) : (a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S));
-    const long long off = (long long)bm * a.ldin + col0;
+  if (POOL) {
+    const long long off = (long long)(meta.x >> 8) * a.ldin + col0;
     const float4 d0 = ld4(a.pool_g + off);
     w.g = make_uint4(__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z), __float_as_uint(d0.w));
     w.dp1 = ld4(a.pool_g + off + 4);
@@ -1155,20 +1154,15 @@ __device__ __forceinline__ void dy8_issue(const RowGemmArgs &a, int row, int col
   }
 }
 
-template <int DYL>
-__device__ __forceinline__ uint4 dy8_finish(const RowGemmArgs &a, int row, int2 meta, const DyRaw8 &w,
-                                            const DyConsts<bf16> &klo, const DyConsts<bf16> &khi) {
+// dY summed over the copies of a compact row = k1 G + w (cb y + cc); dense rows carry w = 1 in their (synthesised) meta
+// word, for which the expression is the plain one bit for bit — no run-time branch left in the loader.
+template <int DYL, bool POOL>
+__device__ __forceinline__ uint4 dy8_finish(int2 meta, const DyRaw8 &w, const DyConsts<bf16> &klo, const DyConsts<bf16> &khi) {
   if (DYL == PLAIN) return w.y;
   float y[8], g[8];
   unpack8(w.y, y);
-  if (a.pool_g != nullptr) {  // kernel-uniform
-    int sidx;
-    if (a.crow) {
-      sidx = meta.x & 255;
-    } else {
-      const int bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
-      sidx = row - bm * a.pool_S;
-    }
+  if (POOL) {
+    const int sidx = meta.x & 255;
     const float d0[4] = {__uint_as_float(w.g.x), __uint_as_float(w.g.y), __uint_as_float(w.g.z), __uint_as_float(w.g.w)};
     const float d1[4] = {w.dp1.x, w.dp1.y, w.dp1.z, w.dp1.w};
 #pragma unroll
@@ -1179,19 +1173,14 @@ __device__ __forceinline__ uint4 dy8_finish(const RowGemmArgs &a, int row, int2 
   } else {
     unpack8(w.g, g);
   }
-  if (a.crow) {  // compact rows: dY summed over the copies = k1 G + w (cb y + cc)
-    const float mult = __int_as_float(meta.y);
-    float o[8];
-    const float ca[8] = {klo.k1.x, klo.k1.y, klo.k1.z, klo.k1.w, khi.k1.x, khi.k1.y, khi.k1.z, khi.k1.w};
-    const float cb[8] = {klo.k2.x, klo.k2.y, klo.k2.z, klo.k2.w, khi.k2.x, khi.k2.y, khi.k2.z, khi.k2.w};
-    const float cc[8] = {klo.k3.x, klo.k3.y, klo.k3.z, klo.k3.w, khi.k3.x, khi.k3.y, khi.k3.z, khi.k3.w};
+  const float mult = __int_as_float(meta.y);
+  float o[8];
+  const float ca[8] = {klo.k1.x, klo.k1.y, klo.k1.z, klo.k1.w, khi.k1.x, khi.k1.y, khi.k1.z, khi.k1.w};
+  const float cb[8] = {klo.k2.x, klo.k2.y, klo.k2.z, klo.k2.w, khi.k2.x, khi.k2.y, khi.k2.z, khi.k2.w};
+  const float cc[8] = {klo.k3.x, klo.k3.y, klo.k3.z, klo.k3.w, khi.k3.x, khi.k3.y, khi.k3.z, khi.k3.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], mult * __builtin_fmaf(cb[i], y[i], cc[i]));
-    return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
-  }
-  const float4 lo = klo.apply(make_float4(g[0], g[1], g[2], g[3]), make_float4(y[0], y[1], y[2], y[3]));
-  const float4 hi = khi.apply(make_float4(g[4], g[5], g[6], g[7]), make_float4(y[4], y[5], y[6], y[7]));
-  return pack8(lo, hi);
+  for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(ca[i], g[i], mult * __builtin_fmaf(cb[i], y[i], cc[i]));
+  return pack8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]));
 }
 
 struct WgradArgs {
@@ -1207,7 +1196,8 @@ struct WgradArgs {
 // plain linear layers (same operand rounding as the bf16 grouped MLPs; accumulation stays fp32).
 // The body takes its block coordinates as arguments: wgrad_kernel passes the launch's own, the batched linear form
 // (rows_wgrad_batch_kernel below) the coordinates inside one job of its table.
-template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>  // MAXT = output tiles per wave
+// POOL (bf16 storage only): dY of the last layer is synthesised from the pooled tensors (w.dy.pool_g / pool_sel)
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false>  // MAXT = output tiles per wave
 __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, const int by, const int gx, const int gy) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
@@ -1292,7 +1282,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   }
   // The gathered operand needs idx[row] before its feature row can be requested: two dependent memory latencies per
   // tile.  The indices therefore run ONE TILE FURTHER AHEAD than the data (pidx/tp hold the next tile's indices).
-  int pidx[MAXE_A], tp = 0;
+  int pidx[MAXE_A], tp = 0, tbm = 0;
+  float tq[3] = {0.f, 0.f, 0.f}, tcn[3] = {0.f, 0.f, 0.f};  // raw [xyz | centre] of the tail chunk (arithmetic at the LDS store)
   auto fetch_idx = [&](long long tile) {
     if (LOADER != GATHER) return;
     const int row0 = (int)(tile * 32);
@@ -1302,7 +1293,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
       pidx[j] = compact ? w.src.crow[row0 + row_of(e)].x : w.src.idx[row0 + row_of(e)];
     }
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
-    tp = compact ? w.src.crow[row0 + te / max(tc, 1)].x : w.src.idx[row0 + te / max(tc, 1)];
+    const int trow = row0 + te / max(tc, 1);
+    if (compact) {
+      const int4 c = w.src.crow[trow];
+      tp = c.x;
+      tbm = c.y >> 8;
+    } else {
+      tp = w.src.idx[trow];
+      tbm = w.src.S_shift >= 0 ? (trow >> w.src.S_shift) : trow / w.src.S;
+    }
   };
   // M*S is a multiple of 32 (checked by the host), so a tile never straddles two scenes: the scene index is a
   // scalar that follows the (monotone) tile counter instead of two integer divisions per staged element.
@@ -1311,8 +1310,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   long long scene_end = (long long)(scene + 1) * tiles_per_scene;
   auto fetch = [&](long long tile) {
     const int row0 = (int)(tile * 32);
-    const int te = min((int)threadIdx.x, max(net, 1) - 1);
-    const int trow = row0 + te / max(tc, 1);
     if (LOADER == GATHER && !compact) {
       if (tile >= scene_end) {  // tiles advance by one and tiles_per_scene >= 1
         ++scene;
@@ -1324,7 +1321,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
 #pragma unroll
       for (int j = 0; j < NE_DY8; ++j) {
         const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
-        dy8_issue<DYL>(w.dy, row0 + e / (COUT / 8), coff + (e % (COUT / 8)) * 8, mc[j], rdy[j]);
+        dy8_issue<DYL, POOL>(w.dy, row0 + e / (COUT / 8), coff + (e % (COUT / 8)) * 8, mc[j], rdy[j]);
       }
     } else {
 #pragma unroll
@@ -1357,28 +1354,38 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
     }
-    vt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOADER == GATHER) {
-      const int bm = compact ? (reinterpret_cast<const int *>(w.src.crow + trow)[1] >> 8)
-                             : (w.src.S_shift >= 0 ? (trow >> w.src.S_shift) : trow / w.src.S);
       const float *q = w.src.xyz + (pbase + tp) * 3;
-      const float *c = w.src.new_xyz + (long long)bm * 3;
-      const float x = (q[0] - c[0]) / w.src.radius, y = (q[1] - c[1]) / w.src.radius, z = (q[2] - c[2]) / w.src.radius;
-      const bool first = (te % max(tc, 1)) == 0;  // chunk 0 of the tail is [dx, dy, dz, 0]
-      vt = make_float4(first ? x : 0.f, first ? y : 0.f, first ? z : 0.f, 0.f);
+      const float *c = w.src.new_xyz + (long long)tbm * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        tq[i] = q[i];
+        tcn[i] = c[i];
+      }
     }
   };
+  auto tail_chunk = [&]() -> float4 {  // [dx, dy, dz, 0] / radius for chunk 0 of the tail, zero padding after it
+    if (LOADER != GATHER) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int te = min((int)threadIdx.x, max(net, 1) - 1);
+    const bool first = (te % max(tc, 1)) == 0;
+    const float x = (tq[0] - tcn[0]) / w.src.radius, y = (tq[1] - tcn[1]) / w.src.radius, z = (tq[2] - tcn[2]) / w.src.radius;
+    return make_float4(first ? x : 0.f, first ? y : 0.f, first ? z : 0.f, 0.f);
+  };
 
-  auto fetch_meta = [&](long long tile) {  // -> mn
+  auto fetch_meta = [&](long long tile) {  // -> mn: ((ball << 8) | position in the ball, multiplicity) of the staged rows
     if constexpr (ST16) {
       const int row0 = (int)(tile * 32);
 #pragma unroll
       for (int j = 0; j < NE_DY8; ++j) {
-        const int e = min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1);
-        mn[j] = make_int2(0, 0);
+        const int row = row0 + min((int)threadIdx.x + 256 * j, 32 * COUT / 8 - 1) / (COUT / 8);
         if (DYL == BNBWD && w.dy.crow) {  // kernel-uniform
-          const int4 c = w.dy.crow[row0 + e / (COUT / 8)];
+          const int4 c = w.dy.crow[row];
           mn[j] = make_int2(c.y, c.z);
+        } else if (POOL) {  // dense rows: (ball, sample) from the row number, multiplicity 1
+          const int bm = w.dy.pool_shift >= 0 ? (row >> w.dy.pool_shift) : (row / w.dy.pool_S);
+          mn[j] = make_int2((bm << 8) | (row - bm * w.dy.pool_S), __float_as_int(1.f));
+        } else {
+          mn[j] = make_int2(0, __float_as_int(1.f));
         }
       }
     }
@@ -1399,6 +1406,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   }
   for (long long tile = t0; tile < t1; ++tile) {
     __syncthreads();  // the previous tile's MFMA reads are done
+    vt = tail_chunk();
     if (BF) {
       // rows of the LDS tiles are 8 (mod 16) bytes apart (bank layout of the operand reads): two 8-byte stores per element
       if constexpr (ST16) {
@@ -1406,7 +1414,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         for (int j = 0; j < NE_DY8; ++j) {
           const int e = threadIdx.x + 256 * j;
           if (e < 32 * COUT / 8) {
-            const uint4 v = dy8_finish<DYL>(w.dy, (int)(tile * 32) + e / (COUT / 8), mc[j], rdy[j], dyk, dyk2);
+            const uint4 v = dy8_finish<DYL, POOL>(mc[j], rdy[j], dyk, dyk2);
             short *q = ldb_dy + (e / (COUT / 8)) * RSD + (e % (COUT / 8)) * 8;
             *reinterpret_cast<uint2 *>(q) = make_uint2(v.x, v.y);
             *reinterpret_cast<uint2 *>(q + 4) = make_uint2(v.z, v.w);
@@ -1533,9 +1541,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   }
 }
 
-template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false>
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs w) {
-  wgrad_body<T, COUT, LOADER, MAXT, DYL, BFM>(w, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+  wgrad_body<T, COUT, LOADER, MAXT, DYL, BFM, POOL>(w, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // Weight gradients of SEVERAL plain linear layers / rows-stack layers in one launch (bf16-MFMA timing configuration,
@@ -1892,16 +1900,16 @@ int launch_row_gemm(int loader, int epi, int cout, const RowGemmArgs &a, hipStre
   return VLP3D_EINVAL;
 }
 
-template <typename T, int LOADER, int COUT, int DYL = BNBWD, bool BFM = false>
+template <typename T, int LOADER, int COUT, int DYL = BNBWD, bool BFM = false, bool POOL = false>
 int launch_wgrad_c(const WgradArgs &w, hipStream_t s, dim3 grid, size_t lds) {
   const int per_wave = ((COUT / 32) * (w.KP / 32) + 3) / 4;
   const dim3 block(256);
   // fewer accumulator registers -> more resident workgroups -> more loads in flight (the kernel is latency bound)
-  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1, DYL, BFM>), grid, block, lds, s, w);
-  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3, DYL, BFM>), grid, block, lds, s, w);
-  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4, DYL, BFM>), grid, block, lds, s, w);
-  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6, DYL, BFM>), grid, block, lds, s, w);
-  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9, DYL, BFM>), grid, block, lds, s, w);
+  if (per_wave <= 1) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 1, DYL, BFM, POOL>), grid, block, lds, s, w);
+  else if (per_wave <= 3) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 3, DYL, BFM, POOL>), grid, block, lds, s, w);
+  else if (per_wave <= 4) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 4, DYL, BFM, POOL>), grid, block, lds, s, w);
+  else if (per_wave <= 6) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 6, DYL, BFM, POOL>), grid, block, lds, s, w);
+  else if (per_wave <= 9) hipLaunchKernelGGL((wgrad_kernel<T, COUT, LOADER, 9, DYL, BFM, POOL>), grid, block, lds, s, w);
   else return VLP3D_EINVAL;
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
@@ -1914,6 +1922,16 @@ int launch_wgrad_t(int cout, const WgradArgs &w, hipStream_t s) {
   const dim3 grid((unsigned)nblk);
   const size_t lds = sizeof(T) == 2 ? (size_t)32 * (cout + w.KP + 8) * 2 : (size_t)32 * (cout + w.KP) * sizeof(float);
   if (lds > 64 * 1024) return VLP3D_EINVAL;
+  if constexpr (sizeof(T) == 2 && LOADER == BNRELU) {
+    if (w.dy.pool_g != nullptr) {  // last layer, bf16 storage: the pooled-gradient loader is its own instantiation
+      if (cout == 256) return launch_wgrad_c<T, LOADER, 128, BNBWD, false, true>(w, s, dim3(grid.x, 2), (size_t)32 * (128 + w.KP + 8) * 2);
+      if (cout == 128) return launch_wgrad_c<T, LOADER, 128, BNBWD, false, true>(w, s, grid, lds);
+      if (cout == 64) return launch_wgrad_c<T, LOADER, 64, BNBWD, false, true>(w, s, grid, lds);
+      return VLP3D_EINVAL;
+    }
+  } else if (sizeof(T) == 2 && w.dy.pool_g != nullptr) {
+    return VLP3D_EINVAL;  // the gather layer is never the pooled one
+  }
   if (sizeof(T) == 2 && cout == 256) {  // two 128-column halves (see the kernel: coff)
     const size_t lds_half = (size_t)32 * (128 + w.KP + 8) * 2;
     return launch_wgrad_c<T, LOADER, 128>(w, s, dim3(grid.x, 2), lds_half);
