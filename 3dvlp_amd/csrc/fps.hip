@@ -157,7 +157,9 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     if ((tid & 63) == 0) atomicMax(&s_best[slot], key);
     const int nslot = slot == 2 ? 0 : slot + 1;
     if (tid == 0) s_best[nslot] = 0ull;  // last read two barriers ago; next written after this barrier
-    __syncthreads();
+    // LDS-only barrier (the global stores of this loop — temp of the overflow points, idx — are read by nobody but their
+    // own thread before the kernel ends)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned long long g = s_best[slot];
     slot = nslot;
 
@@ -169,6 +171,116 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     old = __builtin_amdgcn_readfirstlane((int)k);
     if (tid == 0) idx[j] = old;
   }
+}
+
+// ---- small point sets (N <= 2048: the proposal sampling of the vote clusters, 1024 -> 256 on the step's critical path) ----
+// The iteration is nothing but its dependency chain here (update of <= 8 points per lane, then argmax), so the chain is
+// cut to the pruned kernel's form: four waves only; 32-bit value reductions (DPP) with the reference's tie order resolved
+// lazily — only when a maximum is attained twice do the tied lanes compare the tie key; the wave candidates (value, index)
+// meet in LDS behind an LDS-only barrier and every wave reduces the four of them redundantly (no second barrier, no LDS
+// atomics); coordinates and the sample list live in LDS.  256 threads are HALF the reference's block P = 512 at
+// 512 <= N <= 2048, so a lane's points k = tid + 256 i alternate between two residues mod P: walking the even slots first,
+// then the odd ones, with a strict '>' keeps "first maximum wins" equal to the reference's order
+// (smallest (bitrev_P(k mod P), k)); below 512 points 256 is a multiple of P and the natural order is that order.
+// 0.54 -> 0.3 us per iteration at 8 x 1024 -> 256.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32s(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32s(unsigned v) {  // wave-uniform result
+  v = dpp_max_u32s<0xB1>(v);
+  v = dpp_max_u32s<0x4E>(v);
+  v = dpp_max_u32s<0x141>(v);
+  v = dpp_max_u32s<0x140>(v);
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_small_kernel(const float *__restrict__ xyz_all, int *__restrict__ idx_all, int N,
+                                                        int m, int log2P, const int *__restrict__ not_prefix) {
+  __shared__ uint2 s_vk[2][4];
+  __shared__ float4 s_xyz[PPT * 256];
+  __shared__ int s_idx[PPT * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+  if (not_prefix != nullptr && *not_prefix == 0) {  // see fps_kernel
+    for (int j = tid; j < m; j += 256) idx[j] = j;
+    return;
+  }
+  const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * N * 3;
+  const bool evenodd = log2P == 9;  // P = 512 = 2 x 256 threads
+  const unsigned Pm1 = (1u << log2P) - 1u;
+  auto slot_of = [&](int u) -> int { return evenodd ? (u < PPT / 2 ? 2 * u : 2 * (u - PPT / 2) + 1) : u; };
+  auto tiekey = [&](unsigned k) -> unsigned { return 0xFFFFFFFFu - (__brev(k & Pm1) | (k >> log2P)); };  // larger = preferred
+
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int k = tid + 256 * slot_of(u);
+    float x = 0.f, y = 0.f, z = 0.f, t = -1.f;  // t = -1: never a candidate
+    if (k < N) {
+      x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
+      t = vlp3d_fps_skipped(x, y, z) ? -1.f : 1e10f;
+      s_xyz[k] = make_float4(x, y, z, 0.f);
+    }
+    px[u] = x; py[u] = y; pz[u] = z; pt[u] = t;
+  }
+  __syncthreads();
+  int old = 0, par = 0;
+  for (int j = 1; j < m; ++j) {
+    const float4 q = s_xyz[old];
+    float best = -1.f;
+    int bu = 0;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const float d = vlp3d_sumsq3(px[u] - q.x, py[u] - q.y, pz[u] - q.z);
+      const float t = vmin(d, pt[u]);
+      pt[u] = t;
+      const bool g = t > best;
+      bu = g ? u : bu;
+      best = g ? t : best;
+    }
+    const unsigned k = (unsigned)(tid + 256 * slot_of(bu));
+    const unsigned v = best >= 0.f ? __float_as_uint(best) + 1u : 0u;
+    const unsigned vmax = wave_max_u32s(v);
+    unsigned long long tied = __ballot(v == vmax);
+    if (__popcll(tied) > 1) {  // wave-uniform, rare: an exact tie — the reference's order decides
+      const unsigned tk = v == vmax ? tiekey(k) : 0u;
+      const unsigned tmax = wave_max_u32s(tk);
+      tied = __ballot(v == vmax && tk == tmax);
+    }
+    const unsigned kw = (unsigned)__builtin_amdgcn_readlane((int)k, (int)__builtin_ctzll(tied));
+    if (lane == 0) s_vk[par][wave] = make_uint2(vmax, kw);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier (see fps_kernel)
+    const uint2 c = s_vk[par][lane & 3];
+    const unsigned bv = lane < 4 ? c.x : 0u;
+    unsigned r = dpp_max_u32s<0xB1>(bv);
+    r = dpp_max_u32s<0x4E>(r);
+    const unsigned bmax = (unsigned)__builtin_amdgcn_readlane((int)r, 0);
+    unsigned knew = 0u;  // no candidate left (every point skipped): the reference returns index 0
+    if (bmax != 0u) {
+      unsigned long long w4 = __ballot(lane < 4 && bv == bmax);
+      if (__popcll(w4) > 1) {
+        const unsigned tk = (lane < 4 && bv == bmax) ? tiekey(c.y) : 0u;
+        unsigned tm = dpp_max_u32s<0xB1>(tk);
+        tm = dpp_max_u32s<0x4E>(tm);
+        const unsigned tmax = (unsigned)__builtin_amdgcn_readlane((int)tm, 0);
+        w4 = __ballot(lane < 4 && bv == bmax && tk == tmax);
+      }
+      knew = (unsigned)__builtin_amdgcn_readlane((int)c.y, (int)__builtin_ctzll(w4));
+    }
+    old = (int)knew;
+    if (tid == 0) s_idx[j] = old;
+    par ^= 1;
+  }
+  __syncthreads();
+  if (tid == 0) idx[0] = 0;
+  for (int j = 1 + tid; j < m; j += 256) idx[j] = s_idx[j];
 }
 
 // include/cuda_utils.h:20-24 of the reference: block size used by its FPS launch.
@@ -189,16 +301,20 @@ static int fps_dense(const float *xyz, int B, int N, int m, float *temp, int *id
   const int log2P = reference_log2_block(N);
 #define FPS_LAUNCH(T, R, L) \
   hipLaunchKernelGGL((fps_kernel<T, R, L>), dim3(B), dim3(T), 0, s, xyz, temp, idx, N, m, log2P, not_prefix)
-  // THREADS must be a multiple of P = 2^log2P (the reference's block size) so that all points of
+  // fps_kernel: THREADS must be a multiple of P = 2^log2P (the reference's block size) so that all points of
   // one thread share k mod P: then "lowest slot wins" inside a thread is the reference's order.
-  if (N < 512) FPS_LAUNCH(256, 2, 0);        // P <= 256
-  else if (N <= 1024) FPS_LAUNCH(512, 2, 0);  // P == 512 from here on (or 256 at N == 512)
-  else if (N <= 2048) FPS_LAUNCH(512, 4, 0);
+#define FPS_LAUNCH_S(PPT) \
+  hipLaunchKernelGGL((fps_small_kernel<PPT>), dim3(B), dim3(256), 0, s, xyz, idx, N, m, log2P, not_prefix)
+  if (N <= 256) FPS_LAUNCH_S(1);
+  else if (N <= 512) FPS_LAUNCH_S(2);
+  else if (N <= 1024) FPS_LAUNCH_S(4);
+  else if (N <= 2048) FPS_LAUNCH_S(8);
   else if (N <= 4096) FPS_LAUNCH(1024, 4, 0);
   else if (N <= 8192) FPS_LAUNCH(1024, 8, 0);
   else if (N <= 16384) FPS_LAUNCH(1024, 16, 0);
   else FPS_LAUNCH(1024, 24, 9);
 #undef FPS_LAUNCH
+#undef FPS_LAUNCH_S
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
