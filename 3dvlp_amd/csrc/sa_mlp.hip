@@ -618,14 +618,15 @@ __device__ __forceinline__ void hoist_consts(const RowGemmArgs &a, int col0, flo
   }
 }
 
+// `meta` = ((ball << 8) | position in the ball, multiplicity bits) of the row: the kernel keeps the 32 rows' words of its
+// current tile in LDS (requested one tile ahead), so neither the pooled-gradient address nor the multiplicity waits for a
+// global read of the row map behind the operand itself (round 3: three dependent round trips per chunk batch -> one).
 template <int LOADER>
-__device__ __forceinline__ void raw_load8(const RowGemmArgs &a, int row, int col0, Raw8 &w) {
+__device__ __forceinline__ void raw_load8(const RowGemmArgs &a, int row, int col0, int2 meta, Raw8 &w) {
   w.y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(a.Yin) + (long long)row * a.ldin + col0);
   if (LOADER == BNBWD) {
     if (a.pool_g != nullptr) {  // kernel-uniform
-      int bm, sidx_;
-      ball_of_row(a, row, bm, sidx_);
-      const long long off = (long long)bm * a.ldin + col0;
+      const long long off = (long long)(meta.x >> 8) * a.ldin + col0;
       w.dp0 = ld4(a.pool_g + off);
       w.dp1 = ld4(a.pool_g + off + 4);
       w.sel = *reinterpret_cast<const uint2 *>(a.pool_sel + off);
@@ -636,7 +637,7 @@ __device__ __forceinline__ void raw_load8(const RowGemmArgs &a, int row, int col
 }
 
 template <int LOADER>
-__device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Raw8 &w, const float (&ca)[8],
+__device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int2 meta, const Raw8 &w, const float (&ca)[8],
                                          const float (&cb)[8], const float (&cc)[8]) {
   float y[8], o[8];
   unpack8(w.y, y);
@@ -645,11 +646,9 @@ __device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int row, const Ra
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(0.f, __builtin_fmaf(y[i], ca[i], cb[i]));
   } else {
     float g[8];
-    const float mult = row_weight(a, row);
+    const float mult = __int_as_float(meta.y);
     if (a.pool_g != nullptr) {
-      int bm_, si_;
-      ball_of_row(a, row, bm_, si_);
-      const unsigned sidx = (unsigned)si_;
+      const unsigned sidx = (unsigned)(meta.x & 255);
       const float dp[8] = {w.dp0.x, w.dp0.y, w.dp0.z, w.dp0.w, w.dp1.x, w.dp1.y, w.dp1.z, w.dp1.w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -680,6 +679,8 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   const int wtile = 32 * (ldw > lde ? ldw : lde);  // per-wave LDS tile, shared by the A operand and the epilogue
   bf16 *sW = reinterpret_cast<bf16 *>(smem);
   bf16 *sA = sW + (size_t)COUT * ldw + (size_t)wave * wtile;
+  // per wave: the row-map words ((ball << 8) | position, multiplicity) of the 32 rows of its CURRENT tile (see raw_load8)
+  int2 *sMeta = reinterpret_cast<int2 *>(sW + (size_t)COUT * ldw + (size_t)4 * wtile) + wave * 32;
   const long long ntiles = compact_tiles(a);
   const bool compact = a.crow != nullptr;
   if ((long long)blockIdx.x * 4 >= ntiles) {
@@ -758,8 +759,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       if (64 * u + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[u] * ldw + ccol[u]) = pack8(gv0[u], gv1[u]);
     if (lane < 32) {  // same wave, later instruction: lands after the chunk writes above
       const int rr = row0 + lane;
-      const int bm = compact ? (reinterpret_cast<const int *>(a.crow + rr)[1] >> 8)
-                             : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
+      const int bm = compact ? (sMeta[lane].x >> 8) : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
       const float *cc3 = a.new_xyz + (long long)bm * 3;  // a handful of L1-resident centres per tile
       *reinterpret_cast<uint2 *>(sA + lane * ldw + a.C) =
           pack4(make_float4((qx - cc3[0]) * inv_radius, (qy - cc3[1]) * inv_radius, (qz - cc3[2]) * inv_radius, 0.f));
@@ -806,9 +806,27 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       raw_load_pf<HOIST ? LOADER : BNRELU>(a, (int)(vt0 * 32) + (c >> kshift), (c & (kc - 1)) * 8, hp[u]);
     }
   }
+  // row-map words of the NEXT tile, one row per lane (lanes 0..31), requested a tile ahead; dense rows synthesise them
+  auto meta_of = [&](long long tile) -> int2 {
+    const int row = (int)(tile * 32) + (lane & 31);
+    if (compact) {
+      const int4 c = a.crow[row];
+      return make_int2(c.y, c.z);
+    }
+    int bm = 0, sidx = 0;
+    if (LOADER == BNBWD && a.pool_g != nullptr) {
+      bm = a.pool_shift >= 0 ? (row >> a.pool_shift) : (row / a.pool_S);
+      sidx = row - bm * a.pool_S;
+    }
+    return make_int2((bm << 8) | sidx, __float_as_int(1.f));
+  };
+  int2 pmeta = make_int2(0, __float_as_int(1.f));
+  if (vt0 < vend) pmeta = meta_of(map_tile(vt0));
   for (long long vt = vt0; vt < vend; vt += vstep) {
     const long long tile = map_tile(vt);
     const int row0 = (int)(tile * 32);
+    if (lane < 32) sMeta[lane] = pmeta;  // this wave's earlier reads of the previous tile's words are done (in-order LDS)
+    if (vt + vstep < vend) pmeta = meta_of(map_tile(vt + vstep));
     if (fastg) {
       if (!GATHER_PREFETCH) gather_issue(tile);
       gather_commit(tile);
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         if (c < nch) {
           const int row = c >> kshift, ch = c & (kc - 1);
           *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) =
-              finish_pf<HOIST ? LOADER : BNRELU>(hp[u], ca, cb, cc, LOADER == BNBWD ? row_weight(a, row0 + row) : 1.f);
+              finish_pf<HOIST ? LOADER : BNRELU>(hp[u], ca, cb, cc, LOADER == BNBWD ? __int_as_float(sMeta[row].y) : 1.f);
         }
       }
       const long long vnext = vt + vstep;
@@ -862,14 +880,14 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         for (int u = 0; u < UB; ++u) {  // unconditional (clamped) loads: branch-free, all in flight together
           const int c = min(c0 + 64 * u + lane, nch - 1);
           const int row = c >> kshift, ch = c & (kc - 1);
-          raw_load8<LOADER>(a, row0 + row, ch * 8, raw[u]);
+          raw_load8<LOADER>(a, row0 + row, ch * 8, sMeta[row], raw[u]);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int c = c0 + 64 * u + lane;
           if (c < nch) {
             const int row = c >> kshift, ch = c & (kc - 1);
-            *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish8<LOADER>(a, row0 + row, raw[u], ca, cb, cc);
+            *reinterpret_cast<uint4 *>(sA + row * ldw + ch * 8) = finish8<LOADER>(a, sMeta[row], raw[u], ca, cb, cc);
           }
         }
         continue;
@@ -912,7 +930,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       T *Y = reinterpret_cast<T *>(a.Yout) + (long long)row0 * a.ldout;
       float wr[16];  // multiplicity of this lane's 16 accumulator rows in the BatchNorm batch sums (1 without a row map)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) wr[i] = row_weight(a, row0 + acc_row(i, half));
+      for (int i = 0; i < 16; ++i) wr[i] = __int_as_float(sMeta[acc_row(i, half)].y);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         float ps = 0.f, pq = 0.f;
@@ -1845,7 +1863,7 @@ int launch_row_gemm_t(int cout, const RowGemmArgs &a, hipStream_t s) {
 template <int COUT, int LOADER, int EPI>
 int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
   const size_t wtile = 32 * (size_t)((a.K > COUT ? a.K : COUT) + 8);  // A operand / epilogue staging, per wave
-  const size_t lds = ((size_t)COUT * (a.K + 8) + 4 * wtile) * sizeof(bf16);
+  const size_t lds = ((size_t)COUT * (a.K + 8) + 4 * wtile) * sizeof(bf16) + 4 * 32 * sizeof(int2);  // + row-map words
   const size_t lds_static = (EPI == SCATTER) ? 0 : sizeof(double) * 4 * 2 * COUT;  // block_stats_to_slab
   if (lds + lds_static > 160 * 1024) return VLP3D_EINVAL;
   auto kern = row_gemm_lds_kernel<COUT, LOADER, EPI>;

@@ -1066,7 +1066,7 @@ def test_deferred_slab_reduce_equals_immediate(bf16):
     _eval_dropout_train_bn(step)
     state = [b.clone() for b in step.model.buffers()]
     grads = []
-    for deferred in (False, False, True):  # the first two runs give the run-to-run noise of the float atomics upstream
+    for deferred in (False, False, False, True):  # the first three runs give the run-to-run noise of the float atomics upstream
         for b, s0 in zip(step.model.buffers(), state):
             b.copy_(s0)
         step.bucket.zero()
@@ -1081,12 +1081,16 @@ def test_deferred_slab_reduce_equals_immediate(bf16):
         step.bucket.collect()
         torch.cuda.synchronize()
         grads.append({n: p.grad.clone() for n, p in step.model.named_parameters() if p.grad is not None})
-    assert grads[0].keys() == grads[2].keys()
+    assert grads[0].keys() == grads[3].keys()
+    # Run-to-run noise: the fp32 path differs by the summation order of float atomics (1e-6).  With bf16 storage such an
+    # ulp-level difference flips the rounding of a few stored gradient elements (4e-3 each), which the layers below amplify:
+    # identical backbone inputs give weight gradients 1e-4 .. 5e-4 apart (Frobenius) from one pass to the next, and two
+    # passes are often bit-identical while the third is not (tools/sa_determinism.py) — hence three baseline runs and a floor.
+    floor = 2e-3 if bf16 else 2e-5
     for n, g0 in grads[0].items():
-        noise = _rel(grads[1][n], g0)
-        g1 = grads[2][n]
-        # (one pair of runs is itself a noisy estimate of the atomics' run-to-run noise, bf16 storage amplifies it: x5)
-        assert _rel(g1, g0) <= max(2e-5, 5 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
+        noise = max(_rel(grads[1][n], g0), _rel(grads[2][n], g0), _rel(grads[2][n], grads[1][n]))
+        g1 = grads[3][n]
+        assert _rel(g1, g0) <= max(floor, 5 * noise) or float((g1 - g0).abs().max()) < 1e-7, (n, _rel(g1, g0), noise)
 
 
 def test_linear_wgrad_batch_equals_single_launches():
