@@ -86,6 +86,8 @@ SIGNATURES = {
     "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_rows_slabs": [ctypes.c_longlong],
     "vlp3d_rows_fwd": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
+    "vlp3d_rows_fwd_wt": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
+    "vlp3d_transpose_batch": [_vp, _i, _vp],
     "vlp3d_rows_dgrad": [_vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp],
     "vlp3d_rows_wgrad": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "vlp3d_rows_act": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
@@ -588,6 +590,26 @@ class RowsWgradJob(ctypes.Structure):
 class CopyDesc(ctypes.Structure):
     """include/vlp3d.h: vlp3d_copy_desc."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
+
+
+class TransposeDesc(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_transpose_desc."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("ld_dst", ctypes.c_int)]
+
+
+def transpose_batch(dsts, srcs):
+    """dst[i] (cols x ld) = src[i] (rows x cols)^T for contiguous fp32 CUDA matrices — one launch (csrc/glue.hip)."""
+    if not dsts:
+        return
+    arr = (TransposeDesc * len(dsts))()
+    for c, d, s_ in zip(arr, dsts, srcs):
+        if s_.dim() != 2 or d.dim() != 2 or not (s_.is_contiguous() and d.is_contiguous() and s_.is_cuda and d.is_cuda) or \
+                s_.dtype != torch.float32 or d.dtype != torch.float32 or d.shape[0] != s_.shape[1] or d.shape[1] < s_.shape[0]:
+            raise RuntimeError("transpose_batch: contiguous fp32 CUDA matrices, dst (cols x >= rows)")
+        c.src, c.dst, c.rows, c.cols, c.ld_dst = s_.data_ptr(), d.data_ptr(), s_.shape[0], s_.shape[1], d.shape[1]
+    with torch.cuda.device(dsts[0].device):
+        _check(load().vlp3d_transpose_batch(ctypes.cast(arr, ctypes.c_void_p), len(dsts), _stream()), "vlp3d_transpose_batch")
 
 
 def copy_batch(dsts, srcs):

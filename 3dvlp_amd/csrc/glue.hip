@@ -450,6 +450,59 @@ __global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch t) {
 }
 }  // namespace
 
+// ---- K-major copies of many small weight matrices in one launch (3dvlp_amd/row_mlp.py: prepared_weights) ---------------
+// dst (cols x ld_dst) = src (rows x cols)^T for every job; one workgroup = one 32 x 32 tile through LDS (coalesced both ways).
+namespace {
+constexpr int TR_BATCH = 48;
+struct TransposeBatch {
+  vlp3d_transpose_desc d[TR_BATCH];
+  int first_block[TR_BATCH + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t) {
+  __shared__ float tile[32][33];
+  int e = 0;
+  while (e + 1 < t.count && (int)blockIdx.x >= t.first_block[e + 1]) ++e;
+  const vlp3d_transpose_desc &d = t.d[e];
+  const int tiles_c = (d.cols + 31) / 32;
+  const int tb = (int)blockIdx.x - t.first_block[e];
+  const int r0 = (tb / tiles_c) * 32, c0 = (tb % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float *src = (const float *)d.src;
+  float *dst = (float *)d.dst;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < d.rows && c < d.cols) ? src[(long long)r * d.cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < d.cols && r < d.rows) dst[(long long)c * d.ld_dst + r] = tile[tx][i];
+  }
+}
+}  // namespace
+
+extern "C" int vlp3d_transpose_batch(const vlp3d_transpose_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return VLP3D_EINVAL;
+  for (int c0 = 0; c0 < count; c0 += TR_BATCH) {
+    TransposeBatch t = {};
+    t.count = count - c0 < TR_BATCH ? count - c0 : TR_BATCH;
+    long long blocks = 0;
+    for (int j = 0; j < t.count; ++j) {
+      const vlp3d_transpose_desc &d = descs[c0 + j];
+      if (!d.src || !d.dst || d.rows < 1 || d.cols < 1 || d.ld_dst < d.rows) return VLP3D_EINVAL;
+      t.d[j] = d;
+      t.first_block[j] = (int)blocks;
+      blocks += (long long)((d.rows + 31) / 32) * ((d.cols + 31) / 32);
+      if (blocks >= (1ll << 31)) return VLP3D_EINVAL;
+    }
+    t.first_block[t.count] = (int)blocks;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+    VLP3D_LAUNCH_CHECK();
+  }
+  return VLP3D_OK;
+}
+
 extern "C" int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *stream) {
   if (count < 0 || (count > 0 && !descs)) return VLP3D_EINVAL;
   for (int c0 = 0; c0 < count; c0 += COPY_BATCH) {

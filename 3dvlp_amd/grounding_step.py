@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib as _ext
 from . import mfma_linear
-from . import add_norm, losses, synth
+from . import add_norm, losses, row_mlp, synth
 from .ddp import FlatAdamW, FlatGradBucket, FlatParams
 from .detection import Pointnet2Backbone, ProposalModule, RelationModule, VotingModule
 from .grounding import ContrastModule, MatchModule
@@ -192,6 +192,7 @@ class GroundingStep:
             self.layout = None
             self.bucket = FlatGradBucket(self.model)
             self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=1e-5)
+        self._wprep = row_mlp.PreparedWeights()  # K-major weight copies of the rows stacks, refreshed once per forward pass
         self.epoch = epoch
         self.autocast_dtype = autocast_dtype
         self.sa_dtype = sa_dtype
@@ -228,7 +229,7 @@ class GroundingStep:
         if geometry is not None:
             d["backbone_geometry"] = geometry
         # 26 one-element `add_(1)` launches -> one multi-tensor add; plain linear layers follow the grouped MLPs' dtype
-        with _deferred_bn_counters(self.model), mfma_linear.bf16_mma(self.sa_dtype == torch.bfloat16 and os.environ.get("VLP3D_LINEAR_BF16", "1") != "0"):
+        with self._wprep, _deferred_bn_counters(self.model), mfma_linear.bf16_mma(self.sa_dtype == torch.bfloat16 and os.environ.get("VLP3D_LINEAR_BF16", "1") != "0"):
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                     d = self.model(d)

@@ -24,6 +24,45 @@ BATCH_WGRAD = os.environ.get("VLP3D_ROWS_WGRAD_BATCH", "1") != "0"  # queue the 
 WGRAD_K = 256  # K-slice of one weight-gradient launch (the staging of csrc/sa_mlp.hip: wgrad_kernel covers K <= 288)
 
 
+_ACTIVE = None  # the PreparedWeights whose forward pass is running
+
+
+class PreparedWeights:
+    """K-major copies of the weights the rows stacks of ONE model use, refreshed by one launch at the start of every forward
+    pass (vlp3d_transpose_batch) — `with prepared:` around the model's forward.  The forward product then reads its weight
+    fragments coalesced (vlp3d_rows_fwd_wt) instead of re-staging a 128 x K weight block through LDS for every 32-row tile:
+    30 -> 13 us for the 8192 x 256 x 256 layers of the FP / voting stacks.  A weight is registered the first time a stack
+    sees it (that pass runs the row-major kernel) and served from the next pass on; outside the context nothing is served,
+    so a stale copy can never be read.  The parameters keep the reference's (N, K[, 1]) storage and state_dict layout."""
+
+    def __init__(self):
+        self.entries = {}   # data_ptr -> (weight view (Np, K), K-major copy (K, Np))
+        self.fresh = set()  # registered since the last refresh: not served yet
+
+    def __enter__(self):
+        global _ACTIVE
+        if self.entries:
+            _ext.transpose_batch([t for _, t in self.entries.values()], [w for w, _ in self.entries.values()])
+        self.fresh.clear()
+        self._outer, _ACTIVE = _ACTIVE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE
+        _ACTIVE = self._outer
+        return False
+
+    def lookup(self, w):
+        """w: contiguous (Np, K) view of a parameter's storage -> its K-major copy (K, Np), or None (then registered)."""
+        key = w.data_ptr()
+        e = self.entries.get(key)
+        if e is None or e[0].shape != w.shape:
+            self.entries[key] = (w.detach(), torch.zeros((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device))
+            self.fresh.add(key)
+            return None
+        return None if key in self.fresh else e[1]
+
+
 def _zeros(n, device):
     key = (n, str(device))
     if key not in _ZEROS:
@@ -82,14 +121,22 @@ class _RowStack(Function):
             Wp.append(w)
             y = torch.empty((R, Np), dtype=torch.float32, device=dev)
             bn = bns[l]
+            # K-major copy of the weight made at the start of this forward pass (PreparedWeights), when the step driver runs one
+            wt = _ACTIVE.lookup(w) if (_ACTIVE is not None and w.data_ptr() == W[l].data_ptr()) else None
+
+            def product(bias_, stats_):
+                if wt is not None:
+                    _ext.call("vlp3d_rows_fwd_wt", A, lda, R, K, a_vec, wt, Np, bias_, Np, y, Np, stats_, bf)
+                else:
+                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, bias_, Np, y, Np, stats_, bf)
             if bn is None:
-                _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None, bf)
+                product(b, None)
                 vec = None
             else:
                 vec = torch.empty((4, Np), dtype=torch.float32, device=dev)
                 if training[l]:
                     st = torch.empty((nslab, 2, Np), dtype=torch.float64, device=dev)
-                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, None, Np, y, Np, st, bf)
+                    product(None, st)
                     track = bn.track_running_stats and bn.training
                     if track:
                         if bn.num_batches_tracked is not None:  # None: the step driver increments all counters at once
@@ -102,7 +149,7 @@ class _RowStack(Function):
                               bn.running_var if track else None, Np, R, float(bn.eps), float(mom), 1, vec,
                               b.detach() if (track and b is not None) else None)
                 else:  # eval: y includes the bias, the running statistics normalise it
-                    _ext.call("vlp3d_rows_fwd", A, lda, R, K, a_vec, w, b, Np, y, Np, None, bf)
+                    product(b, None)
                     _ext.call("vlp3d_sa_bn_fold", None, 1, gam[l], bet[l], bn.running_mean, bn.running_var, Np, R,
                               float(bn.eps), 0.0, 0, vec)
             Ys.append(y)

@@ -454,6 +454,9 @@ int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int count, void
 int vlp3d_rows_slabs(long long R);
 int vlp3d_rows_fwd(const float *X, int ldx, long long R, int K, const float *a_vec, const float *W, const float *bias, int N,
                    float *Y, int ldy, double *stats, int bf16_mma, void *stream);
+/* vlp3d_rows_fwd with the weight K-major: WT (K x ldw), WT[k][n] = W[n][k] (a copy made by vlp3d_transpose_batch) */
+int vlp3d_rows_fwd_wt(const float *X, int ldx, long long R, int K, const float *a_vec, const float *WT, int ldw,
+                      const float *bias, int N, float *Y, int ldy, double *stats, int bf16_mma, void *stream);
 int vlp3d_rows_dgrad(const float *G, const float *Ypre, int ldg, const float *bn5, const float *W, long long R, int N, int K,
                      const float *Yprev, int ldprev, const float *p_vec, float *dA, int lda, double *tstats, int bf16_mma,
                      void *stream);
@@ -559,6 +562,17 @@ typedef struct {
   long long bytes;
 } vlp3d_copy_desc;
 int vlp3d_copy_batch(const vlp3d_copy_desc *descs, int count, void *stream);
+
+/* dst (cols x ld_dst floats) = src (rows x cols, row-major, contiguous)^T for `count` matrices in one launch.  Used by the
+ * rows stacks (3dvlp_amd/row_mlp.py prepared_weights) to give the forward product of a Conv1d / nn.Linear layer the K-major
+ * weight image that vlp3d_rows_fwd_wt reads with coalesced fragment loads (reference: the cuBLAS GEMMs behind
+ * lib/pointnet2/pytorch_utils.py:49-90 pick their own operand layout; the parameters keep the reference's (N x K) storage). */
+typedef struct vlp3d_transpose_desc {
+  const void *src;
+  void *dst;
+  int rows, cols, ld_dst;
+} vlp3d_transpose_desc;
+int vlp3d_transpose_batch(const vlp3d_transpose_desc *descs, int count, void *stream);
 
 /* Caption head (csrc/caption.hip).  Replaces, for `TransformerDecoderModel(30522)` of models/jointnet/jointnet.py:104:
  *
