@@ -1215,7 +1215,9 @@ struct WgradArgs {
 // The body takes its block coordinates as arguments: wgrad_kernel passes the launch's own, the batched linear form
 // (rows_wgrad_batch_kernel below) the coordinates inside one job of its table.
 // POOL (bf16 storage only): dY of the last layer is synthesised from the pooled tensors (w.dy.pool_g / pool_sel)
-template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false>  // MAXT = output tiles per wave
+// RAWF (fp32 storage, no pooled gradient, no row map: the rows stacks and plain linear layers): like the bf16 loaders, the
+// next tile's operands are only REQUESTED before the products and transformed when they are written to LDS.
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false, bool RAWF = false>  // MAXT = output tiles per wave
 __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, const int by, const int gx, const int gy) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
@@ -1270,6 +1272,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   auto row_of = [&](int e) -> int { return LOADER == GATHER ? e / kf4 : e >> kfs; };
   const int tc = (KP - KF) / 4, net = 32 * tc;           // tail: [xyz | zero padding] chunks, <= 256 elements
   float4 vdy[ST16 ? 1 : NE_DY], va[A8 ? 1 : MAXE_A], vt;
+  float4 rgf[(RAWF && DYL == BNBWD) ? NE_DY : 1];  // RAWF: vdy holds the raw pre-activation, rgf the raw gradient
   constexpr int MAXE_A8 = (MAXE_A + 1) / 2;
   uint4 pa8[A8 ? MAXE_A8 : 1];         // bf16 storage: RAW operands of the next tile (arithmetic at the LDS store)
   DyRaw8 rdy[ST16 ? NE_DY8 : 1];
@@ -1345,7 +1348,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
 #pragma unroll
       for (int j = 0; j < NE_DY; ++j) {
         const int e = threadIdx.x + 256 * j;
-        vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), coff + (e % (COUT / 4)) * 4, dyk);
+        if constexpr (RAWF) {
+          const long long o = (long long)(row0 + e / (COUT / 4)) * w.dy.ldin + coff + (e % (COUT / 4)) * 4;
+          vdy[j] = ld4(reinterpret_cast<const T *>(w.dy.Yin) + o);
+          if (DYL == BNBWD) rgf[j] = ld4(reinterpret_cast<const T *>(w.dy.Gin) + o);
+        } else {
+          vdy[j] = load_dy4<T, DYL>(w.dy, row0 + e / (COUT / 4), coff + (e % (COUT / 4)) * 4, dyk);
+        }
       }
     }
     if constexpr (A8) {
@@ -1366,8 +1375,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         va[j] = ld4(w.src.feat_pm + (pbase + pidx[j]) * w.src.C + k0);
       } else if (LOADER == BNRELU) {
         const float4 y = ld4(reinterpret_cast<const T *>(w.src.Yin) + (long long)rr * w.src.ldin + k0);
-        va[j] = make_float4(fmaxf(0.f, y.x * a_sc.x + a_sh.x), fmaxf(0.f, y.y * a_sc.y + a_sh.y),
-                            fmaxf(0.f, y.z * a_sc.z + a_sh.z), fmaxf(0.f, y.w * a_sc.w + a_sh.w));
+        if (RAWF) va[j] = y;
+        else va[j] = make_float4(fmaxf(0.f, y.x * a_sc.x + a_sh.x), fmaxf(0.f, y.y * a_sc.y + a_sh.y),
+                                 fmaxf(0.f, y.z * a_sc.z + a_sh.z), fmaxf(0.f, y.w * a_sc.w + a_sh.w));
       } else {
         va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
@@ -1425,6 +1435,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   for (long long tile = t0; tile < t1; ++tile) {
     __syncthreads();  // the previous tile's MFMA reads are done
     vt = tail_chunk();
+    if constexpr (RAWF && !ST16) {
+      if (DYL == BNBWD) {
+#pragma unroll
+        for (int j = 0; j < NE_DY; ++j) vdy[j] = dyk.apply(rgf[j], vdy[j]);
+      }
+      if (LOADER == BNRELU) {
+#pragma unroll
+        for (int j = 0; j < (A8 ? 0 : MAXE_A); ++j)
+          va[j] = make_float4(fmaxf(0.f, va[j].x * a_sc.x + a_sh.x), fmaxf(0.f, va[j].y * a_sc.y + a_sh.y),
+                              fmaxf(0.f, va[j].z * a_sc.z + a_sh.z), fmaxf(0.f, va[j].w * a_sc.w + a_sh.w));
+      }
+    }
     if (BF) {
       // rows of the LDS tiles are 8 (mod 16) bytes apart (bank layout of the operand reads): two 8-byte stores per element
       if constexpr (ST16) {
@@ -1598,7 +1620,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsWgradBatch t)
   w.KP = (jb.K + 31) & ~31;
   w.partials = jb.partials;
   w.tiles_per_block = jb.tpb;
-  wgrad_body<float, 64, LOADER, MAXT, DYL, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
+  wgrad_body<float, 64, LOADER, MAXT, DYL, true, false, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
 }
 
 // dW[i] = sum_b partials[b][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups
