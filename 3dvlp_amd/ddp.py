@@ -201,15 +201,27 @@ class FlatGradBucket:
         (torch.optim skips grad-None parameters) — no weight decay on, and no optimiser state for, sub-modules that
         exist only so that reference checkpoints load (lang_emb_proj, box_con_proj, NCELoss.tau, ...).  All ranks run
         the same graph, so the touched set is the same everywhere."""
+        self._collect(None)
+
+    def collect_subset(self, params):
+        """collect() for some of the parameters only (the launch goes to the CURRENT stream): the step driver's split
+        backward completes the gradients of two disjoint parameter sets on two streams, and each set is copied into its
+        slices of the flat buffer on the stream that produced it.  Every parameter must be covered by exactly one call."""
+        self._collect({id(p) for p in params})
+
+    def _collect(self, only):
         dst, src = [], []
-        self.touched = []
-        for p, v in zip(self.params, self.views):
+        if only is None or len(getattr(self, "touched", ())) != len(self.params):
+            self.touched = [False] * len(self.params)
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if only is not None and id(p) not in only:
+                continue
             got = p.grad is not None
             if got and p.grad.data_ptr() != v.data_ptr():
                 dst.append(v)
                 src.append(p.grad.to(torch.float32) if p.grad.dtype != torch.float32 else p.grad)
             p.grad = v if got else None
-            self.touched.append(got)
+            self.touched[i] = got
         if dst:
             torch._foreach_copy_(dst, src)
 

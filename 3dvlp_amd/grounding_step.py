@@ -386,15 +386,20 @@ class GroundingStep:
                     queue = qctx.__enter__()
                     # (retain_graph: without it the engine releases the saved tensors of the nodes it did NOT run as well)
                     torch.autograd.backward([loss], inputs=head + boundary, retain_graph=True)
+                head_ids = {id(p) for p in head}
+                tail = [p for p in self.model.parameters() if id(p) not in head_ids]
                 with torch.cuda.graph(self._gD, stream=self._side):
                     queue.flush()
+                    # the head parameters' gradients are complete HERE, on this stream: their copy into the flat buffer must
+                    # not run on the main stream beside this graph (it would read buffers the flush is still filling)
+                    self.bucket.collect_subset(head)
                 with torch.cuda.graph(self._gM2):
                     torch.autograd.backward(boundary, [t.grad for t in boundary])
                     qctx.__exit__(None, None, None)
                     for t in boundary:
                         t.grad = None
                     self._static_out = _detached(out)
-                    self.bucket.collect()
+                    self.bucket.collect_subset(tail)
                     add_norm.advance(self.device)
                     self._static_loss = loss.detach()
                 del boundary, out, loss

@@ -378,6 +378,43 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
+def test_split_backward_gradients_do_not_depend_on_side_stream_timing():
+    """The captured, pipelined step finishes the weight-gradient-only work on the side stream while the main stream runs the
+    backward of SA2 / SA1 (GroundingStep._capture).  Every consumer of those gradients must be ordered after the side
+    stream's graph — round 3 found the flat-bucket copy of ALL parameters on the main stream beside it (stale head gradients
+    whenever the side stream was late; it surfaced as a NaN at cfg5's size once in a full test run).  Two identical step
+    objects with learning rate 0 (the weights never move, so the second step's gradient is a function of its batch alone)
+    run batch A, then batch B; in one of them the side stream's deferred graph is held back by 30 ms in the second step.
+    Both must leave batch B's gradient; a consumer that does not wait would leave batch A's in the head parameters."""
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    devc = torch.device("cuda:0")
+    batches = [gs.batch_to_device(synth.make_batch(4 * i, 2, num_points=8192, lang_num_max=2), devc) for i in range(2)]
+    for b in batches:
+        b["random"] = torch.tensor(0.25, device=devc)
+    flats = []
+    for delayed in (False, True):
+        step = gs.GroundingStep(devc, sa_dtype=None, use_graph=True, pipeline=True, lr=0.0)
+        _eval_dropout_train_bn(step)
+        step.run(batches[0], batches[1])
+        torch.cuda.synchronize()
+        first = step.bucket.flat.clone()
+        assert step._gD is not None, "the split backward is what this test is about"
+        if delayed:
+            real = step._gD.replay
+
+            def late_replay():
+                torch.cuda._sleep(int(30e-3 * 2.0e9))  # on the side stream (replay() is called under it)
+                real()
+            step._gD.replay = late_replay
+        step.run(batches[1], batches[1])
+        torch.cuda.synchronize()
+        flats.append(step.bucket.flat.clone())
+        assert torch.isfinite(flats[-1]).all()
+        assert _rel(flats[-1], first) > 1e-2, "the two batches must give different gradients for this test to see anything"
+    assert _rel(flats[1], flats[0]) < 1e-4, _rel(flats[1], flats[0])
+
+
 def test_geometry_pipeline_and_graph_equal_inline_step():
     """Precomputed backbone geometry (side stream) and hipGraph replay give the same STEP as the inline path: the flat
     gradient, the updated parameters and every persistent buffer (BatchNorm running statistics and counters) after
