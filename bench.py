@@ -252,6 +252,9 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     xat_alg, xat_moved = (2 * q.numel() + 2 * kc.numel()) * 2, (2 * q.numel() + 2 * kc.numel()) * 4
     # SA1 layer-1 weight gradient: dW1 = dY1^T A0 over the evaluated rows: features once, G1 and Y1 rows once, the row map
     wg_bytes = B * n * C * 4 + rows * (2 * cout * esz + 16)
+    # SA1 layer-3 input gradient (vlp3d_sa_bwd_layer, pooled-gradient loader + mask epilogue): Y3 and Y2 rows once, G2 written,
+    # the row map, the pooled gradient / arg-max tensors of the balls
+    dg_bytes = rows * (128 * esz + 2 * 64 * esz + 16) + B * m * 128 * 5
     rel_pairs = B * 256 * 256
     rel_flops = rel_pairs * 2.0 * (4 * 32 + 32 * 32 + 32 * 4) * 3   # forward recomputation + both backward products per pair
     gname = ("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>")
@@ -266,14 +269,18 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
                     "rows; `achieved` counts the bytes of the rows evaluated" % (100.0 * rows / R)) if compact else "padded rows"),
         entry("wgrad_kernel<bf16,...,GATHER> SA1 layer 1 weight gradient (dY1^T x gathered rows)", "wgrad_kernel", "hbm", wg_bytes,
               PEAK_HBM_GBS, "GB/s", None, in_step("vlp3d_sa_wgrad", is_sa1), algorithmic_bytes=wg_bytes),
-        entry("relation_bias_bwd_kernel (pairwise-geometry bias MLP 4->32->32->4, backward, one of two layers)",
-              "relation_bias_bwd", "mfma", rel_flops, PEAK_BF16_MFMA_TFLOPS / 16, "TFLOP/s", None, in_step("vlp3d_relation_bias_bwd"),
-              peak_is="exact-fp32 MFMA (1/16 of the bf16 rate)", pairs=rel_pairs),
+        entry("row_gemm_lds_kernel<64,BNBWD,MASK> SA1 layer 3 input gradient (pooled-gradient loader, 128->64 GEMM, ReLU mask + "
+              "BN-backward sums)", "row_gemm_lds_kernel<64, 2, 1>", "hbm", dg_bytes, PEAK_HBM_GBS, "GB/s", None,
+              in_step("vlp3d_sa_bwd_layer", lambda a: a[0] == R and a[1] == 128), algorithmic_bytes=dg_bytes,
+              note="runs beside the side stream's deferred weight-gradient graph (GroundingStep: split backward)"),
     ]
     cands = [c for c in cands if c["ms"] is not None]
     head = max(cands, key=lambda c: c["ms"] if c["ms_is"].startswith("in-step") else 0.0)
     head = dict(head, kernel=head["kernel"] + ": dominant main-stream kernel by in-step duration")
     others = [c for c in cands if c["kernel"] not in head["kernel"]] + [
+        entry("relation_bias_bwd_kernel (pairwise-geometry bias MLP 4->32->32->4, backward, one of two layers; side stream since "
+              "the split backward)", "relation_bias_bwd", "mfma", rel_flops, PEAK_BF16_MFMA_TFLOPS / 16, "TFLOP/s", None,
+              in_step("vlp3d_relation_bias_bwd"), peak_is="exact-fp32 MFMA (1/16 of the bf16 rate)", pairs=rel_pairs),
         entry("fps_pruned_kernel SA1 40000->2048 (side stream; bounding-box pruned FPS, same indices as the dense kernel)", "fps_pruned_kernel",
               "valu", fps_flops, fps_peak, "TFLOP/s", fps_ms, in_step("vlp3d_furthest_point_sampling_pruned"), cus_used=B,
               numerator="ALGORITHMIC: the dense algorithm's B*(m-1)*n distance-update-compares x 11 flop; the kernel "

@@ -32,6 +32,28 @@ for bf in (1, 0):
     stats = torch.empty((int(ext.load().vlp3d_sa_stat_slabs(R)), 2, cout), dtype=torch.float64, device=dev)
     for _ in range(3):
         ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf, *(cm if bf else (None, None, 0)))
+# SA1 layer-3 input gradient (pooled-gradient loader, 128 -> 64, mask epilogue) and the gather layer's weight gradient on the
+# compact rows, bf16: the two largest main-stream kernels of the backward pass (bench.py roofline candidates)
+R = B * m * 64
+Y3 = torch.randn(R, 128, device=dev).to(torch.bfloat16)
+Y2 = torch.randn(R, 64, device=dev).to(torch.bfloat16)
+Y1 = torch.randn(R, 64, device=dev).to(torch.bfloat16)
+G1 = torch.randn(R, 64, device=dev).to(torch.bfloat16)
+c5_3, c5_1 = torch.rand(5, 128, device=dev) + 0.5, torch.rand(5, 64, device=dev) + 0.5
+WT3 = (torch.randn(64, 128, device=dev) * 0.05).to(torch.bfloat16)
+vec2 = torch.rand(4, 64, device=dev) + 0.5
+nslab = int(ext.load().vlp3d_sa_stat_slabs(R))
+t2 = torch.empty((nslab, 2, 64), dtype=torch.float64, device=dev)
+gsel = torch.randn(B * m, 128, device=dev)
+sel = torch.randint(0, 16, (B * m, 128), device=dev, dtype=torch.uint8)
+G2 = torch.empty((R, 64), dtype=torch.bfloat16, device=dev)
+dW = torch.empty((64, 144), device=dev)
+nblk = 1024
+part = torch.empty((nblk, 64, 144), device=dev)
+for _ in range(3):
+    ext.call("vlp3d_sa_bwd_layer", None, Y3, R, 128, c5_3, WT3, 64, Y2, vec2, G2, t2, gsel, sel, 64, 1, *cm)
+    ext.call("vlp3d_sa_wgrad", G1, Y1, R, 64, c5_1, 1, None, 144, None, None, xyz, new_xyz, idx, feat_pm, n, m, 64, 132, 0.2,
+             dW, part, nblk, None, None, 0, 1, 0, *cm)
 q = torch.randn(64, 256, 128, device=dev)
 kc = torch.randn(64, 49, 128, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
