@@ -194,6 +194,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   // The kernel is one dependent chain per scene on 8 of the 256 CUs while the step's dense kernels fill the chip: waves of
   // those kernels that land on the same SIMDs compete for instruction issue (3.4 ms inside the step against 2.8 ms alone).
   // Highest wave priority: the arbiter serves these waves first; the dense kernels lose nothing measurable.
+  // (Tried and rejected, round 3: 16 more slots per wave in REGISTERS — 50 of the 128 VGPRs a 1024-thread workgroup may use
+  // are taken — so that 25 instead of 9 of SA1's 40 slots per wave never touch L2.  A compare-and-select chain per access:
+  // 2.80 -> 3.65 ms; indexed register moves (s_set_gpr_idx): 3.04 ms.  The L2 reads of an iteration's active slots are issued
+  // together and are not what the slowest wave waits for.)
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ float4 lpts[];  // [L][1024]: slots 0..L-1 of every wave; then int s_out[m_lds]: sorted positions
   int *s_out = reinterpret_cast<int *>(lpts + (size_t)L * 1024);  // of the samples (idx = perm[pos], written at the end)
