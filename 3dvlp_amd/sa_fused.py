@@ -22,7 +22,7 @@ WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 2048))
 WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
 
 
-WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 32))  # cap on the partial-dW slabs of one launch
+WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 16))  # cap on the partial-dW slabs of one launch
 
 
 def _wgrad_blocks(R, cout, K):
