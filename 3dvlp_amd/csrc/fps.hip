@@ -394,14 +394,92 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float *__re
   }
   if (bad && p < N) *not_prefix = 1;
 }
+
+// The same two passes for m <= 2048 samples with EIGHT lanes per point / sample and every sample of the scene in LDS at once
+// (the forms above give a lane 1024 dependent iterations and launch 32-64 workgroups: 62 + 78 us for the three levels of cfg2
+// on the geometry stream, which is the step's critical path since the split backward).  v: the lanes of a group take every
+// eighth earlier sample.  check: the running minimum is a prefix minimum over the samples, so a group splits the samples that
+// matter for its point (q < steps - 1) into eight contiguous parts: each lane first takes the minimum of its part, an exclusive
+// prefix minimum over the group gives its starting value, then it walks its part again with the comparisons.
+constexpr int PFX_LANES = 8;
+__global__ __launch_bounds__(256) void fps_prefix_v8_kernel(const float *__restrict__ xyz_all, int N, int m,
+                                                            float *__restrict__ v_all, int *__restrict__ not_prefix) {
+  extern __shared__ float4 sall[];  // [m]: (x, y, z, -)
+  const int b = blockIdx.y, part = threadIdx.x & (PFX_LANES - 1);
+  const int i = blockIdx.x * (256 / PFX_LANES) + threadIdx.x / PFX_LANES;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *not_prefix = 0;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  const int iend = min((int)(blockIdx.x + 1) * (256 / PFX_LANES), m);  // samples q < iend are all this block needs
+  for (int q = threadIdx.x; q < iend; q += 256) sall[q] = make_float4(xyz[q * 3], xyz[q * 3 + 1], xyz[q * 3 + 2], 0.f);
+  __syncthreads();
+  const int ic = min(i, m - 1);
+  const float4 me = sall[min(ic, iend - 1)];
+  float v = 1e10f;
+  for (int q = part; q < ic; q += PFX_LANES) {
+    const float4 s = sall[q];
+    v = fminf(v, vlp3d_sumsq3(me.x - s.x, me.y - s.y, me.z - s.z));
+  }
+#pragma unroll
+  for (int off = 1; off < PFX_LANES; off <<= 1) v = fminf(v, __shfl_xor(v, off));
+  if (i < m && part == 0) v_all[(size_t)b * m + i] = v;
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_check8_kernel(const float *__restrict__ xyz_all, int N, int m,
+                                                                const float *__restrict__ v_all, int *__restrict__ not_prefix) {
+  extern __shared__ float4 sall[];  // [m - 1]: (x, y, z of sample q, v[q + 1])
+  const int b = blockIdx.y, part = threadIdx.x & (PFX_LANES - 1);
+  const int p = blockIdx.x * (256 / PFX_LANES) + threadIdx.x / PFX_LANES;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  const float *__restrict__ v = v_all + (size_t)b * m;
+  for (int q = threadIdx.x; q < m - 1; q += 256) sall[q] = make_float4(xyz[q * 3], xyz[q * 3 + 1], xyz[q * 3 + 2], v[q + 1]);
+  __syncthreads();
+  const int pc = min(p, N - 1);
+  const float x = xyz[pc * 3], y = xyz[pc * 3 + 1], z = xyz[pc * 3 + 2];
+  bool bad = false;
+  if (part == 0) {
+    bad = vlp3d_fps_skipped(x, y, z);
+    if (p >= 1 && p < m) bad = bad || !(v[p] > 0.f);
+  }
+  const int steps = p < m ? p : m;
+  const int nq = max(steps - 1, 0);                     // samples q = 0 .. nq - 1 carry a comparison (q + 1 < steps)
+  const int len = (nq + PFX_LANES - 1) / PFX_LANES;
+  const int q0 = min(part * len, nq), q1 = min(q0 + len, nq);
+  float rmin = 1e10f;
+  for (int q = q0; q < q1; ++q) {
+    const float4 s = sall[q];
+    rmin = fminf(rmin, vlp3d_sumsq3(x - s.x, y - s.y, z - s.z));
+  }
+  // exclusive prefix minimum over the group's lanes (lane ids inside the group are consecutive)
+  float incl = rmin;
+#pragma unroll
+  for (int off = 1; off < PFX_LANES; off <<= 1) {
+    const float o = __shfl_up(incl, off, PFX_LANES);
+    if (part >= off) incl = fminf(incl, o);
+  }
+  float r = __shfl_up(incl, 1, PFX_LANES);
+  if (part == 0) r = 1e10f;
+  for (int q = q0; q < q1; ++q) {
+    const float4 s = sall[q];
+    r = fminf(r, vlp3d_sumsq3(x - s.x, y - s.y, z - s.z));
+    bad = bad || !(r < s.w);
+  }
+  if (bad && p < N) *not_prefix = 1;
+}
 }  // namespace
 
 // v: (B, m) floats of scratch; not_prefix: one int (0 = "the sampling order is 0..m-1" proven).  N, m <= 65536.
 extern "C" int vlp3d_fps_prefix_check(const float *xyz, int B, int N, int m, float *v, int *not_prefix, void *stream) {
   if (!xyz || !v || !not_prefix || B < 1 || N < 1 || m < 1 || m > N || N > 65536) return VLP3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fps_prefix_v_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
-  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
+  if (m <= 2048) {
+    constexpr int PPB = 256 / PFX_LANES;  // points / samples per workgroup
+    const size_t lds = (size_t)m * sizeof(float4);
+    hipLaunchKernelGGL(fps_prefix_v8_kernel, dim3((m + PPB - 1) / PPB, B), dim3(256), lds, s, xyz, N, m, v, not_prefix);
+    hipLaunchKernelGGL(fps_prefix_check8_kernel, dim3((N + PPB - 1) / PPB, B), dim3(256), lds, s, xyz, N, m, v, not_prefix);
+  } else {
+    hipLaunchKernelGGL(fps_prefix_v_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
+    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, m, v, not_prefix);
+  }
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
