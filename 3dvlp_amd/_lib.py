@@ -83,7 +83,7 @@ SIGNATURES = {
     "vlp3d_linear_wgrad": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_relation_bias_nparam": [],
     "vlp3d_relation_bias_fwd": [_vp, _vp, _i, _i, _vp, _vp],
-    "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "vlp3d_relation_bias_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp],
     "vlp3d_rows_slabs": [ctypes.c_longlong],
     "vlp3d_rows_fwd": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "vlp3d_rows_fwd_wt": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],

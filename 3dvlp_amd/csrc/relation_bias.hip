@@ -13,6 +13,8 @@
 // The geometry input carries no gradient (the reference detaches it, :86-87).  The file is compiled with
 // -ffp-contract=off like the rest of the library; the dot products use explicit fused multiply-adds (as a BLAS GEMM
 // does) — half the VALU instructions of separate multiplies and adds.
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 namespace {
@@ -157,6 +159,28 @@ __device__ __forceinline__ f32x16 rank32_update(const float *__restrict__ A, con
   }
   return acc;
 }
+typedef short bf16x8_rb __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ short rb_bf16(float v) {
+  __hip_bfloat16 h = __float2bfloat16(v);
+  return *reinterpret_cast<short *>(&h);
+}
+// bf16 form of rank32_update (timing configuration): the same contraction over the tile's 32 pairs as two 32x32x16 steps;
+// lane (r, half) supplies pairs 16 s + 8 half + t, t = 0..7, of feature column r (operands rounded to bf16, fp32 accumulation)
+__device__ __forceinline__ f32x16 rank32_update_bf16(const float *__restrict__ A, const float *__restrict__ Bm, int r, int half,
+                                                     f32x16 acc) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    bf16x8_rb a, b;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = 16 * s2 + 8 * half + t;
+      a[t] = rb_bf16(A[row * LDT + r]);
+      b[t] = rb_bf16(Bm[row * LDT + r]);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
 __device__ __forceinline__ float column_sum32(const float *__restrict__ A, int r, int half) {
   float s = 0.f;
 #pragma unroll 8
@@ -164,6 +188,11 @@ __device__ __forceinline__ float column_sum32(const float *__restrict__ A, int r
   return s + __shfl_xor(s, 32);
 }
 
+// BF (the step's bf16 timing configuration): the input-gradient product dH1 = W2^T dZ2 and the three rank-32 parameter-gradient
+// updates run as v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 in registers (16 exact + 8 bf16 matrix instructions per
+// 32-pair tile instead of 80 exact ones: the fp32 MFMAs were a third of the kernel); the recomputed forward (layer 1, the
+// layer-2 product, both LayerNorms) and all sums stay fp32.
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *__restrict__ centre,
                                                                  const float *__restrict__ Pg,
                                                                  const float *__restrict__ dout, int B, int K,
@@ -183,6 +212,15 @@ __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *
     const int f = acc_row(kk, hh);
     A2[i] = Pg[O_W2 + c * HID + f];
     A2T[i] = Pg[O_W2 + f * HID + c];
+  }
+  // bf16 image for the 32x32x16 input-gradient product: [(s2 * 2 + h) * 32 + i][8]: element t = W2[F(8 s2 + t, h)][i] — one
+  // 16-byte LDS read per operand
+  short *A2Tb = reinterpret_cast<short *>(tiles + 4 * 2 * 32 * LDT);
+  if (BF) {
+    for (int i = threadIdx.x; i < HID * HID; i += 256) {
+      const int t = i & 7, row = (i >> 3) & 31, sh = i >> 8;  // sh = s2 * 2 + h
+      A2Tb[i] = rb_bf16(Pg[O_W2 + acc_row(8 * (sh >> 1) + t, sh & 1) * HID + row]);
+    }
   }
   __syncthreads();
   const int fo = 4 * half;  // F(e,h) = (e & 3) + 8 * (e >> 2) + 4h: compile-time part + fo
@@ -236,6 +274,8 @@ __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // (also in the bf16 configuration this product stays exact: z2 decides the ReLU mask and feeds LayerNorm 2's statistics,
+    // and a bf16 z2 put a coherent 3 % error on every gradient upstream of it — tools/relbias_bf16_err.py)
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const int f = FEAT(kk) + fo;
@@ -279,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *
                             __builtin_fmaf(sp[O_W3 + 2 * HID + f], dO[2],
                                            __builtin_fmaf(sp[O_W3 + HID + f], dO[1], sp[O_W3 + f] * dO[0])));
     }
-    accW3 = rank32_update(TA, TB, r, half, accW3);
+    accW3 = BF ? rank32_update_bf16(TA, TB, r, half, accW3) : rank32_update(TA, TB, r, half, accW3);
     s_b3 += column_sum32(TA, r, half);
     // LN2 affine grads, then through LN2 and ReLU
 #pragma unroll
@@ -306,14 +346,25 @@ __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *
       TA[r * LDT + f] = v[e];
       TB[r * LDT + f] = __builtin_fmaf(n1[e], sp[O_G1 + f], sp[O_E1 + f]);  // h1
     }
-    accW2 = rank32_update(TA, TB, r, half, accW2);
+    accW2 = BF ? rank32_update_bf16(TA, TB, r, half, accW2) : rank32_update(TA, TB, r, half, accW2);
     s_b2 += column_sum32(TA, r, half);
     // dH1^T = W2^T dZ2^T on the matrix cores
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (BF) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2T[(half * 16 + kk) * 32 + r], v[kk], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_rb vb;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) vb[t] = rb_bf16(v[8 * s2 + t]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_rb *>(A2Tb + ((s2 * 2 + half) * 32 + r) * 8), vb,
+                                                      acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2T[(half * 16 + kk) * 32 + r], v[kk], acc, 0, 0, 0);
+    }
     // LN1 affine grads, through LN1 and ReLU
     a1 = a2 = 0.f;
 #pragma unroll
@@ -340,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *
       TA[r * LDT + f] = ((m1 >> e) & 1u) ? g : 0.f;
       TB[r * LDT + f] = (half == 0 && e < 4) ? x[e & 3] : 0.f;
     }
-    accW1 = rank32_update(TA, TB, r, half, accW1);
+    accW1 = BF ? rank32_update_bf16(TA, TB, r, half, accW1) : rank32_update(TA, TB, r, half, accW1);
     s_b1 += column_sum32(TA, r, half);
   }
 #undef FEAT
@@ -415,7 +466,7 @@ extern "C" int vlp3d_relation_bias_fwd(const float *centre, const float *params,
 
 // dout (B,4,K,K) -> dparams (NPARAM); slabs: scratch of at least nblocks*NPARAM floats (nblocks >= 1).
 extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
-                                       float *dparams, float *slabs, int nblocks, void *stream) {
+                                       float *dparams, float *slabs, int nblocks, int bf16_mma, void *stream) {
   if (!centre || !params || !dout || !dparams || !slabs || B < 1 || K < 1 || nblocks < 1 ||
       (long long)B * K * K >= (1ll << 32))
     return VLP3D_EINVAL;
@@ -423,9 +474,13 @@ extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params,
   const long long ntiles = ((long long)B * K * K + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > nblocks) blocks = nblocks;
-  const size_t lds = (size_t)(NPARAM + 4 + 2 * HID * HID + 4 * 2 * 32 * LDT) * sizeof(float);
-  hipLaunchKernelGGL(relation_bias_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
-                     slabs);
+  const size_t lds = (size_t)(NPARAM + 4 + 2 * HID * HID + 4 * 2 * 32 * LDT) * sizeof(float) + HID * HID * sizeof(short);
+  if (bf16_mma)
+    hipLaunchKernelGGL(relation_bias_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
+                       slabs);
+  else
+    hipLaunchKernelGGL(relation_bias_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
+                       slabs);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((NPARAM + 63) / 64), dim3(256), 0, s, slabs, (int)blocks, NPARAM, dparams);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

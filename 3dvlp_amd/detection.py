@@ -21,6 +21,7 @@ from . import _lib as _ext
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from . import glue, row_mlp
 from .ddp import merge_adjacent
+from . import mfma_linear
 from .mfma_linear import linear as _linear
 from .transformer import MultiHeadAttention
 
@@ -382,6 +383,7 @@ class _RelationBias(torch.autograd.Function):
         out = torch.empty((B, 4, K, K), dtype=torch.float32, device=centre.device)
         _ext.call("vlp3d_relation_bias_fwd", centre, params, B, K, out)
         ctx.save_for_backward(centre, params)
+        ctx.bf16_mma = int(mfma_linear.BF16_MMA)  # the step's bf16 timing configuration (read at forward: backward runs outside its context)
         return out
 
     @staticmethod
@@ -392,8 +394,9 @@ class _RelationBias(torch.autograd.Function):
         dparams = torch.empty_like(params)
         slabs = torch.empty((_RelationBias.SLAB_BLOCKS, n), dtype=torch.float32, device=centre.device)
         dout = dout.contiguous().float()
+        bf = ctx.bf16_mma
         run = lambda: _ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dparams, slabs,
-                                _RelationBias.SLAB_BLOCKS)
+                                _RelationBias.SLAB_BLOCKS, bf)
         q = _ext.slab_queue()
         if q is not None:  # only parameter gradients come out of this kernel: it runs with the other optimiser-only launches
             q.defer(run, (centre, params, dout, dparams, slabs))

@@ -373,9 +373,11 @@ int vlp3d_box_decode_bwd(const float *rois, const float *heading, const int *hea
  * (the order of nn.Sequential.parameters()).  centre (B,K,3) -> out (B,4,K,K). */
 int vlp3d_relation_bias_nparam(void);
 int vlp3d_relation_bias_fwd(const float *centre, const float *params, int B, int K, float *out, void *stream);
-/* dout (B,4,K,K) -> dparams (nparam, fully written); slabs: scratch of nblocks*nparam floats (one partial per workgroup). */
+/* dout (B,4,K,K) -> dparams (nparam, fully written); slabs: scratch of nblocks*nparam floats (one partial per workgroup).
+ * bf16_mma != 0: the 32 x 32 layer products and the parameter-gradient updates as bf16 MFMA (operands rounded in registers,
+ * fp32 accumulation; the step's timing configuration); 0: exact fp32 MFMA (parity configuration). */
 int vlp3d_relation_bias_bwd(const float *centre, const float *params, const float *dout, int B, int K,
-                            float *dparams, float *slabs, int nblocks, void *stream);
+                            float *dparams, float *slabs, int nblocks, int bf16_mma, void *stream);
 
 /* replaces the att = softmax(QK^T/sqrt(dk) [+bias | *w] [mask]) V core of
  * models/transformer/attention.py:63-75 without materialising att.

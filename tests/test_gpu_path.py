@@ -367,6 +367,37 @@ def test_relation_bias_fused_forward_backward():
         assert (a.double() - b).abs().max().item() < 2e-4 * scale + 1e-5, n
 
 
+def test_relation_bias_backward_bf16_mma_close_to_fp64():
+    """The bf16-MFMA form of the relation-bias backward (the step's timing configuration: mfma_linear.bf16_mma) against the
+    fp64 op sequence: operands of the two 32 x 32 products and of the rank-32 updates are rounded to bf16 (2^-9 relative each),
+    the sums over B*K*K pairs are fp32; the recomputed forward stays exact — parameter gradients within 1 % of their scale
+    (0.2-0.5 % measured, tools/relbias_bf16_err.py; a bf16 layer-2 forward product gave 3-5 %)."""
+    det = importlib.import_module("3dvlp_amd.detection")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    torch.manual_seed(4)
+    B, K = 3, 70
+    m = det.RelationModule(num_proposals=K, det_channel=128).cuda()
+    fc = m.self_attn_fc[1]
+    with torch.no_grad():
+        for p in fc.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    centre = torch.rand(B, K, 3, device="cuda") * 4
+    with ml.bf16_mma(True):
+        out = det.relation_bias(centre, fc)
+    import copy
+    fc64 = copy.deepcopy(fc).double()
+    c64 = centre.double()
+    delta = c64[:, None, :, :] - c64[:, :, None, :]
+    pair = torch.cat([delta, delta.pow(2).sum(-1, keepdim=True).sqrt()], dim=-1)
+    ref = fc64(pair).permute(0, 3, 1, 2)
+    g = torch.randn_like(out)
+    got = torch.autograd.grad(out, list(fc.parameters()), g)
+    exp = torch.autograd.grad(ref, list(fc64.parameters()), g.double())
+    for (n, _), a, b in zip(fc.named_parameters(), got, exp):
+        scale = b.abs().max().item()
+        assert (a.double() - b).abs().max().item() < 1e-2 * scale + 1e-4, (n, (a.double() - b).abs().max().item(), scale)
+
+
 def _eval_dropout_train_bn(step):
     step.model.eval()  # no dropout: execution variants must agree numerically
     for m in step.model.modules():

@@ -22,4 +22,4 @@ def t(fn, reps=20):
     e.record(); e.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 print("fwd %.1f us" % t(lambda: ext.call("vlp3d_relation_bias_fwd", centre, params, B, K, out)))
-print("bwd %.1f us" % t(lambda: ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dpar, slabs, nb)))
+print("bwd %.1f us" % t(lambda: ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dpar, slabs, nb, 0)))

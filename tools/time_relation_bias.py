@@ -26,7 +26,7 @@ ref = None
 for blocks in (256, 384, 512, 768, 1024):
     slabs = torch.empty(blocks, n, device="cuda")
     dp = torch.empty(n, device="cuda")
-    us = t(lambda: ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dp, slabs, blocks))
+    us = t(lambda: ext.call("vlp3d_relation_bias_bwd", centre, params, dout, B, K, dp, slabs, blocks, 0))
     if ref is None: ref = dp.clone()
     print(f"blocks {blocks}: {us:.1f} us (bwd + slab sum), rel diff vs 256 blocks {((dp - ref).norm() / ref.norm()).item():.1e}")
 out = torch.empty(B, 4, K, K, device="cuda")
