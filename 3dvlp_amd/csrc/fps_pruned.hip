@@ -199,6 +199,11 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   // 2.80 -> 3.65 ms; indexed register moves (s_set_gpr_idx): 3.04 ms.  The L2 reads of an iteration's active slots are issued
   // together and are not what the slowest wave waits for.)
   __builtin_amdgcn_s_setprio(3);
+#ifndef VLP3D_FPS_SHARE_CU
+  // ... and the workgroup claims its CU's whole register file (16 waves x 128 VGPRs; the kernel itself needs 50): no wave of
+  // another kernel can become resident on these 8 CUs while the chain runs, so nothing competes for their issue slots and LDS.
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");
+#endif
   extern __shared__ float4 lpts[];  // [L][1024]: slots 0..L-1 of every wave; then int s_out[m_lds]: sorted positions
   int *s_out = reinterpret_cast<int *>(lpts + (size_t)L * 1024);  // of the samples (idx = perm[pos], written at the end)
   // per parity and wave: the wave's candidate (value, sorted position) and its coordinates.  Lanes 0..15 fetch BOTH for
