@@ -112,7 +112,37 @@ __global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__
     c = c < 0 ? 0 : (c > 31 ? 31 : c);  // also catches NaN -> 0
     q[a] = (unsigned)c;
   }
+#ifdef VLP3D_FPS_MORTON
   const int cell = (int)(spread5(q[0]) | (spread5(q[1]) << 1) | (spread5(q[2]) << 2));
+#else
+  // position of the cell on the 3-D Hilbert curve (Skilling's transpose form, 5 bits per axis): consecutive cells are face
+  // neighbours, so a slot (64 consecutive sorted points) never straddles one of the Z-order curve's long jumps and its
+  // bounding box is tighter — fewer (slot, wave) pairs pass the pruning test per iteration.  Only the ORDER of the cells
+  // changes; histogram, scan and scatter are the same.
+  {
+    const unsigned M = 1u << (CELL_BITS - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+      const unsigned P = Q - 1;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (q[a] & Q) {
+          q[0] ^= P;
+        } else {
+          const unsigned t = (q[0] ^ q[a]) & P;
+          q[0] ^= t;
+          q[a] ^= t;
+        }
+      }
+    }
+    q[1] ^= q[0];
+    q[2] ^= q[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+      if (q[2] & Q) t ^= Q - 1;
+    q[0] ^= t; q[1] ^= t; q[2] ^= t;
+  }
+  const int cell = (int)((spread5(q[0]) << 2) | (spread5(q[1]) << 1) | spread5(q[2]));
+#endif
   cellid[(size_t)b * N + k] = cell;
   atomicAdd(hist + (size_t)b * NCELL + cell, 1);
 }
