@@ -278,8 +278,75 @@ __global__ __launch_bounds__(256) void rows_act_kernel(const float *__restrict__
 }
 
 // G = dOut * act'(Y*scale + shift), per-workgroup column sums of G and G*yhat -> slab [blockIdx.x][2][C]; with a PReLU slope
-// also sum(dOut * min(v, 0)) -> dslope slab [blockIdx.x][C]; thread = column
+// also sum(dOut * min(v, 0)) -> dslope slab [blockIdx.x][C].  A workgroup owns `rows_per_block` (<= 64) rows; a thread = four
+// consecutive columns x every RL-th row of them (RL = 256 / (C/4) row lanes), all of its rows in flight at once, the column
+// sums of the row lanes folded through LDS.  (First form: thread = column walking 64 rows four at a time — 16 dependent
+// round trips, 128 of 256 threads idle at C = 128: 23 us for a 2048 x 128 matrix.)
 __global__ __launch_bounds__(256) void rows_act_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ Y,
+                                                           long long R, int C, const float *__restrict__ vec,
+                                                           const float *__restrict__ slope, long long rows_per_block,
+                                                           float *__restrict__ G, double *__restrict__ slabs,
+                                                           double *__restrict__ dslope) {
+  __shared__ double red[3][256][4];
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  const int c4n = C / 4;                       // float4 chunks per row (C % 4 == 0, C <= 1024: host-checked)
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n, RL = 256 / c4n;  // 256 % c4n == 0 (host-checked)
+  const int c = 4 * cl;
+  const float4 sc = ld4(vec + c), sh = ld4(vec + C + c), rs = ld4(vec + 2 * C + c), nm = ld4(vec + 3 * C + c);
+  const float4 al = slope ? ld4(slope + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, s3[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int INF = 8;  // rows in flight per thread
+  for (long long rb = r0 + rl; rb < r1; rb += (long long)RL * INF) {
+    float4 y[INF], d[INF];
+#pragma unroll
+    for (int u = 0; u < INF; ++u) {
+      const long long r = min(rb + (long long)u * RL, R - 1);  // clamped: unconditional loads
+      y[u] = ld4(Y + r * C + c);
+      d[u] = ld4(dOut + r * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < INF; ++u) {
+      const long long r = rb + (long long)u * RL;
+      if (r >= r1) break;
+      const float yy[4] = {y[u].x, y[u].y, y[u].z, y[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+      const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+      const float nmv[4] = {nm.x, nm.y, nm.z, nm.w}, alv[4] = {al.x, al.y, al.z, al.w};
+      float g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = yy[e] * scv[e] + shv[e];
+        g[e] = v > 0.f ? dd[e] : alv[e] * dd[e];
+        s1[e] += g[e];
+        s2[e] += g[e] * (yy[e] * rsv[e] + nmv[e]);
+        s3[e] += v > 0.f ? 0.f : dd[e] * v;
+      }
+      *reinterpret_cast<float4 *>(G + r * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][threadIdx.x][e] = s1[e];
+    red[1][threadIdx.x][e] = s2[e];
+    red[2][threadIdx.x][e] = s3[e];
+  }
+  __syncthreads();
+  // thread t < C sums column t over the row lanes (fixed order: deterministic)
+  for (int col = threadIdx.x; col < C; col += 256) {
+    const int cc = col >> 2, e = col & 3;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int k = 0; k < RL; ++k) {
+      a1 += red[0][k * c4n + cc][e];
+      a2 += red[1][k * c4n + cc][e];
+      a3 += red[2][k * c4n + cc][e];
+    }
+    slabs[((size_t)blockIdx.x * 2) * C + col] = a1;
+    slabs[((size_t)blockIdx.x * 2 + 1) * C + col] = a2;
+    if (dslope) dslope[(size_t)blockIdx.x * C + col] = a3;
+  }
+}
+
+// generic form (any C): thread = column, four rows in flight
+__global__ __launch_bounds__(256) void rows_act_bwd_cols_kernel(const float *__restrict__ dOut, const float *__restrict__ Y,
                                                            long long R, int C, const float *__restrict__ vec,
                                                            const float *__restrict__ slope, long long rows_per_block,
                                                            float *__restrict__ G, double *__restrict__ slabs,
@@ -472,7 +539,7 @@ extern "C" int vlp3d_rows_act(const float *Y, long long R, int C, const float *v
 // G (R x C) = dOut masked by the ReLU of the last BatchNorm layer, tstats slabs [nslab][2][C] (nslab returned by
 // vlp3d_rows_act_slabs) for vlp3d_sa_bn_bwd_consts.  vec = that layer's [scale | shift | rstd | -mean*rstd].
 extern "C" int vlp3d_rows_act_slabs(long long R) {
-  const long long n = (R + 63) / 64;
+  const long long n = (R + 31) / 32;  // 32 rows per workgroup up to 256 workgroups (round 3: 64 -> 32, one per CU at 8192 rows)
   return (int)(n < 256 ? n : 256);
 }
 extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, const float *slope,
@@ -480,8 +547,12 @@ extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R
   if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 1 || (slope && !dslope_slabs)) return VLP3D_EINVAL;
   const int nslab = vlp3d_rows_act_slabs(R);
   const long long rpb = (R + nslab - 1) / nslab;
-  hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G, tstats,
-                     slope ? dslope_slabs : nullptr);
+  if (C >= 4 && (C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0)
+    hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G, tstats,
+                       slope ? dslope_slabs : nullptr);
+  else
+    hipLaunchKernelGGL(rows_act_bwd_cols_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G,
+                       tstats, slope ? dslope_slabs : nullptr);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
