@@ -113,3 +113,36 @@ def test_flat_bucket_allreduce_world8():
         assert torch.allclose(ret[r][6], ret[0][6])             # identical averaged gradients everywhere
     mean_local = torch.stack([ret[r][5] for r in range(world)]).mean(0)
     assert torch.allclose(ret[0][6], mean_local, atol=1e-6)
+
+
+def test_collect_subsets_equal_one_collect():
+    """FlatGradBucket.collect_subset over two disjoint parameter sets (the step driver's split backward: each stream copies the
+    gradients IT completed) leaves the same flat buffer, .grad views and touched flags as one collect()."""
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        m.add_module("unused", torch.nn.Linear(2, 2))
+        return m
+
+    x = torch.randn(8, 6)
+    res = []
+    for split in (False, True):
+        model = make()
+        bucket = ddp.FlatGradBucket(model)
+        bucket.zero()
+        model[2](model[1](model[0](x))).pow(2).mean().backward()
+        if split:
+            head = list(model[2].parameters()) + list(model.unused.parameters())
+            tail = [p for p in model.parameters() if all(p is not q for q in head)]
+            bucket.collect_subset(head)
+            bucket.collect_subset(tail)
+        else:
+            bucket.collect()
+        views_ok = all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        res.append((bucket.flat.clone(), list(bucket.touched), views_ok))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][1].count(False) == 2  # the unused layer's weight and bias
+    assert res[0][2] and res[1][2]
