@@ -95,6 +95,7 @@ SIGNATURES = {
     "vlp3d_rows_act_bwd": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_fp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_fp_rows_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "vlp3d_fp_rows_grad_csr": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_roi_split": [_vp, _i, ctypes.c_longlong, _i, _i, _f] + [_vp] * 8 + [_vp],
     "vlp3d_roi_split_bwd": [_vp] * 7 + [ctypes.c_longlong, _i, _i, _f, _vp, _i, _vp],
     "vlp3d_vote_epilogue": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],

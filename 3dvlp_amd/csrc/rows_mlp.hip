@@ -467,6 +467,46 @@ bool bad_gemm(const float *X, const float *W, const float *Y, long long R, int K
          (ldx & 3) || ldw < 1 || ldy < N;
 }
 
+// The same adjoint through the INVERSE of the three_nn map (vlp3d_sa_inverse(idx as (B, n, 3), N = m): inv_start (B*m + 1),
+// inv_refs = flat (b*n + p)*3 + k): a wave per known point sums w[ref] * dX[ref / 3][:C1] over its references with 16-byte
+// loads down whole rows — no LDS atomics, every output written once.  (The LDS-atomic form reads dX in 32-byte pieces, one
+// workgroup per scene and 8-channel slab: 34 + 17 us for the two FP modules of cfg2.)
+__global__ __launch_bounds__(256) void fp_rows_grad_csr_kernel(const float *__restrict__ dX, const float *__restrict__ w,
+                                                               const int *__restrict__ inv_start, const int *__restrict__ inv_refs,
+                                                               int nknown, int C1, int ld, float *__restrict__ dknown) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= nknown) return;
+  const int s0 = inv_start[j], cnt = inv_start[j + 1] - s0;
+  for (int c = 4 * lane; c < C1; c += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {  // four references in flight
+      int ref[4];
+      float wt[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ref[u] = inv_refs[s0 + i + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wt[u] = w[ref[u]];
+        v[u] = ld4(dX + (long long)(ref[u] / 3) * ld + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x += wt[u] * v[u].x; acc.y += wt[u] * v[u].y; acc.z += wt[u] * v[u].z; acc.w += wt[u] * v[u].w;
+      }
+    }
+    for (; i < cnt; ++i) {
+      const int ref = inv_refs[s0 + i];
+      const float wt = w[ref];
+      const float4 v = ld4(dX + (long long)(ref / 3) * ld + c);
+      acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+    }
+    *reinterpret_cast<float4 *>(dknown + (long long)j * C1 + c) = acc;
+  }
+}
+
 }  // namespace
 
 // workgroups (= statistic slabs of 2*N doubles each) a rows product over R rows is launched with
@@ -553,6 +593,18 @@ extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R
   else
     hipLaunchKernelGGL(rows_act_bwd_cols_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G,
                        tstats, slope ? dslope_slabs : nullptr);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// d_known (B*m, C1) through the inverse three_nn map (see fp_rows_grad_csr_kernel); C1 % 4 == 0, ld >= C1 and % 4 == 0.
+extern "C" int vlp3d_fp_rows_grad_csr(const float *dX, const float *weight, const int *inv_start, const int *inv_refs, int B,
+                                      int m, int C1, int ld, float *d_known, void *stream) {
+  if (!dX || !weight || !inv_start || !inv_refs || !d_known || B < 1 || m < 1 || C1 < 4 || (C1 & 3) || ld < C1 || (ld & 3))
+    return VLP3D_EINVAL;
+  const int nk = B * m;
+  hipLaunchKernelGGL(fp_rows_grad_csr_kernel, dim3((nk + 3) / 4), dim3(256), 0, (hipStream_t)stream, dX, weight, inv_start,
+                     inv_refs, nk, C1, ld, d_known);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -188,7 +188,11 @@ class PointnetFPModule(nn.Module):
         """Weight-independent part: three_nn indices + inverse-distance weights (:393-397)."""
         if unknown.is_cuda and unknown.dtype == torch.float32:
             dist2, idx = sa_fused_ext.three_nn(unknown.contiguous(), known.contiguous())
-            return idx, sa_fused_ext.three_nn_weights(dist2)   # sqrt, reciprocal, sum, divide: one launch
+            weight = sa_fused_ext.three_nn_weights(dist2)   # sqrt, reciprocal, sum, divide: one launch
+            if os.environ.get("VLP3D_FP_CSR", "1") != "0":
+                # known point -> references map for the atomic-free adjoint of the interpolation (row_mlp._FPRows.backward)
+                return (idx, weight) + tuple(sa_fused_ext.sa_inverse(idx, known.shape[1]))
+            return idx, weight
         dist, idx = pointnet2_utils.three_nn(unknown, known)
         dist_recip = 1.0 / (dist + 1e-8)
         return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
@@ -203,18 +207,16 @@ class PointnetFPModule(nn.Module):
             B, n = unknown_pm.shape[:2]
             if row_mlp.fp_rows_supported(known_pm, unknown_pm) and (B * n) % 32 == 0 and all(
                     hasattr(layer, "bn") and layer.conv.bias is None for layer in self.mlp):
-                if geometry is not None:
-                    idx, weight = geometry
-                else:
-                    idx, weight = self.compute_geometry(unknown, known)
-                X = row_mlp.fp_rows(known_pm, unknown_pm, idx, weight)
+                geo = geometry if geometry is not None else self.compute_geometry(unknown, known)
+                idx, weight = geo[:2]
+                X = row_mlp.fp_rows(known_pm, unknown_pm, idx, weight, tuple(geo[2:4]) if len(geo) >= 4 else None)
                 if row_mlp.supported(X, layers):
                     out = row_mlp.row_stack(X, layers)
                     return out.view(B, n, -1).transpose(1, 2)
         known_feats = known_feats.float().contiguous()
         if known is not None:
             if geometry is not None:
-                idx, weight = geometry
+                idx, weight = geometry[:2]
             else:
                 dist, idx = pointnet2_utils.three_nn(unknown, known)
                 dist_recip = 1.0 / (dist + 1e-8)

@@ -273,28 +273,32 @@ class _FPRows(Function):
     """[three_interpolate(known, idx, weight) | unknown] on point-major features: (B,m,C1), (B,n,C2) -> (B*n, C1+C2)."""
 
     @staticmethod
-    def forward(ctx, known, unknown, idx, weight):
+    def forward(ctx, known, unknown, idx, weight, inv):
         known, unknown = known.contiguous().float(), unknown.contiguous().float()
         B, m, C1 = known.shape
         n, C2 = unknown.shape[1:]
         X = torch.empty((B * n, C1 + C2), dtype=torch.float32, device=known.device)
         _ext.call("vlp3d_fp_rows", known, unknown, idx.contiguous(), weight.contiguous(), B, n, m, C1, C2, X)
-        ctx.save_for_backward(idx, weight)
+        ctx.save_for_backward(idx, weight, *(inv if inv is not None else ()))
         ctx.dims = (B, n, m, C1, C2)
         return X
 
     @staticmethod
     def backward(ctx, dX):
-        idx, weight = ctx.saved_tensors
+        idx, weight = ctx.saved_tensors[:2]
+        inv = ctx.saved_tensors[2:]
         B, n, m, C1, C2 = ctx.dims
         dX = dX.contiguous()
         dk = du = None
         if ctx.needs_input_grad[0]:
             dk = torch.empty((B, m, C1), dtype=torch.float32, device=dX.device)
-            _ext.call("vlp3d_fp_rows_grad", dX, idx.contiguous(), weight.contiguous(), B, n, m, C1, C1 + C2, dk)
+            if len(inv) == 2:  # inverse of the three_nn map (built with the geometry): a wave per known point, no atomics
+                _ext.call("vlp3d_fp_rows_grad_csr", dX, weight.contiguous(), inv[0], inv[1], B, m, C1, C1 + C2, dk)
+            else:
+                _ext.call("vlp3d_fp_rows_grad", dX, idx.contiguous(), weight.contiguous(), B, n, m, C1, C1 + C2, dk)
         if ctx.needs_input_grad[1]:
             du = dX.view(B, n, C1 + C2)[:, :, C1:]
-        return dk, du, None, None
+        return dk, du, None, None, None
 
 
 def fp_rows_supported(known_pm, unknown_pm):
@@ -302,5 +306,6 @@ def fp_rows_supported(known_pm, unknown_pm):
             and known_pm.shape[1] <= 1024)
 
 
-def fp_rows(known_pm, unknown_pm, idx, weight):
-    return _FPRows.apply(known_pm, unknown_pm, idx, weight)
+def fp_rows(known_pm, unknown_pm, idx, weight, inv=None):
+    """inv: (inv_start, inv_refs) = _lib.sa_inverse(idx (B, n, 3), m) — the atomic-free backward (PointnetFPModule.compute_geometry)."""
+    return _FPRows.apply(known_pm, unknown_pm, idx, weight, inv)

@@ -473,6 +473,10 @@ int vlp3d_fp_rows(const float *known, const float *unknown, const int *idx, cons
                   int C2, float *X, void *stream);
 int vlp3d_fp_rows_grad(const float *dX, const int *idx, const float *weight, int B, int n, int m, int C1, int ld,
                        float *d_known, void *stream);
+/* the same adjoint without LDS atomics, through the inverse of the three_nn map: inv_start (B*m + 1), inv_refs (B*n*3) =
+ * vlp3d_sa_inverse(idx viewed as (B, n, 3), crow NULL, N = m) — references are flat (b*n + p)*3 + k into `weight` */
+int vlp3d_fp_rows_grad_csr(const float *dX, const float *weight, const int *inv_start, const int *inv_refs, int B, int m,
+                           int C1, int ld, float *d_known, void *stream);
 
 /* ---- fused glue between the matrix-core kernels (csrc/glue.hip) ---------------------------------------------
  * roi_split: out (R x ld) = [heading_reg NH | heading_cls NH | box 6 | objectness 2 | sem NC] of the merged ROI

@@ -759,7 +759,18 @@ def test_fp_module_rows_equals_fp64_formula(training):
     (out * g).sum().backward()
     got = [out.detach(), uf.grad, kf.grad] + [p.grad.clone() for p in fp.parameters()]
     # fp64 reference
-    idx, w = pm.PointnetFPModule.compute_geometry(unknown, known)
+    geo = pm.PointnetFPModule.compute_geometry(unknown, known)
+    idx, w = geo[:2]
+    assert len(geo) == 4, "the inverse three_nn map travels with the geometry (atomic-free adjoint)"
+    # the LDS-atomic adjoint (no inverse map) agrees with the CSR form the module just used
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    kf2 = kf0.clone().requires_grad_(True)
+    X2 = rm.fp_rows(kf2, uf0, idx, w, None)
+    gX = torch.randn_like(X2)
+    X2.backward(gX)
+    kf3 = kf0.clone().requires_grad_(True)
+    rm.fp_rows(kf3, uf0, idx, w, tuple(geo[2:4])).backward(gX)
+    _grads_close(kf3.grad, kf2.grad.double(), 1e-5)
     ufd, kfd = uf0.double().requires_grad_(True), kf0.double().requires_grad_(True)
     base = (torch.arange(B, device="cuda") * m)[:, None, None]
     nb = kfd.reshape(B * m, 256)[(idx.long() + base).reshape(-1, 3)]
