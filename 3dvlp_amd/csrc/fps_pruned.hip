@@ -209,6 +209,14 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // result is wav
   const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
   return ab > cd ? ab : cd;
 }
+// maximum over lanes 0..15 (one DPP row), valid in lane 0..15; the caller reads lane 0: one v_readlane instead of four + 3 s_max
+__device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
+  v = dpp_max_u32<0xB1>(v);
+  v = dpp_max_u32<0x4E>(v);
+  v = dpp_max_u32<0x141>(v);
+  v = dpp_max_u32<0x140>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+}
 __device__ __forceinline__ float readlane_f32(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     const float4 cxyz = s_xyz4[par][lane & 15];
     const unsigned bv = lane < 16 ? vp.x : 0u;
     const unsigned bpos = lane < 16 ? vp.y : 0u;
-    const unsigned bmax = wave_max_u32(bv);
+    const unsigned bmax = row0_max_u32(bv);  // the 16 candidates sit in lanes 0..15
     if (bmax != 0u) {
       const int wi = winner_lane(bv, bmax, (int)min(bpos, (unsigned)(N - 1)));
       x1 = readlane_f32(cxyz.x, wi); y1 = readlane_f32(cxyz.y, wi); z1 = readlane_f32(cxyz.z, wi);
