@@ -540,9 +540,13 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
   float *Wt = reinterpret_cast<float *>(sm);  // [K][N]
   float *xs = Wt + (size_t)K * N;             // [16][SMALLK_KP]
   const long long r0 = (long long)blockIdx.x * 16;
-  for (int e = threadIdx.x; e < N * K; e += 256) {
-    const int n = e / K, k = e - n * K;
-    Wt[k * N + n] = W[e];
+  for (int n = threadIdx.x; n < N; n += 256) {  // a thread transposes one weight row; ALL its loads first (a load / store pair
+    float wv[SMALLK_KP];                          // per element waited for memory K times: 13 of the kernel's 15 us)
+#pragma unroll
+    for (int k = 0; k < SMALLK_KP; ++k) wv[k] = W[n * K + min(k, K - 1)];
+#pragma unroll
+    for (int k = 0; k < SMALLK_KP; ++k)
+      if (k < K) Wt[k * N + n] = wv[k];
   }
   for (int e = threadIdx.x; e < 16 * SMALLK_KP; e += 256) {
     const int rr = e / SMALLK_KP, k = e - rr * SMALLK_KP;
@@ -572,10 +576,19 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void smallk_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, int ldx,
                                                          long long R, int K, int N, float *__restrict__ slabs) {
   __shared__ float xs[64 * SMALLK_KP];
+  extern __shared__ int sm[];
+  float *dys = reinterpret_cast<float *>(sm);  // [64][N]: the block's dY rows, staged with all loads in flight (the loop
+  //                                              below used to wait for one global load per row: 64 dependent round trips)
   const long long r0 = (long long)blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * SMALLK_KP; e += 256) {
     const int rr = e / SMALLK_KP, k = e - rr * SMALLK_KP;
     xs[e] = (k < K && r0 + rr < R) ? x[(r0 + rr) * ldx + k] : 0.f;
+  }
+  for (int e = threadIdx.x; e < 64 * (N / 4); e += 256) {
+    const int rr = e / (N / 4), c4 = e - rr * (N / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < R) v = *reinterpret_cast<const float4 *>(dy + (r0 + rr) * N + 4 * c4);
+    *reinterpret_cast<float4 *>(dys + rr * N + 4 * c4) = v;
   }
   __syncthreads();
   float *slab = slabs + (size_t)blockIdx.x * ((size_t)N * SMALLK_KP + N);
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(256) void smallk_bwd_kernel(const float *__restrict
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     for (int rr = 0; rr < 64; ++rr) {
-      const float d = r0 + rr < R ? dy[(r0 + rr) * N + n] : 0.f;
+      const float d = dys[rr * N + n];
       db += d;
       const float4 *xp = reinterpret_cast<const float4 *>(xs + rr * SMALLK_KP + 16 * kh);
 #pragma unroll
@@ -679,8 +692,9 @@ extern "C" int vlp3d_smallk_fwd(const float *x, int ldx, const float *W, const f
  * ldo = K_true, ncol_out = K_true, n_bias = N} */
 extern "C" int vlp3d_smallk_bwd(const float *dy, const float *x, int ldx, long long R, int K, int N, float *slabs, void *stream) {
   if (!dy || !x || !slabs || R < 1 || K < 1 || K > SMALLK_KP || ldx < K || N < 4 || (N & 3)) return VLP3D_EINVAL;
-  hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, x, ldx, R, K, N,
-                     slabs);
+  if ((size_t)64 * N * sizeof(float) > 64 * 1024) return VLP3D_EINVAL;  // N <= 256
+  hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)64 * N * sizeof(float), (hipStream_t)stream,
+                     dy, x, ldx, R, K, N, slabs);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
