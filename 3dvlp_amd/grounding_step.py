@@ -10,6 +10,7 @@ in the data_dict.
 `grounding_loss` is the reference's loss for this path (lib/loss_helper/loss_joint.py:26-227 with detection +
 reference + DIoU + OCC/OSC as run.sh:1 configures it): 3dvlp_amd/losses.py, fused in csrc/joint_loss.hip.
 """
+import gc
 import importlib
 import os
 from types import SimpleNamespace
@@ -317,6 +318,20 @@ class GroundingStep:
         return list(self.model.buffers()) + [add_norm.state(self.device)]
 
     def _capture(self, batch, next_batch):
+        # The cyclic garbage collector stays OFF while the graphs are captured: a collection that runs on the capturing
+        # (or the autograd) thread in the middle of a capture can finalise an unrelated object that owns HIP resources — a
+        # CUDAGraph of an earlier step object kept alive by a reference cycle did, and its destructor's calls are illegal
+        # under capture: the process aborted (round 3, seen once in three full test runs).  Everything collectable goes first.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_graphs(batch, next_batch)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_graphs(self, batch, next_batch):
         # static inputs of the captured graphs.  With the loader's split of the cloud (k/xyz, k/feat_pm) the step never reads
         # `point_clouds` itself: it is left out (173 MB less to refill per step when batches change); of the NEXT batch
         # only the coordinates are needed (its geometry).

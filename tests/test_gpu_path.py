@@ -440,6 +440,8 @@ def test_split_backward_gradients_do_not_depend_on_side_stream_timing():
             step._gD.replay = late_replay
         step.run(batches[1], batches[1])
         torch.cuda.synchronize()
+        if delayed:
+            del step._gD.replay  # (the instance attribute made a reference cycle through the graph object)
         flats.append(step.bucket.flat.clone())
         assert torch.isfinite(flats[-1]).all()
         assert _rel(flats[-1], first) > 1e-2, "the two batches must give different gradients for this test to see anything"
