@@ -58,6 +58,26 @@ def test_fps_ties_and_skip_rule(pu, N):
     assert (got == orc.furthest_point_sampling(xyz, m)).all()
 
 
+@pytest.mark.parametrize("N", [1, 2, 63, 100, 255, 256, 257, 511, 512, 513, 600, 1023, 1024, 1025, 2047, 2048, 2049])
+def test_fps_small_sets_ties_and_skip_rule(pu, N):
+    """The four-wave kernel for N <= 2048 (csrc/fps.hip fps_small_kernel: 256 threads = half the reference's block at
+    512 <= N <= 2048, lanes walk their even slots first; a whole block below) on massive exact ties, every point sampled
+    (m = N), a skipped start point and a point exactly at the skip threshold — around every size where the slot count or the
+    reference's block size changes."""
+    rng = np.random.default_rng(1000 + N)
+    xyz = rng.integers(1, 4, size=(3, N, 3)).astype(np.float32)  # 27 distinct positions: ties at every step
+    if N > 5:
+        xyz[:, 5] = 0.01
+    xyz[1, 0] = 0.0
+    xyz[2, -1] = np.float32(np.sqrt(1e-3 / 3))
+    for m in sorted({1, min(N, 7), max(1, N // 2), N}):
+        got = pu.furthest_point_sample(dev(xyz), m).cpu().numpy()
+        assert (got == orc.furthest_point_sampling(xyz, m)).all(), (N, m)
+    smooth = rng.normal(0, 1, size=(2, N, 3)).astype(np.float32) + 3
+    got = pu.furthest_point_sample(dev(smooth), N).cpu().numpy()
+    assert (got == orc.furthest_point_sampling(smooth, N)).all()
+
+
 @pytest.mark.parametrize("B,N,m", [(2, 9000, 300), (2, 20000, 512), (1, 40000, 700), (1, 65536, 64), (3, 5000, 5000),
                                    (2, 80000, 300), (1, 131072, 96), (1, 65537, 128)])
 def test_fps_pruned_equals_dense_and_oracle(ext, B, N, m):
@@ -241,6 +261,22 @@ def test_three_nn(pu, ext, B, n, m):
     assert (d2.cpu().numpy() == rd2).all()  # same fp32 expression -> bit-identical distances
     dist, _ = pu.three_nn(dev(unknown), dev(known))
     np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(rd2), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,m", [(257, 1), (300, 2), (64, 3), (1000, 4), (513, 5), (2048, 7), (700, 1024), (1024, 1025), (100, 2050)])
+def test_three_nn_exact_ties_and_tiny_known_sets(ext, n, m):
+    """Coordinates on a 3 x 3 x 3 lattice: nearly every distance is tied many times over, so the result is decided by the
+    reference's strict '<' chain in index order (lowest index wins) — the order the four-lanes-per-point kernel has to
+    reproduce when it merges its lanes' triples (csrc/interpolate.hip); known sets of 1 and 2 points leave +inf / index 0 in
+    the unfilled slots; known counts around the 1024-point LDS tile."""
+    rng = np.random.default_rng(7 * n + m)
+    unknown = rng.integers(0, 3, size=(3, n, 3)).astype(np.float32)
+    known = rng.integers(0, 3, size=(3, m, 3)).astype(np.float32)
+    d2, idx = ext.three_nn(dev(unknown), dev(known))
+    rd2, ridx = orc.three_nn(unknown, known)
+    assert (idx.cpu().numpy() == ridx).all()
+    got = d2.cpu().numpy()
+    assert ((got == rd2) | (np.isinf(got) & np.isinf(rd2))).all()
 
 
 def test_gather_and_group_forward_backward(pu):
