@@ -345,50 +345,6 @@ __global__ __launch_bounds__(256) void rows_act_bwd_kernel(const float *__restri
   }
 }
 
-// generic form (any C): thread = column, four rows in flight
-__global__ __launch_bounds__(256) void rows_act_bwd_cols_kernel(const float *__restrict__ dOut, const float *__restrict__ Y,
-                                                           long long R, int C, const float *__restrict__ vec,
-                                                           const float *__restrict__ slope, long long rows_per_block,
-                                                           float *__restrict__ G, double *__restrict__ slabs,
-                                                           double *__restrict__ dslope) {
-  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float sc = vec[c], sh = vec[C + c], rs = vec[2 * C + c], nm = vec[3 * C + c];
-    const float al = slope ? slope[c] : 0.f;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    long long r = r0;
-    for (; r + 4 <= r1; r += 4) {  // four rows in flight
-      float y[4], d[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        y[u] = Y[(r + u) * C + c];
-        d[u] = dOut[(r + u) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float v = y[u] * sc + sh;
-        const float g = v > 0.f ? d[u] : al * d[u];
-        G[(r + u) * C + c] = g;
-        s1 += g;
-        s2 += g * (y[u] * rs + nm);
-        s3 += v > 0.f ? 0.f : d[u] * v;
-      }
-    }
-    for (; r < r1; ++r) {
-      const float y = Y[r * C + c], d = dOut[r * C + c];
-      const float v = y * sc + sh;
-      const float g = v > 0.f ? d : al * d;
-      G[r * C + c] = g;
-      s1 += g;
-      s2 += g * (y * rs + nm);
-      s3 += v > 0.f ? 0.f : d * v;
-    }
-    slabs[((size_t)blockIdx.x * 2) * C + c] = s1;
-    slabs[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
-    if (dslope) dslope[(size_t)blockIdx.x * C + c] = s3;
-  }
-}
-
 // ---- feature propagation glue on point-major rows (pointnet2_modules.py:393-411) -------------------------------------
 // X[b,n,:] = [ sum_k w[b,n,k] * known[b, idx[b,n,k], :]  |  unknown[b,n,:] ]   (three_interpolate + torch.cat)
 __global__ __launch_bounds__(256) void fp_rows_kernel(const float *__restrict__ known, const float *__restrict__ unknown,
@@ -584,15 +540,14 @@ extern "C" int vlp3d_rows_act_slabs(long long R) {
 }
 extern "C" int vlp3d_rows_act_bwd(const float *dOut, const float *Y, long long R, int C, const float *vec, const float *slope,
                                   float *G, double *tstats, double *dslope_slabs, void *stream) {
-  if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 1 || (slope && !dslope_slabs)) return VLP3D_EINVAL;
+  // C / 4 must divide 256 (a thread keeps its four columns): 64, 128, 256, 512, 1024 — the widths the BatchNorm loaders of the
+  // rows products accept as well (row_mlp.supported)
+  if (!dOut || !Y || !vec || !G || !tstats || R < 1 || C < 4 || (C & 3) || C > 1024 || (256 % (C / 4)) || (slope && !dslope_slabs))
+    return VLP3D_EINVAL;
   const int nslab = vlp3d_rows_act_slabs(R);
   const long long rpb = (R + nslab - 1) / nslab;
-  if (C >= 4 && (C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0)
-    hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G, tstats,
-                       slope ? dslope_slabs : nullptr);
-  else
-    hipLaunchKernelGGL(rows_act_bwd_cols_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G,
-                       tstats, slope ? dslope_slabs : nullptr);
+  hipLaunchKernelGGL(rows_act_bwd_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dOut, Y, R, C, vec, slope, rpb, G, tstats,
+                     slope ? dslope_slabs : nullptr);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

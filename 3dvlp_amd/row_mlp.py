@@ -75,7 +75,8 @@ def _round_up(x, m):
 
 
 def supported(x, layers):
-    """fp32 CUDA rows, R % 32 == 0, every BatchNorm layer 64-aligned, input widths the weight-gradient kernel slices."""
+    """fp32 CUDA rows, R % 32 == 0, every BatchNorm layer 64 / 128 / 256 / 512 / 1024 wide, input widths the weight-gradient
+    kernel slices."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] % 32 == 0 and x.shape[0] >= 32):
         return False
     k = x.shape[1]
@@ -86,7 +87,7 @@ def supported(x, layers):
         if bn is None:
             if i != len(layers) - 1:
                 return False
-        elif n % 64 or not bn.affine:
+        elif n not in (64, 128, 256, 512, 1024) or not bn.affine:  # n / 4 divides 256: the BatchNorm loaders' staging
             return False
         k = n
     return not torch.is_autocast_enabled("cuda")

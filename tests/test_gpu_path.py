@@ -668,10 +668,22 @@ def _grads_close(a, b, tol=5e-3):
     assert (a - b).norm().item() <= tol * b.norm().item() + 1e-9, ((a - b).norm().item(), b.norm().item())
 
 
+def test_row_stack_declines_widths_its_kernels_do_not_stage():
+    """A BatchNorm layer 192 wide passed `supported` (n % 64 == 0) although the BatchNorm loaders of the rows products stage
+    four columns per thread and need n / 4 to divide 256 — the stack then failed loudly inside backward (round 3)."""
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    x = torch.randn(2048, 128, device="cuda")
+    for n, ok in ((64, True), (128, True), (192, False), (256, True), (320, False), (512, True)):
+        w, b, bn = torch.randn(n, 128, device="cuda"), torch.randn(n, device="cuda"), torch.nn.BatchNorm1d(n).cuda()
+        assert rm.supported(x, [(w, b, bn)]) == ok, n
+
+
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("R,dims,last_plain", [(4096, [512, 256, 256], False), (8192, [256, 256, 256, 259], True),
                                                (2048, [128, 128, 128, 28], True), (4096, [256, 128, 256], False),
-                                               (64, [64, 64], False)])
+                                               (64, [64, 64], False),
+                                               # 96 rows x 128: three partial workgroups of rows_act_bwd's row-lane form
+                                               (96, [64, 128], False)])
 def test_row_stack_exact_vs_fp64(R, dims, last_plain, training):
     """row_mlp.row_stack (csrc/rows_mlp.hip + the weight-gradient kernel of csrc/sa_mlp.hip) against Linear(+bias) ->
     BatchNorm1d -> ReLU in fp64 on random data: output, input gradient and every parameter gradient to 1e-5 of their
