@@ -692,9 +692,19 @@ extern "C" int vlp3d_smallk_fwd(const float *x, int ldx, const float *W, const f
  * ldo = K_true, ncol_out = K_true, n_bias = N} */
 extern "C" int vlp3d_smallk_bwd(const float *dy, const float *x, int ldx, long long R, int K, int N, float *slabs, void *stream) {
   if (!dy || !x || !slabs || R < 1 || K < 1 || K > SMALLK_KP || ldx < K || N < 4 || (N & 3)) return VLP3D_EINVAL;
-  if ((size_t)64 * N * sizeof(float) > 64 * 1024) return VLP3D_EINVAL;  // N <= 256
-  hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)64 * N * sizeof(float), (hipStream_t)stream,
-                     dy, x, ldx, R, K, N, slabs);
+  const size_t lds = (size_t)64 * N * sizeof(float);  // + 8 KB static: above 64 KB per workgroup at N = 256
+  if (lds > 96 * 1024) return VLP3D_EINVAL;
+  if (lds + 64 * SMALLK_KP * sizeof(float) > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(smallk_bwd_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), lds, (hipStream_t)stream, dy, x, ldx, R, K, N,
+                     slabs);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -1261,18 +1261,19 @@ def test_act_dropout_equals_torch_with_same_mask(kind, p):
                                else torch.nn.functional.gelu(z.detach()), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,rows", [(64, 250), (128, 256), (256, 250)])
 @pytest.mark.parametrize("deferred", [False, True])
-def test_small_linears_equal_f_linear(deferred):
+def test_small_linears_equal_f_linear(deferred, N, rows):
     """Linear(27,128) added onto a base (relation_module.py:64,118) and Linear(128,1) (match_module.py:47) on the glue
     kernels vs F.linear in fp64: values, input / base gradients, weight and bias gradients (immediate and queued sums)."""
     glue = importlib.import_module("3dvlp_amd.glue")
     ext = importlib.import_module("3dvlp_amd._lib")
     torch.manual_seed(5)
     dev = "cuda"
-    x = torch.randn(8, 256, 27, device=dev)
-    W = (torch.randn(128, 27, device=dev) * 0.2).requires_grad_(True)
-    b = torch.randn(128, device=dev).requires_grad_(True)
-    base = torch.randn(8, 256, 128, device=dev).requires_grad_(True)
+    x = torch.randn(8, rows, 27, device=dev)   # (8 x 250 rows: the last 64-row block of the backward kernel is partial)
+    W = (torch.randn(N, 27, device=dev) * 0.2).requires_grad_(True)
+    b = torch.randn(N, device=dev).requires_grad_(True)
+    base = torch.randn(8, rows, N, device=dev).requires_grad_(True)
     xr = torch.randn(3000, 128, device=dev).requires_grad_(True)
     wr = (torch.randn(1, 128, device=dev) * 0.2).requires_grad_(True)
     br = torch.randn(1, device=dev).requires_grad_(True)
