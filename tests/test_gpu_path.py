@@ -668,6 +668,50 @@ def _grads_close(a, b, tol=5e-3):
     assert (a - b).norm().item() <= tol * b.norm().item() + 1e-9, ((a - b).norm().item(), b.norm().item())
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_row_stack_with_prepared_k_major_weights_equals_row_major(bf16):
+    """Inside `with row_mlp.PreparedWeights()` the forward product of a rows stack reads K-major weight copies made by ONE
+    batched transpose at the start of the pass (vlp3d_transpose_batch, vlp3d_rows_fwd_wt): the first pass registers the
+    weights (and runs the row-major kernel), the second is served the copies — same outputs and gradients; a weight changed
+    between the passes is transposed again; outside the context nothing is served."""
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    torch.manual_seed(3)
+    dims = [512, 256, 128, 64]
+    Ws = [(torch.randn(dims[i + 1], dims[i], device="cuda") * 0.1).requires_grad_(True) for i in range(3)]
+    bns = [torch.nn.BatchNorm1d(d).cuda().train() for d in dims[1:]]
+    x = torch.randn(4096, 512, device="cuda")
+    go = torch.randn(4096, 64, device="cuda")
+    prep = rm.PreparedWeights()
+
+    def run(ctx):
+        for w in Ws:
+            w.grad = None
+        with ml.bf16_mma(bf16):
+            if ctx:
+                with prep:
+                    y = rm.row_stack(x, [(w, None, bn) for w, bn in zip(Ws, bns)])
+            else:
+                y = rm.row_stack(x, [(w, None, bn) for w, bn in zip(Ws, bns)])
+        (y * go).sum().backward()
+        return [y.detach().clone()] + [w.grad.clone() for w in Ws]
+    plain = run(False)
+    first = run(True)                      # registers: row-major kernels
+    assert len(prep.entries) == 3 and len(prep.fresh) == 3
+    served = run(True)                     # K-major copies
+    assert len(prep.fresh) == 0
+    tol = 2e-3 if bf16 else 1e-6           # bf16: the two kernels round the same operands but sum in different orders
+    for a, b, c in zip(plain, first, served):
+        assert torch.equal(a, b)
+        assert _rel(c, a) <= tol, _rel(c, a)
+    with torch.no_grad():
+        Ws[1].add_(0.3 * torch.randn_like(Ws[1]))  # (a pure scaling would vanish in the train-mode BatchNorm behind it)
+    changed_plain = run(False)
+    changed = run(True)
+    assert _rel(changed[0], changed_plain[0]) <= tol and _rel(changed[0], plain[0]) > 1e-2
+    assert rm._ACTIVE is None
+
+
 def test_row_stack_declines_widths_its_kernels_do_not_stage():
     """A BatchNorm layer 192 wide passed `supported` (n % 64 == 0) although the BatchNorm loaders of the rows products stage
     four columns per thread and need n / 4 to divide 256 — the stack then failed loudly inside backward (round 3)."""
