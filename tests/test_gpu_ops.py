@@ -135,7 +135,11 @@ def test_fps_pruned_degenerate_sets_equal_dense_and_oracle(ext, kind, N, m):
 
 
 @pytest.mark.parametrize("B,N,n1,m", [(2, 6000, 2048, 1024), (3, 3000, 1024, 512), (2, 1500, 512, 256), (1, 900, 300, 300),
-                                      (2, 40000, 2048, 1)])
+                                      (2, 40000, 2048, 1),
+                                      # m = 2048: the largest sample count of the eight-lane proof kernels; 2049 / 2500: the
+                                      # one-lane kernels above it; 33 / 31: one workgroup of 32 points, partly filled
+                                      (1, 9000, 4096, 2048), (1, 9000, 4096, 2049), (2, 8000, 3000, 2500), (2, 700, 33, 33),
+                                      (2, 700, 64, 31)])
 def test_fps_prefix_hint_proves_arange_on_fps_ordered_input(ext, B, N, n1, m):
     """sa2..sa4 sample from the previous level's samples, stored in sampling order: the parallel proof must succeed
     (flag 0) and the result is 0..m-1 == the sequential kernel == the oracle."""
