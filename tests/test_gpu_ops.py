@@ -78,6 +78,35 @@ def test_fps_small_sets_ties_and_skip_rule(pu, N):
     assert (got == orc.furthest_point_sampling(smooth, N)).all()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fps_small_sets_fuzz_vs_oracle(ext, seed):
+    """Random N in 1..2600 (the four-wave kernel up to 2048, the dense kernel above), random m in 1..N, uniform / lattice
+    (exact ties) / duplicated / planar / skip-ball point sets: same indices as the C oracle, 40 cases per seed (400 more were
+    run once while the kernel was written: no mismatch)."""
+    rng = np.random.default_rng(seed)
+    for case in range(40):
+        B = int(rng.integers(1, 4))
+        N = int(rng.integers(1, 2600))
+        m = int(rng.integers(1, N + 1))
+        kind = rng.choice(["uniform", "lattice", "dups", "plane", "skip"])
+        if kind == "uniform":
+            p = rng.uniform(-3, 3, (B, N, 3))
+        elif kind == "lattice":
+            p = rng.integers(0, 4, (B, N, 3)).astype(np.float64) * 0.5 + 0.5
+        elif kind == "dups":
+            base = rng.uniform(-2, 2, (B, N // 8 + 1, 3))
+            p = base[:, rng.integers(0, N // 8 + 1, N)]
+        elif kind == "plane":
+            p = rng.uniform(-3, 3, (B, N, 3))
+            p[..., 2] = 1.0
+        else:
+            p = rng.uniform(-1, 1, (B, N, 3))
+            p[:, rng.integers(0, N, N // 10 + 1)] *= 0.01
+        xyz = p.astype(np.float32)
+        got = ext.furthest_point_sampling(dev(xyz), m, "dense").cpu().numpy()
+        assert (got == orc.furthest_point_sampling(xyz, m)).all(), (case, kind, B, N, m)
+
+
 @pytest.mark.parametrize("B,N,m", [(2, 9000, 300), (2, 20000, 512), (1, 40000, 700), (1, 65536, 64), (3, 5000, 5000),
                                    (2, 80000, 300), (1, 131072, 96), (1, 65537, 128)])
 def test_fps_pruned_equals_dense_and_oracle(ext, B, N, m):
