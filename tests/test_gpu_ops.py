@@ -312,6 +312,30 @@ def test_three_nn_exact_ties_and_tiny_known_sets(ext, n, m):
     assert ((got == rd2) | (np.isinf(got) & np.isinf(rd2))).all()
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_three_nn_fuzz_vs_oracle(ext, seed):
+    """Random unknown / known counts (1..2500), uniform clouds, lattices with exact ties and duplicated points: indices and
+    squared distances of the four-lanes-per-point kernel equal the C oracle's, 30 cases per seed."""
+    rng = np.random.default_rng(seed)
+    for case in range(30):
+        B = int(rng.integers(1, 4))
+        n, m = int(rng.integers(1, 2500)), int(rng.integers(1, 2500))
+        kind = rng.choice(["uniform", "lattice", "dups"])
+        if kind == "uniform":
+            u, k = rng.uniform(-2, 2, (B, n, 3)), rng.uniform(-2, 2, (B, m, 3))
+        elif kind == "lattice":
+            u, k = rng.integers(0, 4, (B, n, 3)) * 0.5, rng.integers(0, 4, (B, m, 3)) * 0.5
+        else:
+            base = rng.uniform(-2, 2, (B, 40, 3))
+            u, k = base[:, rng.integers(0, 40, n)], base[:, rng.integers(0, 40, m)]
+        u, k = u.astype(np.float32), k.astype(np.float32)
+        d2, idx = ext.three_nn(dev(u), dev(k))
+        rd2, ridx = orc.three_nn(u, k)
+        assert (idx.cpu().numpy() == ridx).all(), (case, kind, B, n, m)
+        got = d2.cpu().numpy()
+        assert ((got == rd2) | (np.isinf(got) & np.isinf(rd2))).all(), (case, kind, B, n, m)
+
+
 def test_gather_and_group_forward_backward(pu):
     rng = np.random.default_rng(11)
     B, C, N, M, S = 3, 37, 500, 60, 9
