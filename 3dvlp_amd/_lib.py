@@ -131,6 +131,7 @@ SIGNATURES = {
     "vlp3d_vocab_ce_partial_bytes": [ctypes.c_longlong, _i],
     "vlp3d_vocab_ce_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_vocab_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_rows_chain": [_vp, ctypes.c_longlong, _vp, _i, _vp, _vp],
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _i, _i, _i, _i, _vp],
@@ -625,6 +626,54 @@ def copy_batch(dsts, srcs):
         c.src, c.dst, c.bytes = s_.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
     with torch.cuda.device(dsts[0].device):
         _check(load().vlp3d_copy_batch(ctypes.cast(arr, ctypes.c_void_p), len(dsts), _stream()), "vlp3d_copy_batch")
+
+
+class ChainStage(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_chain_stage."""
+    _fields_ = [("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int),
+                ("v_out", ctypes.c_void_p), ("act_kind", ctypes.c_int), ("act_p", ctypes.c_float), ("act_call", ctypes.c_int),
+                ("h_out", ctypes.c_void_p), ("has_ln", ctypes.c_int), ("res", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p), ("ln_p", ctypes.c_float), ("ln_call", ctypes.c_int), ("eps", ctypes.c_float),
+                ("ln_out", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p)]
+
+
+def _prod(shape):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+def rows_chain(X, stages, seed):
+    """One launch of csrc/rows_chain.hip.  X (R, K0) fp32 contiguous CUDA; stages: list of dicts with the fields of
+    vlp3d_chain_stage (tensors or None for the pointers; missing keys = NULL / 0, act_kind defaults to -1)."""
+    if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2):
+        raise RuntimeError("rows_chain: X must be a contiguous fp32 CUDA matrix")
+    R = X.shape[0]
+    arr = (ChainStage * len(stages))()
+    ptrs = ("W", "bias", "v_out", "h_out", "res", "gamma", "beta", "ln_out", "xhat", "rstd")
+    width = {"bias": lambda st: (st["N"],), "v_out": lambda st: (R, st["N"]), "h_out": lambda st: (R, st["N"]),
+             "res": lambda st: (R, st["N"]), "gamma": lambda st: (st["N"],), "beta": lambda st: (st["N"],),
+             "ln_out": lambda st: (R, st["N"]), "xhat": lambda st: (R, st["N"]), "rstd": lambda st: (R,),
+             "W": lambda st: (st["N"], st["K"])}
+    for c, st in zip(arr, stages):
+        for name in ptrs:
+            t = st.get(name)
+            if t is not None:
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == X.device) or \
+                        t.numel() != _prod(width[name](st)):
+                    raise RuntimeError("rows_chain: %s must be contiguous fp32 on X's device with %s elements"
+                                       % (name, width[name](st)))
+            setattr(c, name, None if t is None else t.data_ptr())
+        c.N, c.K = int(st["N"]), int(st["K"])
+        c.act_kind, c.act_p, c.act_call = int(st.get("act_kind", -1)), float(st.get("act_p", 0.0)), int(st.get("act_call", 0))
+        c.has_ln, c.ln_p, c.ln_call = int(st.get("has_ln", 0)), float(st.get("ln_p", 0.0)), int(st.get("ln_call", 0))
+        c.eps = float(st.get("eps", 1e-5))
+    if stages[0]["K"] != X.shape[1]:
+        raise RuntimeError("rows_chain: X has %d columns, stage 0 reads %d" % (X.shape[1], stages[0]["K"]))
+    with torch.cuda.device(X.device):
+        _check(load().vlp3d_rows_chain(X.data_ptr(), R, ctypes.cast(arr, ctypes.c_void_p), len(stages),
+                                       None if seed is None else seed.data_ptr(), _stream()), "vlp3d_rows_chain")
 
 
 def wgrad_slabs(R, max_blocks):

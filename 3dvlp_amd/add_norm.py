@@ -32,6 +32,29 @@ def advance(device):
     state(device).add_(1)
 
 
+def next_call():
+    """A fresh call id for one dropout site (process-wide counter; baked into a captured graph)."""
+    _CALLS[0] = (_CALLS[0] + 1) & 0xFFFFF
+    return _CALLS[0]
+
+
+def norm_backward(d2, r2, xhat, rstd, kappa, gamma, R, D, p, seed, call_id, has_y):
+    """Backward of LayerNorm(x + dropout_p(y)) (vlp3d_sum_norm_bwd): d2 (R, D) = gradient of the normalised rows, r2 = gradient
+    arriving at the sum directly (or None).  Returns (dx, dy or None, dgamma, dbeta); [dgamma | dbeta] is summed now, or with
+    the other slabs of the backward pass when a deferred queue is open."""
+    dx = torch.empty_like(d2)
+    dy = torch.empty_like(d2) if has_y else None
+    nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
+    part = torch.empty((nblk, 2, D), dtype=torch.float32, device=d2.device)
+    dgb = torch.empty((2, D), dtype=torch.float32, device=d2.device)
+    q = _ext.slab_queue()
+    _ext.call("vlp3d_sum_norm_bwd", d2, r2, xhat, rstd, kappa, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
+              dgb, int(q is not None))
+    if q is not None:
+        q.add(part, nblk, dgb, 2 * D, 2 * D, 2 * D)
+    return dx, dy, dgb[0], dgb[1]
+
+
 def supported(x, y, norm):
     D = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape and D in _DIMS
@@ -57,17 +80,9 @@ class _AddNorm(Function):
     def backward(ctx, dout):
         xhat, rstd, gamma, seed = ctx.saved_tensors
         R, D, p, call_id, shape = ctx.cfg
-        d2 = dout.reshape(R, D).contiguous()
-        dx, dy = torch.empty_like(d2), torch.empty_like(d2)
-        nblk = int(_ext.load().vlp3d_add_norm_blocks(R))
-        part = torch.empty((nblk, 2, D), dtype=torch.float32, device=dout.device)
-        dgb = torch.empty((2, D), dtype=torch.float32, device=dout.device)
-        q = _ext.slab_queue()  # deferred: [dgamma | dbeta] is summed with the other slabs of the backward pass
-        _ext.call("vlp3d_sum_norm_bwd", d2, None, xhat, rstd, None, gamma.contiguous(), R, D, p, seed, call_id, dx, dy, part,
-                  dgb, int(q is not None))
-        if q is not None:
-            q.add(part, nblk, dgb, 2 * D, 2 * D, 2 * D)
-        return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None, None, None
+        dx, dy, dgam, dbet = norm_backward(dout.reshape(R, D).contiguous(), None, xhat, rstd, None, gamma, R, D, p, seed, call_id,
+                                           True)
+        return dx.view(shape), dy.view(shape), dgam, dbet, None, None, None, None, None
 
 
 def add_norm(x, y, norm, p=0.0, training=True, mask_out=None):

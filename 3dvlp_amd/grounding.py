@@ -11,9 +11,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as _ext
-from . import add_norm, glue
+from . import add_norm, glue, row_chain
 from .mfma_linear import linear as _linear
-from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention
+from .transformer import CrossAttentionDecoderLayer, MultiHeadAttention, decoder_stack_chained
 
 
 class MatchModule(nn.Module):
@@ -98,14 +98,27 @@ class MatchModule(nn.Module):
         # the proposals are tiled over the L sentences of their scene (:127); the first layer takes the UN-tiled features and
         # tiles after its (copy-independent) self-attention block — same values, see CrossAttentionDecoderLayer.forward_tiled
         layers = list(self.grounding_cross_attn)
-        feature1 = layers[0].forward_tiled(feature0.contiguous(), L, lang_fea, lang_fea)  # (B*L, K, hidden)
-        for layer in layers[1:]:
-            feature1 = layer(feature1, lang_fea, lang_fea)
+        mods, i = list(self.match), 0
+        # the row-local runs between the attention cores as one launch each (transformer.decoder_stack_chained), the first two
+        # Linear/GELU/Dropout pairs of the match MLP riding on the last one; None: a shape / mode the chain kernel does not cover
+        tail = []
+        while (len(mods) >= i + 3 and isinstance(mods[i], nn.Linear) and isinstance(mods[i + 1], nn.GELU)
+               and mods[i + 1].approximate == "none" and isinstance(mods[i + 2], nn.Dropout) and len(tail) < 2):
+            tail.append(row_chain.linear(mods[i].weight, mods[i].bias, "gelu", mods[i + 2].p))
+            i += 3
+        chained = decoder_stack_chained(layers, feature0.contiguous(), L, lang_fea, tail)
+        if chained is not None:
+            feature1, x = chained
+            if x is None:
+                x, i = feature1.reshape(B * L * K, -1), 0
+        else:
+            feature1 = layers[0].forward_tiled(feature0.contiguous(), L, lang_fea, lang_fea)  # (B*L, K, hidden)
+            for layer in layers[1:]:
+                feature1 = layer(feature1, lang_fea, lang_fea)
+            x, i = feature1.reshape(B * L * K, -1), 0
         data_dict["cross_box_feature"] = feature1
 
         feature1_agg = feature1.reshape(B * L * K, -1)
-        x = feature1_agg
-        mods, i = list(self.match), 0
         while i < len(mods):  # nn.Sequential of Linear / GELU / Dropout: Linears on the MFMA kernels, GELU+Dropout fused
             layer = mods[i]
             if isinstance(layer, nn.Linear) and glue.rowdot_supported(x, layer.weight) and not torch.is_autocast_enabled("cuda"):

@@ -45,6 +45,30 @@ def supported(x, weight):
     return (not blocked or N % 128 == 0) and (nb // 32) * kt <= 36 and 32 * (nb + kt * 32) * 4 <= 65536
 
 
+def weight_grad(dy2, x2, N, K, want_db, bf):
+    """(dW (N, K), db (N) or None) of y = x W^T + b from dy2 (R, N), x2 (R, K): launched now, or queued when a deferred
+    slab-reduce queue is open (one batched launch for all queued layers at the end of backward)."""
+    R = x2.shape[0]
+    # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
+    dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy2.device)
+    nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
+    q = _ext.slab_queue()
+    batched = q is not None and bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
+    if batched:  # the batch supplies the parallelism: fewer, longer row groups per layer = a quarter of the slab traffic
+        nblk = max(8, min(BATCH_WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))
+    part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy2.device)
+    if batched:
+        # not launched now: up to 48 of these run as ONE launch when the queue is flushed (end of backward)
+        q.add_linear_wgrad(dy2, x2, part, R, K, N, nblk, want_db, _ext.wgrad_slabs(R, nblk), dwb,
+                           dwb[N * K:] if want_db else None)
+    else:
+        _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None), int(bf))
+        if q is not None:
+            q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None,
+                  N if want_db else 0)
+    return dwb[:N * K].view(N, K), (dwb[N * K:] if want_db else None)
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bf16_mma, with_residual=False):
@@ -87,26 +111,7 @@ class _Linear(Function):
             dx = dres
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
-            dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy.device)
-            nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
-            q = _ext.slab_queue()
-            batched = q is not None and ctx.bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
-            if batched:  # the batch supplies the parallelism: fewer, longer row groups per layer = a quarter of the slab traffic
-                nblk = max(8, min(BATCH_WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))
-            part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy.device)
-            if batched:
-                # not launched now: up to 48 of these run as ONE launch when the queue is flushed (end of backward)
-                q.add_linear_wgrad(dy2, x2, part, R, K, N, nblk, want_db, _ext.wgrad_slabs(R, nblk), dwb,
-                                   dwb[N * K:] if want_db else None)
-            else:
-                _ext.call("vlp3d_linear_wgrad", dy2, x2, R, K, N, dwb, part, nblk, int(want_db), int(q is not None), ctx.bf)
-                if q is not None:
-                    q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None,
-                          N if want_db else 0)
-            dw = dwb[:N * K].view(N, K)
-            if want_db:
-                db = dwb[N * K:]
+            dw, db = weight_grad(dy2, x2, N, K, want_db, ctx.bf)
         elif want_db:
             db = dy2.sum(0)
         return dx, dw, db, None, None

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import add_norm, fused_attention
+from . import add_norm, fused_attention, row_chain
 from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 
@@ -191,3 +191,78 @@ class CrossAttentionDecoderLayer(nn.Module):
         out, _, q_res = mha.attention(query, query, query, need_att=False, with_residual=True)
         x = add_norm.add_norm_rep(q_res, out, mha.layer_norm, rep, mha.dropout.p, mha.training)
         return self._after_self_attention(x, key, value, src_trg_mask)
+
+
+def _attn_weights(att):
+    return (merge_adjacent([att.fc_q.weight, att.fc_k.weight, att.fc_v.weight]),
+            merge_adjacent([att.fc_q.bias, att.fc_k.bias, att.fc_v.bias]))
+
+
+def decoder_stack_chained(layers, query, rep, key, tail=()):
+    """The decoder stack of match_module.py:127-137 — `layers[0].forward_tiled(query, rep, key, key)` followed by
+    `layer(x, key, key)` for the other layers — with every row-local run between two attention cores as ONE launch
+    (row_chain.py): [fc_o -> add & norm -> next fc_q] after a self-attention core, [fc_o -> add & norm -> FFN -> add & norm ->
+    the next layer's fc_q|k|v, or the `tail` stages after the last layer] after a cross-attention core.
+    tail: row_chain stages applied to the stack's output rows (match_module.py:40-47's Linear/GELU/Dropout pairs).
+    Returns (x (B*rep, K, C), tail output (B*rep*K, N) or None), or None when a shape / mode is outside what the chain kernel
+    covers (the caller then runs the layer modules)."""
+    l0 = layers[0]
+    mha = l0.self_attention
+    B, K, C = query.shape
+    R = B * rep * K
+    if (not query.is_cuda or query.dtype != torch.float32 or C != 128 or not l0.fused_norm or not mha.fused_norm
+            or mha.identity_map_reordering or not mfma_supported(query, layers, R)):
+        return None
+    probe = query.new_empty((R, C))
+    plan = []
+    for i, layer in enumerate(layers):
+        ca, ffn = layer.enc_dec_attention, layer.ffn
+        p = layer.dropout.p
+        st = [row_chain.linear_add_norm(ca.attention.fc_o.weight, ca.attention.fc_o.bias, ca.layer_norm, probe, ca.dropout.p),
+              row_chain.linear(ffn.linear1.weight, ffn.linear1.bias, "relu", ffn.dropout.p),
+              row_chain.linear_add_norm(ffn.linear2.weight, ffn.linear2.bias, layer.norm, ("tile", 1), p)]
+        if i + 1 < len(layers):
+            w, b = _attn_weights(layers[i + 1].self_attention.attention)
+            st.append(row_chain.linear(w, b))
+        else:
+            st.extend(tail)
+        plan.append(st)
+        if not row_chain.supported(probe, st):
+            return None
+        if i > 0:
+            sa = layer.self_attention
+            head = [row_chain.linear_add_norm(sa.attention.fc_o.weight, sa.attention.fc_o.bias, sa.layer_norm, probe, sa.dropout.p),
+                    row_chain.linear(ca.attention.fc_q.weight, ca.attention.fc_q.bias)]
+            if not row_chain.supported(probe, head):
+                return None
+    h = mha.attention.h
+    bf = mha.attention.bf16_mma
+    # layer 0: the copy-independent self-attention block on the B sequences, replicated by its add & norm (forward_tiled)
+    out, _, q_res = mha.attention(query, query, query, need_att=False, with_residual=True)
+    x = add_norm.add_norm_rep(q_res, out, mha.layer_norm, rep, mha.dropout.p, mha.training).reshape(R, C)
+    ca = l0.enc_dec_attention.attention
+    q, x = _linear(x, ca.fc_q.weight, ca.fc_q.bias, with_residual=True)
+    tail_out = None
+    for i, layer in enumerate(layers):
+        ca = layer.enc_dec_attention.attention
+        kv = _linear(key, merge_adjacent([ca.fc_k.weight, ca.fc_v.weight]), merge_adjacent([ca.fc_k.bias, ca.fc_v.bias]))
+        a = fused_attention.sdpa_merged(q.view(B * rep, K, C), kv, h, None, "add", None, bf16_mma=bf)
+        st = plan[i]
+        st[0]["res"] = x
+        t = row_chain.run(a.reshape(R, C), st, layer.training)
+        x = t[2]
+        if i + 1 < len(layers):
+            nl = layers[i + 1]
+            a = fused_attention.sdpa_merged(t[3].view(B * rep, K, 3 * C), None, h, None, "add", None, bf16_mma=bf)
+            sa, nca = nl.self_attention, nl.enc_dec_attention.attention
+            x, q = row_chain.run(a.reshape(R, C), [
+                row_chain.linear_add_norm(sa.attention.fc_o.weight, sa.attention.fc_o.bias, sa.layer_norm, x, sa.dropout.p),
+                row_chain.linear(nca.fc_q.weight, nca.fc_q.bias)], nl.training)
+        elif tail:
+            tail_out = t[-1]
+    return x.view(B * rep, K, C), tail_out
+
+
+def mfma_supported(query, layers, R):
+    from . import mfma_linear
+    return mfma_linear.BF16_MMA and R % 64 == 0 and len(layers) >= 1 and not torch.is_autocast_enabled("cuda")

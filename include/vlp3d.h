@@ -580,6 +580,41 @@ typedef struct vlp3d_transpose_desc {
 } vlp3d_transpose_desc;
 int vlp3d_transpose_batch(const vlp3d_transpose_desc *descs, int count, void *stream);
 
+/* A chain of nn.Linear stages over 64-row tiles that stay in LDS between the stages (csrc/rows_chain.hip) — the row-local
+ * part of the reference's decoder layer between two attention cores, one launch instead of one per module:
+ *   attention.py:75 fc_o -> :128-130 LayerNorm(q + dropout(out))                      [-> the next block's fc_q / fc_q|k|v]
+ *   mmattention.py:36-50 FFN linear1 -> ReLU -> dropout -> linear2 -> :84-86 LayerNorm(dropout(f) + x)
+ *   match_module.py:40-47 Linear -> GELU -> Dropout (x2)
+ * Stage s maps the current tile t_s (R x K) to t_{s+1}:
+ *   v = t_s W^T + bias                                   W (N x K) fp32 row-major; N, K multiples of 128, K <= 256, N <= 384
+ *   v_out != NULL: v is stored (R x N)
+ *   act_kind >= 0: v = dropout_{act_p}(act(v)), act 0 = ReLU, 1 = GELU (erf); mask = the add & norm hash of (seed, act_call,
+ *                  row * N + column) — the mask vlp3d_act_dropout draws for the same call id; h_out != NULL: stored
+ *   has_ln: N = 128; v = LayerNorm_{gamma,beta,eps}(res + dropout_{ln_p}(v)) with res (R x 128) and the mask of
+ *           vlp3d_add_norm_fwd for call id ln_call; ln_out, xhat (R x 128) and rstd (R) are stored (all required)
+ *   t_{s+1} = v (bf16 in LDS: the next stage's MFMA operand; the last stage may have N = 384, the others N <= 256).
+ * X (R x K0) fp32 contiguous, K0 = stage 0's K.  bf16 MFMA operands, fp32 accumulation: the timing configuration — results
+ * equal the unfused bf16 entry points (vlp3d_linear_fwd bf16_mma=1, vlp3d_add_norm_fwd, vlp3d_act_dropout) up to the
+ * summation order of the LayerNorm statistics.  Backward uses the unfused entries on the stored tensors. */
+#define VLP3D_CHAIN_MAX_STAGES 6
+typedef struct vlp3d_chain_stage {
+  const float *W, *bias;
+  int N, K;
+  float *v_out;
+  int act_kind;
+  float act_p;
+  int act_call;
+  float *h_out;
+  int has_ln;
+  const float *res, *gamma, *beta;
+  float ln_p;
+  int ln_call;
+  float eps;
+  float *ln_out, *xhat, *rstd;
+} vlp3d_chain_stage;
+int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
+                     const unsigned long long *seed, void *stream);
+
 /* Caption head (csrc/caption.hip).  Replaces, for `TransformerDecoderModel(30522)` of models/jointnet/jointnet.py:104:
  *
  * cap_attn — `attention()` + the head split/merge of `MultiHeadedAttention.forward`

@@ -1479,3 +1479,173 @@ def test_step_runs_at_other_baseline_shapes(name, B, N):
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)), (name, losses)
     assert min(losses[3:]) < losses[0], (name, losses)
+
+
+def _chain_parts(R, seed=0):
+    torch.manual_seed(seed)
+    lin = lambda n, k: torch.nn.Linear(k, n).cuda()
+    mods = {"fo": lin(128, 128), "l1": lin(256, 128), "l2": lin(128, 256), "nx": lin(384, 128), "m1": lin(128, 128),
+            "n1": torch.nn.LayerNorm(128).cuda(), "n2": torch.nn.LayerNorm(128).cuda()}
+    for n in ("n1", "n2"):
+        mods[n].weight.data.uniform_(0.5, 1.5)
+        mods[n].bias.data.uniform_(-0.5, 0.5)
+    return mods, torch.randn(R, 128, device="cuda"), torch.randn(R, 128, device="cuda")
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_row_chain_equals_unfused_modules(p):
+    """[fc_o -> add & norm -> FFN linear1 -> ReLU -> dropout -> linear2 -> add & norm -> q|k|v projection -> Linear/GELU/Dropout]
+    as ONE launch (csrc/rows_chain.hip) against the same modules as separate launches with the same dropout call ids (= the
+    same masks): the first add & norm equals to fp32 round-off (only the order of the row statistics differs); after it a
+    1e-7 difference can flip a bf16 operand rounding, so later tensors agree on all but a sprinkle of elements.  Backward of
+    the chain = the unfused entry points on the stored tensors: every gradient agrees to bf16-flip noise."""
+    an = importlib.import_module("3dvlp_amd.add_norm")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    rc = importlib.import_module("3dvlp_amd.row_chain")
+    R = 64 * 37
+    m, a0, x0 = _chain_parts(R)
+    g3, gq, gm = torch.randn(R, 128, device="cuda"), torch.randn(R, 384, device="cuda"), torch.randn(R, 128, device="cuda")
+    params = [q for mod in m.values() for q in mod.parameters()]
+
+    def unfused(a, x):
+        y = ml.linear(a, m["fo"].weight, m["fo"].bias)
+        x1 = an.add_norm(x, y, m["n1"], p, True)
+        h = an.act_dropout(ml.linear(x1, m["l1"].weight, m["l1"].bias), "relu", p, True)
+        x3 = an.add_norm(x1, ml.linear(h, m["l2"].weight, m["l2"].bias), m["n2"], p, True)
+        qkv = ml.linear(x3, m["nx"].weight, m["nx"].bias)
+        return x1, x3, qkv
+
+    def chained(a, x):
+        st = [rc.linear_add_norm(m["fo"].weight, m["fo"].bias, m["n1"], x, p), rc.linear(m["l1"].weight, m["l1"].bias, "relu", p),
+              rc.linear_add_norm(m["l2"].weight, m["l2"].bias, m["n2"], ("tile", 1), p), rc.linear(m["nx"].weight, m["nx"].bias)]
+        assert rc.supported(a, st)
+        t = rc.run(a, st)
+        return t[0], t[2], t[3]
+
+    res = []
+    for fn in (unfused, chained):
+        an._CALLS[0] = 500
+        a, x = a0.clone().requires_grad_(), x0.clone().requires_grad_()
+        for q in params:
+            q.grad = None
+        with ml.bf16_mma(True):
+            x1, x3, qkv = fn(a, x)
+            gl = an.act_dropout(ml.linear(x3, m["m1"].weight, m["m1"].bias), "gelu", 0.5 if p else 0.0, True)
+            ((x3 * g3).sum() + (qkv * gq).sum() + (gl * gm).sum()).backward()
+        res.append(([x1.detach(), x3.detach(), qkv.detach()], [a.grad, x.grad] + [q.grad for q in params if q.grad is not None]))
+    (fu, gu), (fc, gc) = res
+    assert float((fu[0] - fc[0]).abs().max()) < 1e-5
+    for u, c in zip(fu[1:], fc[1:]):
+        d = (u - c).abs()
+        assert float(d.max()) < 5e-2 and float((d > 1e-4).float().mean()) < 2e-3 and float(d.mean()) < 1e-5
+    assert len(gu) == len(gc)
+    for u, c in zip(gu, gc):
+        assert float((u - c).norm()) < 1e-3 * float(u.norm()) + 1e-6, (u.shape, _rel(c, u))
+
+
+@pytest.mark.parametrize("R", [100, 32, 1])
+def test_row_chain_kernel_ragged_rows_gelu_and_wide_input(R):
+    """The kernel itself on row counts that fill no tile, starting from a 256-column input, with a GELU stage and no dropout:
+    against fp64 products of the bf16-rounded operands (what the MFMA computes), each stage checked from the stored tensors
+    of the stage before it."""
+    ext = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(R)
+    X = torch.randn(R, 256, device="cuda")
+    W1, b1 = torch.randn(128, 256, device="cuda") * 0.1, torch.randn(128, device="cuda")
+    W2, b2 = torch.randn(256, 128, device="cuda") * 0.1, torch.randn(256, device="cuda")
+    W3 = torch.randn(128, 256, device="cuda") * 0.1
+    gam, bet = torch.rand(128, device="cuda") + 0.5, torch.randn(128, device="cuda")
+    res = torch.randn(R, 128, device="cuda")
+    z1, h1 = torch.empty(R, 128, device="cuda"), torch.empty(R, 128, device="cuda")
+    v2 = torch.empty(R, 256, device="cuda")
+    out, xhat, rstd = torch.empty(R, 128, device="cuda"), torch.empty(R, 128, device="cuda"), torch.empty(R, device="cuda")
+    ext.rows_chain(X, [dict(W=W1, bias=b1, N=128, K=256, v_out=z1, act_kind=1, h_out=h1),
+                       dict(W=W2, bias=b2, N=256, K=128, v_out=v2),
+                       dict(W=W3, bias=None, N=128, K=256, has_ln=1, res=res, gamma=gam, beta=bet, eps=1e-5, ln_out=out,
+                            xhat=xhat, rstd=rstd)], None)
+    r16 = lambda t: t.bfloat16().double()
+    e1 = r16(X) @ r16(W1).t() + b1.double()
+    torch.testing.assert_close(z1.double(), e1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(h1.double(), torch.nn.functional.gelu(z1.double()), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(v2.double(), r16(h1) @ r16(W2).t() + b2.double(), rtol=1e-5, atol=1e-5)
+    s = res.double() + r16(v2) @ r16(W3).t()
+    mu, var = s.mean(1, keepdim=True), s.var(1, unbiased=False, keepdim=True)
+    eh = (s - mu) / torch.sqrt(var + 1e-5)
+    torch.testing.assert_close(xhat.double(), eh, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.double(), eh * gam.double() + bet.double(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd.double(), 1 / torch.sqrt(var + 1e-5).squeeze(1), rtol=1e-5, atol=0)
+
+
+def test_row_chain_rejects_shapes_it_does_not_stage():
+    ext = importlib.import_module("3dvlp_amd._lib")
+    X = torch.randn(64, 128, device="cuda")
+    y = torch.empty(64, 192, device="cuda")
+    with pytest.raises(ext.Vlp3dError):   # 192 columns: not a multiple of the 128-column weight block
+        ext.rows_chain(X, [dict(W=torch.randn(192, 128, device="cuda"), N=192, K=128, v_out=y)], None)
+    with pytest.raises(ext.Vlp3dError):   # stage 1 reads 256 columns, stage 0 produced 128
+        ext.rows_chain(X, [dict(W=torch.randn(128, 128, device="cuda"), N=128, K=128),
+                           dict(W=torch.randn(128, 256, device="cuda"), N=128, K=256)], None)
+    with pytest.raises(ext.Vlp3dError):   # dropout without a seed word
+        ext.rows_chain(X, [dict(W=torch.randn(128, 128, device="cuda"), N=128, K=128, act_kind=0, act_p=0.1,
+                                h_out=torch.empty(64, 128, device="cuda"))], None)
+    with pytest.raises(ext.Vlp3dError):   # 512 columns only as the last stage's 384
+        ext.rows_chain(X, [dict(W=torch.randn(512, 128, device="cuda"), N=512, K=128)], None)
+
+
+def test_match_module_chained_decoder_equals_layer_modules():
+    """MatchModule.forward with the decoder stack on the row chains (transformer.decoder_stack_chained) against the same module
+    with the chains off (the layer modules' own launches), all dropout rates 0 so that neither draws masks.  Both are bf16-MFMA
+    evaluations whose 1e-7 differences flip operand roundings and ReLU gates, so the yardstick is what bf16 itself costs: every
+    gradient of the chained form is within half the distance between the module form and the exact-fp32 MFMA form (measured:
+    a tenth for most, a quarter for the first layer's query / key projections, which sit behind both layers' noise)."""
+    gr = importlib.import_module("3dvlp_amd.grounding")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    rc = importlib.import_module("3dvlp_amd.row_chain")
+    torch.manual_seed(5)
+    B, L, K, C, T = 2, 4, 256, 128, 20
+    mm = gr.MatchModule(num_proposals=K, hidden_size=C).cuda().train()
+    for mod in mm.modules():
+        if hasattr(mod, "fused_norm"):
+            mod.fused_norm = True
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    feats = torch.randn(B, K, C, device="cuda")
+    lang = torch.randn(B * L, T + 1, C, device="cuda")
+    gconf, gfeat = torch.randn(B * L, K, device="cuda"), torch.randn(B * L, K, C, device="cuda")
+
+    def run(bf, chain):
+        rc.ENABLED = chain
+        try:
+            for mod in mm.modules():
+                if hasattr(mod, "bf16_mma"):
+                    mod.bf16_mma = bf
+            mm.zero_grad()
+            x = feats.clone().requires_grad_()
+            dd = {"bbox_feature": x, "input_ids": torch.zeros(B, L, T + 1), "istrain": [0], "lang_fea": lang}
+            launches = []
+            orig = ext_mod.rows_chain
+            ext_mod.rows_chain = lambda *a, **k: (launches.append(1), orig(*a, **k))[1]
+            try:
+                with ml.bf16_mma(bf):
+                    dd = mm(dd)
+                    ((dd["cluster_ref"] * gconf).sum() + (dd["cross_box_feature"] * gfeat).sum()).backward()
+            finally:
+                ext_mod.rows_chain = orig
+            out = {"cluster_ref": dd["cluster_ref"].detach().double(), "cross_box_feature": dd["cross_box_feature"].detach().double(),
+                   "d bbox_feature": x.grad.double()}
+            out.update({n: p_.grad.double() for n, p_ in mm.named_parameters() if p_.grad is not None})
+            return out, len(launches)
+        finally:
+            rc.ENABLED = True
+
+    ext_mod = importlib.import_module("3dvlp_amd._lib")
+    (exact, n0), (mods, n1), (chain, n2) = run(False, False), run(True, False), run(True, True)
+    assert (n0, n1, n2) == (0, 0, 3)   # [layer 0 tail + layer 1 q|k|v], [layer 1 fc_o + fc_q], [layer 1 tail + match MLP]
+    assert exact.keys() == mods.keys() == chain.keys()
+    scale = max(float(v.norm()) for n, v in exact.items() if "." in n)
+    for n in exact:
+        if n.endswith("fc_k.bias"):  # exactly zero in exact arithmetic (softmax is shift invariant): all sides are round-off
+            assert float(chain[n].norm()) < 1e-3 * scale
+            continue
+        bf_cost = float((mods[n] - exact[n]).norm())
+        assert float((chain[n] - mods[n]).norm()) < 0.5 * bf_cost + 1e-6 * scale, (n, _rel(chain[n], mods[n]), _rel(mods[n], exact[n]))
