@@ -132,6 +132,8 @@ SIGNATURES = {
     "vlp3d_vocab_ce_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_vocab_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_rows_chain": [_vp, ctypes.c_longlong, _vp, _i, _vp, _vp],
+    "vlp3d_rows_chain_bwd_blocks": [ctypes.c_longlong],
+    "vlp3d_rows_chain_bwd": [_vp, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp],
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _i, _i, _i, _i, _vp],
@@ -674,6 +676,57 @@ def rows_chain(X, stages, seed):
     with torch.cuda.device(X.device):
         _check(load().vlp3d_rows_chain(X.data_ptr(), R, ctypes.cast(arr, ctypes.c_void_p), len(stages),
                                        None if seed is None else seed.data_ptr(), _stream()), "vlp3d_rows_chain")
+
+
+class ChainBwdPoint(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_chain_bwd_point."""
+    _fields_ = [("base", ctypes.c_void_p), ("add_kept", ctypes.c_int), ("op", ctypes.c_int), ("aux", ctypes.c_void_p),
+                ("rstd", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("p", ctypes.c_float), ("call", ctypes.c_int),
+                ("act_kind", ctypes.c_int), ("g_out", ctypes.c_void_p), ("dres_out", ctypes.c_void_p), ("keep", ctypes.c_int),
+                ("part", ctypes.c_void_p)]
+
+
+class ChainBwdGemm(ctypes.Structure):
+    """include/vlp3d.h: vlp3d_chain_bwd_gemm."""
+    _fields_ = [("Wt", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+def rows_chain_bwd_blocks(R):
+    return int(load().vlp3d_rows_chain_bwd_blocks(int(R)))
+
+
+def rows_chain_bwd(G, points, gemms, seed):
+    """One launch of the chain backward (csrc/rows_chain.hip).  G (R, gemms[0].K) fp32 contiguous; points: len(gemms) + 1 dicts
+    with the fields of vlp3d_chain_bwd_point, gemms: dicts Wt (N, K) / N / K (include/vlp3d.h)."""
+    R = G.shape[0]
+    if not (G.is_cuda and G.dtype == torch.float32 and G.is_contiguous() and G.dim() == 2) or len(points) != len(gemms) + 1:
+        raise RuntimeError("rows_chain_bwd: G must be a contiguous fp32 CUDA matrix, one more point than products")
+    widths = [gemms[0]["K"]] + [g["N"] for g in gemms]
+    if G.shape[1] != widths[0]:
+        raise RuntimeError("rows_chain_bwd: G has %d columns, product 0 reduces over %d" % (G.shape[1], widths[0]))
+    pa = (ChainBwdPoint * len(points))()
+    ga = (ChainBwdGemm * len(gemms))()
+    nblk = rows_chain_bwd_blocks(R)
+    for c, P, N in zip(pa, points, widths):
+        sizes = {"base": R * N, "aux": R * N, "rstd": R, "gamma": N, "g_out": R * N, "dres_out": R * N, "part": nblk * 2 * N}
+        for name, n in sizes.items():
+            t = P.get(name)
+            if t is not None and (not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == G.device)
+                                  or t.numel() != n):
+                raise RuntimeError("rows_chain_bwd: %s must be contiguous fp32 on G's device with %d elements" % (name, n))
+            setattr(c, name, None if t is None else t.data_ptr())
+        c.add_kept, c.op, c.keep = int(P.get("add_kept", 0)), int(P.get("op", 0)), int(P.get("keep", 0))
+        c.p, c.call, c.act_kind = float(P.get("p", 0.0)), int(P.get("call", 0)), int(P.get("act_kind", 0))
+    for c, g in zip(ga, gemms):
+        t = g["Wt"]
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == G.device) or \
+                tuple(t.shape) != (g["N"], g["K"]):
+            raise RuntimeError("rows_chain_bwd: Wt must be a contiguous fp32 (N, K) matrix on G's device")
+        c.Wt, c.N, c.K = t.data_ptr(), int(g["N"]), int(g["K"])
+    with torch.cuda.device(G.device):
+        _check(load().vlp3d_rows_chain_bwd(G.data_ptr(), R, ctypes.cast(pa, ctypes.c_void_p), ctypes.cast(ga, ctypes.c_void_p),
+                                           len(gemms), None if seed is None else seed.data_ptr(), _stream()),
+               "vlp3d_rows_chain_bwd")
 
 
 def wgrad_slabs(R, max_blocks):

@@ -266,6 +266,217 @@ __global__ __launch_bounds__(256) void rows_chain_kernel(const ChainArgs a) {
   }
 }
 
+// ---- backward ---------------------------------------------------------------------------------------------------------
+// The same tile walk for the gradient: input-gradient products (weights transposed: the same staging and MFMA code) with a
+// row pass at every point between them — residual adds, add & norm backward, activation / dropout backward — and the
+// gradients the weight-gradient kernels read stored on the way.  The residual gradient of an add & norm waits in registers
+// (the row pass always maps a lane to the same rows and columns) until the product chain reaches the tensor it belongs to.
+constexpr int BT = 32;                                  // rows per workgroup
+constexpr int BRP = BT / 16;                            // row passes: 4 rows per wave each
+constexpr int BSX = BT * LDX * 2;
+constexpr int BRED = SW_BYTES + 2 * BSX;                // [4][2][128] floats: the waves' dgamma | dbeta sums
+constexpr int BWD_LDS = BRED + 4 * 2 * DLN * 4;
+
+struct ChainBwdArgs {
+  const float *G;
+  long long R;
+  const unsigned long long *seed;
+  int ngemm;
+  vlp3d_chain_bwd_gemm gm[VLP3D_CHAIN_MAX_STAGES];
+  vlp3d_chain_bwd_point pt[VLP3D_CHAIN_MAX_STAGES + 1];
+};
+
+__device__ __forceinline__ float act_grad(float z, int kind) {
+  if (kind == 0) return z > 0.f ? 1.f : 0.f;
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+__device__ __forceinline__ void unpack8(const float4 &a, const float4 &b, float (&v)[8]) {
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float *p, const float (&v)[8]) {
+  *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// One point of the chain on the workgroup's rows, columns [cb, cb + 128) of an N-wide gradient.  src: the fp32 tile (row
+// stride LDF) or NULL = read G.  dst: the bf16 tile the next product reads, or NULL.
+template <bool FROM_G>
+__device__ __forceinline__ void bwd_point(const vlp3d_chain_bwd_point &P, const unsigned long long *seed, const float *src,
+                                          const float *G, int N, int cb, long long row0, long long R, short *dst,
+                                          float (&kept)[BRP][8], float *red, int lane, int wave) {
+  const int g = lane >> 4, c0 = (lane & 15) * 8;
+  const float p = P.p;
+  const unsigned thresh = (unsigned)(p * 16777216.0f);
+  const unsigned mix = p > 0.f ? seed_mix_of(seed, P.call) : 0u;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float y[BRP][8], ax[BRP][8], rs[BRP];
+  float gam[8], dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dg[j] = db[j] = 0.f;
+  if (P.op == 1) unpack8(ld4(P.gamma + c0), ld4(P.gamma + c0 + 4), gam);
+#pragma unroll
+  for (int it = 0; it < BRP; ++it) {  // every global operand of both passes in flight first
+    const int row = wave * (4 * BRP) + it * 4 + g;
+    const long long gr = min(row0 + row, R - 1), o = gr * N + cb + c0;
+    if (!FROM_G) unpack8(*reinterpret_cast<const float4 *>(src + row * LDF + c0), *reinterpret_cast<const float4 *>(src + row * LDF + c0 + 4), y[it]);
+    else unpack8(ld4(G + o), ld4(G + o + 4), y[it]);
+    if (P.base) {
+      float b[8];
+      unpack8(ld4(P.base + o), ld4(P.base + o + 4), b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[it][j] += b[j];
+    }
+    if (P.op != 0) unpack8(ld4(P.aux + o), ld4(P.aux + o + 4), ax[it]);
+    if (P.op == 1) rs[it] = P.rstd[gr];
+  }
+#pragma unroll
+  for (int it = 0; it < BRP; ++it) {
+    const int row = wave * (4 * BRP) + it * 4 + g;
+    const long long grow = row0 + row, o = grow * N + cb + c0;
+    const bool live = grow < R;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = y[it][j] + (P.add_kept ? kept[it][j] : 0.f);
+    if (P.op == 1) {
+      float gg[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gg[j] = v[j] * gam[j];
+        if (live) {
+          dg[j] += v[j] * ax[it][j];
+          db[j] += v[j];
+        }
+        s1 += gg[j];
+        s2 += gg[j] * ax[it][j];
+      }
+      const float m1 = sum16(s1) * (1.0f / DLN), m2 = sum16(s2) * (1.0f / DLN);
+      float dx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dx[j] = rs[it] * (gg[j] - m1 - ax[it][j] * m2);
+        v[j] = p > 0.f ? (keep_element(mix, (unsigned)(o + j), thresh) ? dx[j] * inv_keep : 0.f) : dx[j];
+        if (P.keep) kept[it][j] = dx[j];
+      }
+      if (P.dres_out && live) store8(P.dres_out + o, dx);
+    } else if (P.op == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[j] * act_grad(ax[it][j], P.act_kind);
+        v[j] = p > 0.f ? (keep_element(mix, (unsigned)(o + j), thresh) ? d * inv_keep : 0.f) : d;
+      }
+    }
+    if (P.g_out && live) store8(P.g_out + o, v);
+    if (dst) {
+      bf16x8 ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ob[j] = bf16_bits(v[j]);
+      *reinterpret_cast<bf16x8 *>(dst + row * LDX + cb + c0) = ob;
+    }
+  }
+  if (P.op == 1 && P.part) {  // (wave-uniform) this workgroup's [sum dout * xhat | sum dout]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dg[j] += __shfl_xor(dg[j], 16);
+      dg[j] += __shfl_xor(dg[j], 32);
+      db[j] += __shfl_xor(db[j], 16);
+      db[j] += __shfl_xor(db[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * 2 + 0) * DLN + c0 + j] = dg[j];
+        red[(wave * 2 + 1) * DLN + c0 + j] = db[j];
+      }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;  // 256 threads = [2][128]
+    P.part[(long long)blockIdx.x * 2 * DLN + t] = (red[t] + red[2 * DLN + t]) + (red[4 * DLN + t] + red[6 * DLN + t]);
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_chain_bwd_kernel(const ChainBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  short *sW = reinterpret_cast<short *>(smem);
+  float *sF = reinterpret_cast<float *>(smem);
+  short *cur = reinterpret_cast<short *>(smem + SW_BYTES);
+  short *nxt = reinterpret_cast<short *>(smem + SW_BYTES + BSX);
+  float *red = reinterpret_cast<float *>(smem + BRED);
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long row0 = (long long)blockIdx.x * BT;
+  const long long R = a.R;
+  constexpr int NV = KC * (KC / 4) / 256;
+  float4 vw[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
+    vw[j] = ld4(a.gm[0].Wt + (long long)col * a.gm[0].K + 4 * c4);
+  }
+  float kept[BRP][8];
+#pragma unroll
+  for (int it = 0; it < BRP; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kept[it][j] = 0.f;
+  for (int cb = 0; cb < a.gm[0].K; cb += KC) bwd_point<true>(a.pt[0], a.seed, nullptr, a.G, a.gm[0].K, cb, row0, R, cur, kept, red, lane, wave);
+
+  int s = 0, cb = 0, k0 = 0;
+  f32x16 acc;
+  while (true) {
+    const vlp3d_chain_bwd_gemm &S = a.gm[s];
+    const int N = S.N, K = S.K;
+    if (k0 == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    }
+    __syncthreads();  // the previous chunk's fragment reads / the previous point's fp32 tile and `red` reads are done
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
+      *reinterpret_cast<bf16x4 *>(sW + col * LDW + 4 * c4) = pack4(vw[j]);
+    }
+    int ns = s, ncb = cb, nk0 = k0 + KC;
+    if (nk0 >= K) {
+      nk0 = 0;
+      ncb = cb + KC;
+      if (ncb >= N) {
+        ncb = 0;
+        ns = s + 1;
+      }
+    }
+    if (ns < a.ngemm) {
+      const float *wn = a.gm[ns].Wt + (long long)ncb * a.gm[ns].K + nk0;
+      const int ldn = a.gm[ns].K;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = threadIdx.x + 256 * j, col = e >> 5, c4 = e & 31;
+        vw[j] = ld4(wn + (long long)col * ldn + 4 * c4);
+      }
+    }
+    __syncthreads();
+    {
+      const short *pa = cur + r * LDX + k0 + 8 * half;
+      const short *pw = sW + (32 * wave + r) * LDW + 8 * half;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(pa + 16 * ks),
+                                                      *reinterpret_cast<const bf16x8 *>(pw + 16 * ks), acc, 0, 0, 0);
+    }
+    if (k0 + KC >= K) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sF[acc_row(i, half) * LDF + 32 * wave + r] = acc[i];
+      __syncthreads();
+      bwd_point<false>(a.pt[s + 1], a.seed, sF, nullptr, N, cb, row0, R, s + 1 < a.ngemm ? nxt : nullptr, kept, red, lane, wave);
+    }
+    if (ns >= a.ngemm) break;
+    if (ns != s) {  // ordered by the next chunk's first barrier
+      short *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    s = ns; cb = ncb; k0 = nk0;
+  }
+}
+
 }  // namespace
 
 extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
@@ -304,6 +515,49 @@ extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_s
     hipLaunchKernelGGL(rows_chain_kernel<64>, dim3((unsigned)((R + 63) / 64)), dim3(256), lds_bytes(64), (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(rows_chain_kernel<32>, dim3((unsigned)((R + 31) / 32)), dim3(256), lds_bytes(32), (hipStream_t)stream, a);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+extern "C" int vlp3d_rows_chain_bwd_blocks(long long R) { return (int)((R + BT - 1) / BT); }
+
+extern "C" int vlp3d_rows_chain_bwd(const float *G, long long R, const vlp3d_chain_bwd_point *points,
+                                    const vlp3d_chain_bwd_gemm *gemms, int ngemm, const unsigned long long *seed, void *stream) {
+  if (!G || !points || !gemms || R < 1 || ngemm < 1 || ngemm > VLP3D_CHAIN_MAX_STAGES) return VLP3D_EINVAL;
+  ChainBwdArgs a;
+  a.G = G;
+  a.R = R;
+  a.seed = seed;
+  a.ngemm = ngemm;
+  bool kept = false;
+  for (int j = 0; j <= ngemm; ++j) {
+    const vlp3d_chain_bwd_point &P = points[j];
+    const int N = j == 0 ? gemms[0].K : gemms[j - 1].N;
+    if (j < ngemm) {
+      const vlp3d_chain_bwd_gemm &S = gemms[j];
+      if (!S.Wt || S.N < KC || S.N % KC || S.N > MAXK || S.K < KC || S.K % KC || S.K > MAXK) return VLP3D_EINVAL;
+      if (j > 0 && S.K != gemms[j - 1].N) return VLP3D_EINVAL;
+      a.gm[j] = S;
+    } else if (!P.g_out) {
+      return VLP3D_EINVAL;
+    }
+    if (P.op < 0 || P.op > 2 || P.p < 0.f || P.p >= 1.f || (P.p > 0.f && !seed)) return VLP3D_EINVAL;
+    if (P.op == 1 && (N != DLN || !P.aux || !P.rstd || !P.gamma)) return VLP3D_EINVAL;
+    if (P.op == 2 && (!P.aux || P.act_kind < 0 || P.act_kind > 1)) return VLP3D_EINVAL;
+    if (P.op != 1 && (P.keep || P.dres_out || P.part)) return VLP3D_EINVAL;
+    if (P.add_kept && (!kept || N != DLN)) return VLP3D_EINVAL;  // nothing kept yet / kept rows are 128 wide
+    if (P.op == 1 && P.keep) kept = true;
+    if (R * (long long)N >= (1ll << 32)) return VLP3D_EINVAL;
+    a.pt[j] = P;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(rows_chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            BWD_LDS) != hipSuccess)
+      return VLP3D_EINVAL;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rows_chain_bwd_kernel, dim3((unsigned)((R + BT - 1) / BT)), dim3(256), BWD_LDS, (hipStream_t)stream, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

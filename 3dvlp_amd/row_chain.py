@@ -8,10 +8,12 @@ A chain is a list of stages over the rows of a matrix X; stage s maps the curren
                                                      the caller or an earlier t_j of the same chain
 
 i.e. attention.py:75 fc_o -> :128-130 add & norm -> the next projection; mmattention.py:36-50 FFN -> :84-86 add & norm;
-match_module.py:40-47 Linear/GELU/Dropout.  The forward pass of a chain is one kernel launch whose 64-row tiles stay in LDS
-between the stages; every t_{s+1} (and what backward needs: pre-activations, xhat, rstd) is stored on the way.  Backward walks
-the stages in reverse on the existing entry points (vlp3d_sum_norm_bwd, vlp3d_act_dropout, vlp3d_linear_dgrad with the
-residual gradient as `base`, the queued weight gradients) — the launches autograd would have made for the unfused modules.
+match_module.py:40-47 Linear/GELU/Dropout.  The forward pass of a chain is one kernel launch whose 32-row tiles stay in LDS
+between the stages; every t_{s+1} (and what backward needs: pre-activations, xhat, rstd) is stored on the way.  Backward is
+ONE launch too for the stages up to 256 columns wide (vlp3d_rows_chain_bwd: input-gradient products on the transposed weights,
+add & norm / activation / dropout backward and the residual adds at the points between them, the gradients the queued
+weight-gradient kernels read stored on the way); a wider top stage (the merged q|k|v projection) and passes without transposed
+weights at hand walk the stages on the unfused entry points (vlp3d_sum_norm_bwd, vlp3d_act_dropout, vlp3d_linear_dgrad).
 
 bf16 MFMA operands only (the timing configuration of the step driver): callers check `supported()` and use the unfused
 modules otherwise — that is a different sequence of the same HIP entry points, never a library or CPU path.
@@ -22,9 +24,10 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as _ext
-from . import add_norm, mfma_linear
+from . import add_norm, mfma_linear, row_mlp
 
 ENABLED = os.environ.get("VLP3D_ROW_CHAIN", "1") != "0"
+FUSED_BACKWARD = os.environ.get("VLP3D_ROW_CHAIN_BWD", "1") != "0"  # the chain's backward as one launch (+ the weight gradients)
 _ACTS = {"relu": 0, "gelu": 1}
 
 
@@ -92,6 +95,14 @@ class _Chain(Function):
             xhats.append(xh)
             rstds.append(rs)
         _ext.rows_chain(X, descs, seed)
+        # the transposed weights the one-launch backward multiplies with: the K-major copies of the step's PreparedWeights
+        # (refreshed once per forward pass; a weight seen for the first time is served from the next pass on — this pass then
+        # walks the unfused entry points), or a transposed copy made here when no PreparedWeights context is open
+        ctx.wt = None
+        if FUSED_BACKWARD:
+            prep = row_mlp._ACTIVE
+            ctx.wt = [(prep.lookup(tensors[st[0]]) if prep is not None else tensors[st[0]].detach().t().contiguous())
+                      if max(tensors[st[0]].shape) <= 256 else None for st in spec]
         ctx.spec = spec
         ctx.n_tensors = len(tensors)
         keep = [seed, X] + list(tensors) + tiles[1:] + [t for t in zs + xhats + rstds if t is not None]
@@ -120,10 +131,10 @@ class _Chain(Function):
         def accumulate(slot, g):
             return g if slot is None else slot + g
 
-        for s in reversed(range(n)):
+        def unfused_stage(s):
             g = pend[s + 1]
             if g is None:
-                continue
+                return
             (iW, ib, act_kind, act_p, act_call, has, res, ig, ibeta, ln_p, ln_call, eps) = spec[s]
             W = tensors[iW]
             N, K = W.shape
@@ -149,6 +160,79 @@ class _Chain(Function):
                 dx = torch.empty((R, K), dtype=torch.float32, device=g.device)
                 _ext.call("vlp3d_linear_dgrad", g, W, R, N, K, dx, pend[s], 1)  # base: the gradient already waiting for t_s
                 pend[s] = dx
+
+        def chainable(top):
+            """stages top..0 as ONE backward launch: transposed weights at hand, widths the tile kernel stages, residuals
+            that are tiles of the chain above t_0."""
+            if ctx.wt is None or pend[top + 1] is None or not ctx.needs_input_grad[2]:
+                return False
+            for s in range(top + 1):
+                st = spec[s]
+                N, K = tensors[st[0]].shape
+                if ctx.wt[s] is None or N > 256 or K > 256 or (st[5] and st[6][0] == "tile" and not 1 <= st[6][1] <= s):
+                    return False
+            return True
+
+        def fused_run(top):
+            G = pend[top + 1]
+            dev = G.device
+            points, gemms, gouts, lns = [], [], {}, []
+            nblk = _ext.rows_chain_bwd_blocks(R)
+            kept_for = {}  # tile index -> an add & norm above keeps its residual gradient for it
+            for j, s in enumerate(range(top, -1, -1)):
+                (iW, ib, act_kind, act_p, act_call, has, res, ig, ibeta, ln_p, ln_call, eps) = spec[s]
+                N, K = tensors[iW].shape
+                P = {"base": pend[s + 1] if j > 0 else None, "add_kept": int(kept_for.pop(s + 1, False))}
+                if has:
+                    part = torch.empty((nblk, 2, N), dtype=torch.float32, device=dev)
+                    g = torch.empty((R, N), dtype=torch.float32, device=dev)
+                    P.update(op=1, aux=xhats[s], rstd=rstds[s], gamma=tensors[ig], p=ln_p, call=ln_call, g_out=g, part=part)
+                    if res[0] == "ext":
+                        dres = torch.empty((R, N), dtype=torch.float32, device=dev)
+                        P["dres_out"] = dres
+                        grads[res[1]] = accumulate(grads[res[1]], dres)
+                    else:
+                        P["keep"] = 1
+                        kept_for[res[1]] = True
+                    lns.append((s, part))
+                elif act_kind >= 0:
+                    g = torch.empty((R, N), dtype=torch.float32, device=dev)
+                    P.update(op=2, aux=zs[s], act_kind=act_kind, p=act_p, call=act_call, g_out=g)
+                elif j == 0:
+                    g = G  # the incoming gradient is what this stage's weight gradient reads
+                else:
+                    g = torch.empty((R, N), dtype=torch.float32, device=dev)
+                    P.update(op=0, g_out=g)
+                gouts[s] = g
+                points.append(P)
+                gemms.append({"Wt": ctx.wt[s], "N": K, "K": N})
+            gX = torch.empty((R, tensors[spec[0][0]].shape[1]), dtype=torch.float32, device=dev)
+            points.append({"base": pend[0], "add_kept": int(kept_for.pop(0, False)), "op": 0, "g_out": gX})
+            assert not kept_for
+            _ext.rows_chain_bwd(G, points, gemms, seed)
+            for s, part in lns:
+                ig, ibeta = spec[s][7], spec[s][8]
+                N = part.shape[2]
+                dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
+                _ext.reduce_slabs(part, nblk, dgb, 2 * N, 2 * N, 2 * N)
+                grads[ig], grads[ibeta] = dgb[0], dgb[1]
+            for s in range(top, -1, -1):
+                iW, ib = spec[s][0], spec[s][1]
+                N, K = tensors[iW].shape
+                want_db = ib is not None and ctx.needs_input_grad[3 + ib]
+                if ctx.needs_input_grad[3 + iW]:
+                    dw, db = mfma_linear.weight_grad(gouts[s], tiles[s], N, K, want_db, 1)
+                    grads[iW] = dw
+                    if want_db:
+                        grads[ib] = db
+            pend[0] = gX
+
+        s = n - 1
+        while s >= 0 and not chainable(s):
+            unfused_stage(s)
+            s -= 1
+        if s >= 0:
+            fused_run(s)
         gX = pend[0]
         for i, t in enumerate(tensors):  # residual tensors keep the caller's shape
             if grads[i] is not None and grads[i].shape != t.shape:

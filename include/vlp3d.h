@@ -615,6 +615,39 @@ typedef struct vlp3d_chain_stage {
 int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
                      const unsigned long long *seed, void *stream);
 
+/* Backward of such a chain's row-local part, again one launch over 32-row tiles (csrc/rows_chain.hip).  The gradient walks
+ * `ngemm` input-gradient products with `ngemm + 1` POINTS between them; point 0 sees the incoming gradient G (R x gemms[0].K),
+ * point j > 0 the result of product j-1 (R x gemms[j-1].N).  At a point, in this order:
+ *   + base   (R x N, e.g. the gradient a residual connection delivers from outside the chain), + the kept residual gradient
+ *   op 0: nothing.
+ *   op 1: add & norm backward (vlp3d_sum_norm_bwd's arithmetic, N = 128) with aux = xhat, rstd, gamma, dropout (p, call):
+ *         the gradient of the residual input goes to dres_out and / or is kept for a later point's add_kept; the gradient of
+ *         the normalised branch continues; part (blocks x 2 x 128, blocks = vlp3d_rows_chain_bwd_blocks(R)) receives this
+ *         workgroup's [sum dout*xhat | sum dout] for vlp3d_slab_reduce_batch.
+ *   op 2: activation + dropout backward (vlp3d_act_dropout's arithmetic) with aux = z, act_kind, (p, call).
+ *   g_out != NULL: the gradient after the op is stored (R x N) — what the layer's weight gradient reads; required at the last point.
+ * Product j: out = g Wt^T with Wt (N x K) row-major = the forward weight TRANSPOSED (dX = dY W needs W's columns as rows; the
+ * K-major copies row_mlp.PreparedWeights keeps serve both directions).  N, K multiples of 128, <= 256. */
+typedef struct vlp3d_chain_bwd_point {
+  const float *base;
+  int add_kept;
+  int op;
+  const float *aux, *rstd, *gamma;
+  float p;
+  int call;
+  int act_kind;
+  float *g_out, *dres_out;
+  int keep;
+  float *part;
+} vlp3d_chain_bwd_point;
+typedef struct vlp3d_chain_bwd_gemm {
+  const float *Wt;
+  int N, K;
+} vlp3d_chain_bwd_gemm;
+int vlp3d_rows_chain_bwd_blocks(long long R);
+int vlp3d_rows_chain_bwd(const float *G, long long R, const vlp3d_chain_bwd_point *points, const vlp3d_chain_bwd_gemm *gemms,
+                         int ngemm, const unsigned long long *seed, void *stream);
+
 /* Caption head (csrc/caption.hip).  Replaces, for `TransformerDecoderModel(30522)` of models/jointnet/jointnet.py:104:
  *
  * cap_attn — `attention()` + the head split/merge of `MultiHeadedAttention.forward`

@@ -1498,7 +1498,8 @@ def test_row_chain_equals_unfused_modules(p):
     as ONE launch (csrc/rows_chain.hip) against the same modules as separate launches with the same dropout call ids (= the
     same masks): the first add & norm equals to fp32 round-off (only the order of the row statistics differs); after it a
     1e-7 difference can flip a bf16 operand rounding, so later tensors agree on all but a sprinkle of elements.  Backward of
-    the chain = the unfused entry points on the stored tensors: every gradient agrees to bf16-flip noise."""
+    the chain = the q|k|v product's own launch, then ONE launch for the rest (vlp3d_rows_chain_bwd), which has to regenerate the
+    forward launch's dropout masks (p = 0.1: a wrong mask is an O(1) error): every gradient agrees to bf16-flip noise."""
     an = importlib.import_module("3dvlp_amd.add_norm")
     ml = importlib.import_module("3dvlp_amd.mfma_linear")
     rc = importlib.import_module("3dvlp_amd.row_chain")
@@ -1649,3 +1650,47 @@ def test_match_module_chained_decoder_equals_layer_modules():
             continue
         bf_cost = float((mods[n] - exact[n]).norm())
         assert float((chain[n] - mods[n]).norm()) < 0.5 * bf_cost + 1e-6 * scale, (n, _rel(chain[n], mods[n]), _rel(mods[n], exact[n]))
+
+
+@pytest.mark.parametrize("R", [100, 32, 7])
+def test_row_chain_backward_kernel_against_fp64_arithmetic(R):
+    """vlp3d_rows_chain_bwd on row counts that fill no tile: add & norm backward (residual gradient kept in registers) ->
+    product (128 -> 256) -> ReLU backward -> product (256 -> 128) -> + base + kept -> add & norm backward (residual gradient
+    stored) -> product -> result.  Every stage against fp64 arithmetic on the bf16-rounded operands it actually multiplied (the
+    stored gradient of the stage before it), and the [dgamma | dbeta] slabs against the column sums."""
+    ext = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(R)
+    cu = lambda *s: torch.randn(*s, device="cuda")
+    G, xh0, xh2, z, base = cu(R, 128), cu(R, 128), cu(R, 128), cu(R, 256), cu(R, 128)
+    rs0, rs2 = torch.rand(R, device="cuda") + 0.5, torch.rand(R, device="cuda") + 0.5
+    gam0, gam2 = torch.rand(128, device="cuda") + 0.5, torch.rand(128, device="cuda") + 0.5
+    Wt0, Wt1, Wt2 = cu(256, 128) * 0.1, cu(128, 256) * 0.1, cu(128, 128) * 0.1
+    nblk = ext.rows_chain_bwd_blocks(R)
+    e = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dy0, dz, dy2, dres2, gX = e(R, 128), e(R, 256), e(R, 128), e(R, 128), e(R, 128)
+    part0, part2 = e(nblk, 2, 128), e(nblk, 2, 128)
+    ext.rows_chain_bwd(G, [dict(op=1, aux=xh0, rstd=rs0, gamma=gam0, g_out=dy0, keep=1, part=part0),
+                           dict(op=2, aux=z, act_kind=0, g_out=dz),
+                           dict(base=base, add_kept=1, op=1, aux=xh2, rstd=rs2, gamma=gam2, g_out=dy2, dres_out=dres2, part=part2),
+                           dict(op=0, g_out=gX)],
+                       [dict(Wt=Wt0, N=256, K=128), dict(Wt=Wt1, N=128, K=256), dict(Wt=Wt2, N=128, K=128)], None)
+    r16 = lambda t: t.bfloat16().double()
+
+    def ln_bwd(v, xhat, rstd, gamma):
+        gg = v * gamma.double()
+        m1, m2 = gg.mean(1, keepdim=True), (gg * xhat.double()).mean(1, keepdim=True)
+        return rstd.double()[:, None] * (gg - m1 - xhat.double() * m2)
+
+    close = lambda a, b: torch.testing.assert_close(a.double(), b, rtol=1e-4, atol=1e-5)
+    dx0 = ln_bwd(G.double(), xh0, rs0, gam0)
+    close(dy0, dx0)
+    close(part0.sum(0)[0], (G.double() * xh0.double()).sum(0))
+    close(part0.sum(0)[1], G.double().sum(0))
+    close(dz, (r16(dy0) @ r16(Wt0).t()) * (z > 0).double())
+    v2 = r16(dz) @ r16(Wt1).t() + base.double() + dx0
+    dx2 = ln_bwd(v2, xh2, rs2, gam2)
+    close(dres2, dx2)
+    close(dy2, dx2)
+    close(part2.sum(0)[0], (v2 * xh2.double()).sum(0))
+    close(part2.sum(0)[1], v2.sum(0))
+    close(gX, r16(dy2) @ r16(Wt2).t())
