@@ -336,6 +336,33 @@ def test_three_nn_fuzz_vs_oracle(ext, seed):
         assert ((got == rd2) | (np.isinf(got) & np.isinf(rd2))).all(), (case, kind, B, n, m)
 
 
+@pytest.mark.parametrize("B,N,M,S", [(8, 2048, 1024, 32), (3, 500, 77, 5), (2, 8192, 64, 16), (2, 9000, 64, 16), (1, 1, 1, 1)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_sa_inverse_lists_exactly_the_rows_of_every_point(ext, B, N, M, S, compact):
+    """vlp3d_sa_inverse (one workgroup per cloud for N <= 8192, the five-launch form above that): inv_start is the exclusive
+    scan of the per-point row counts and the slice of a point holds exactly the rows that gather it (any order) — over all
+    padded rows, and over the distinct rows of the compact map (whose row u of ball j reads point crow[u].x)."""
+    rng = np.random.default_rng(B * 1000 + N)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    idx[:, :, S // 2:] = idx[:, :, :1]  # ball-query padding: the tail repeats the first neighbour
+    d = dev(idx)
+    cmap = ext.sa_compact(d, N) if compact else None
+    start, rows = ext.sa_inverse(d, N, cmap)
+    start, rows = start.cpu().numpy().astype(np.int64), rows.cpu().numpy()
+    if compact:
+        rowptr, crow = cmap[0].cpu().numpy(), cmap[1].cpu().numpy()
+        total = int(rowptr[-1])
+        point = crow[:total, 0].astype(np.int64)
+    else:
+        total = B * M * S
+        point = (np.arange(B)[:, None, None] * N + idx).reshape(-1).astype(np.int64)
+    counts = np.bincount(point, minlength=B * N)
+    assert start[0] == 0 and start[-1] == total and (np.diff(start) == counts).all()
+    got = rows[:total].astype(np.int64)
+    assert (np.sort(got) == np.arange(total)).all()                      # every row listed exactly once
+    assert (point[got] == np.repeat(np.arange(B * N), counts)).all()     # ... in the slice of the point it gathers
+
+
 def test_gather_and_group_forward_backward(pu):
     rng = np.random.default_rng(11)
     B, C, N, M, S = 3, 37, 500, 60, 9
