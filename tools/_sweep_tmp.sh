@@ -1,6 +1,6 @@
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > /dev/null 2>&1
-mkdir -p /tmp/pt/x && cp /tmp/prof_t/t_kernel_trace.csv /tmp/pt/x/
-cd $GRAFT_REPO_ROOT
-python tools/step_timeline.py /tmp/pt > gpurun_out/timeline_chain.txt 2>&1
-grep -n "^== queue" gpurun_out/timeline_chain.txt
+for v in 0 1 0 1; do
+  echo "DEFERRED_LAST=$v: $(VLP3D_DEFERRED_LAST=$v timeout -k 10 300 python bench.py 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'])")"
+done
