@@ -64,14 +64,17 @@ __device__ __forceinline__ unsigned spread5(unsigned v) {  // 5 bits -> every th
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
 
-// ---- pre-pass 1: per-scene bounding box, histogram cleared -------------------------------------------------
-__global__ __launch_bounds__(1024) void fps_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ bbox,
-                                                        int *__restrict__ hist) {
-  __shared__ float red[6][16];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// ---- pre-pass 1: bounding boxes of BBOX_PARTS chunks of every scene, histogram cleared ------------------------
+// (one workgroup per scene read its 480 KB alone: 16.5 us; the cell kernel folds the partial boxes itself)
+constexpr int BBOX_PARTS = 16;
+__global__ __launch_bounds__(256) void fps_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ bbox,
+                                                       int *__restrict__ hist) {
+  __shared__ float red[6][4];
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
   const float *p = xyz + (size_t)b * N * 3;
+  const int per = (N + BBOX_PARTS - 1) / BBOX_PARTS, k1 = min(N, (part + 1) * per);
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = tid; k < N; k += 1024)
+  for (int k = part * per + tid; k < k1; k += 256)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float v = p[k * 3 + a];
@@ -86,12 +89,12 @@ __global__ __launch_bounds__(1024) void fps_bbox_kernel(const float *__restrict_
       red[3 + a][tid >> 6] = h;
     }
   }
-  for (int c = tid; c < NCELL; c += 1024) hist[(size_t)b * NCELL + c] = 0;
+  for (int c = part * (NCELL / BBOX_PARTS) + tid; c < (part + 1) * (NCELL / BBOX_PARTS); c += 256) hist[(size_t)b * NCELL + c] = 0;
   __syncthreads();
   if (tid < 6) {
     float v = red[tid][0];
-    for (int w = 1; w < 16; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
-    bbox[b * 6 + tid] = v;
+    for (int w = 1; w < 4; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+    bbox[(b * BBOX_PARTS + part) * 6 + tid] = v;
   }
 }
 
@@ -99,13 +102,23 @@ __global__ __launch_bounds__(1024) void fps_bbox_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__ xyz, int N,
                                                        const float *__restrict__ bbox, int *__restrict__ cellid,
                                                        int *__restrict__ hist) {
+  __shared__ float bb[6];
   const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 6) {
+    float v = bbox[b * BBOX_PARTS * 6 + threadIdx.x];
+    for (int w = 1; w < BBOX_PARTS; ++w) {
+      const float o = bbox[(b * BBOX_PARTS + w) * 6 + threadIdx.x];
+      v = threadIdx.x < 3 ? fminf(v, o) : fmaxf(v, o);
+    }
+    bb[threadIdx.x] = v;
+  }
+  __syncthreads();
   if (k >= N) return;
   const float *p = xyz + ((size_t)b * N + k) * 3;
   unsigned q[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float lo = bbox[b * 6 + a], hi = bbox[b * 6 + 3 + a];
+    const float lo = bb[a], hi = bb[3 + a];
     const float ext = hi - lo;
     float t = ext > 0.f ? (p[a] - lo) / ext * 32.f : 0.f;
     int c = (int)t;
@@ -184,6 +197,10 @@ __global__ __launch_bounds__(256) void fps_scatter_kernel(const float *__restric
   perm[(size_t)b * N + pos] = k;
 }
 
+// (Measured and rejected, round 3: the whole pre-pass of a scene in ONE workgroup — bounding box, cells kept in registers,
+// the 32 768-bin histogram and the slot claims as LDS atomics, the scan in between — to replace the four launches' 320 000
+// memory-side atomics each way and three kernel boundaries: 118-125 us against 81 us; forty Hilbert codes and two LDS atomics
+// per thread on one CU per scene are slower than the same work spread over the chip.)
 // ---- main kernel ------------------------------------------------------------------------------------------------
 // One workgroup (16 waves) per scene.  The per-iteration dependency chain is what bounds it, so:
 //  * the cached per-slot state is (max value, winner lane, winner coordinates); the reference's tie order among
@@ -464,7 +481,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
   if (B < 1 || N < 1) return 0;
   return (long long)(align256((size_t)B * N * 16) + align256((size_t)B * N * 4) * 2 + align256((size_t)B * NCELL * 4) +
-                     align256((size_t)B * 6 * 4));
+                     align256((size_t)B * BBOX_PARTS * 6 * 4));
 }
 
 // Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
@@ -505,7 +522,7 @@ static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *worksp
   w += align256((size_t)B * NCELL * 4);
   float *bbox = (float *)w;
   const dim3 gridN((N + 255) / 256, B);
-  hipLaunchKernelGGL(fps_bbox_kernel, dim3(B), dim3(1024), 0, s, xyz, N, bbox, hist);
+  hipLaunchKernelGGL(fps_bbox_kernel, dim3(BBOX_PARTS, B), dim3(256), 0, s, xyz, N, bbox, hist);
   hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist);
   hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
   hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
