@@ -136,7 +136,8 @@ def pmc_traffic():
 
 STAMPED = ("vlp3d_sa_fwd_gather", "vlp3d_sa_fwd_layer", "vlp3d_sa_bwd_layer", "vlp3d_sa_bwd_gather", "vlp3d_sa_wgrad",
            "vlp3d_sa_pool", "vlp3d_sdpa_fwd", "vlp3d_sdpa_bwd", "vlp3d_relation_bias_fwd", "vlp3d_relation_bias_bwd",
-           "vlp3d_furthest_point_sampling_pruned", "vlp3d_ball_query_grid", "vlp3d_probe_empty")
+           "vlp3d_furthest_point_sampling_pruned", "vlp3d_ball_query_grid", "vlp3d_rows_chain", "vlp3d_rows_chain_bwd",
+           "vlp3d_probe_empty")
 
 
 def in_step_durations(args, batch, gs, ext, steps=12, side_stream=None):
@@ -275,8 +276,26 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
               note="runs beside the side stream's deferred weight-gradient graph (GroundingStep: split backward)"),
     ]
     cands = [c for c in cands if c["ms"] is not None]
+    Rm = BL * 256
+    chain_bytes = Rm * 4 * (128 + 128 + 128 + 128 + 256 + 256 + 128 + 128 + 384)   # a, res | x2, xhat2, z, h, x3, xhat3, q|k|v
+    chain_bwd_bytes = Rm * 4 * (128 + 128 + 256 + 128 + 128 + 128 + 256 + 128 + 128 + 128)  # d x3 (+ base), xhat3, z, xhat2 | dy, dz, dy, d res, d a
     head = max(cands, key=lambda c: c["ms"] if c["ms_is"].startswith("in-step") else 0.0)
     head = dict(head, kernel=head["kernel"] + ": dominant main-stream kernel by in-step duration")
+    chain_fwd_ms = in_step("vlp3d_rows_chain", lambda a: a[1:3] == (Rm, 4))
+    chain_bwd_ms = in_step("vlp3d_rows_chain_bwd", lambda a: a[1] == Rm and a[2] == 3, pick=min)
+    chain_entries = []  # bf16 configuration only: the fp32 step runs the layer modules' own launches
+    if chain_fwd_ms is not None:
+        chain_entries.append(
+            entry("rows_chain_kernel<32> decoder-layer tail: fc_o -> add & norm -> FFN -> add & norm -> next q|k|v, 16 384 rows, one "
+                  "launch", "rows_chain_kernel", "hbm", chain_bytes, PEAK_HBM_GBS, "GB/s", None, chain_fwd_ms,
+                  algorithmic_bytes=chain_bytes,
+                  numerator="fp32 rows the stage contract moves: input + residual in, every stage output and what backward keeps "
+                            "(pre-activation, FFN hidden, xhat) out; the weights (0.5 MB) stay in L2"))
+    if chain_bwd_ms is not None:
+        chain_entries.append(
+            entry("rows_chain_bwd_kernel decoder-layer tail backward: add & norm bwd -> W2^T -> ReLU/dropout bwd -> W1^T -> add & norm "
+                  "bwd -> fc_o^T, one launch", "rows_chain_bwd_kernel", "hbm", chain_bwd_bytes, PEAK_HBM_GBS, "GB/s", None,
+                  chain_bwd_ms, algorithmic_bytes=chain_bwd_bytes))
     others = [c for c in cands if c["kernel"] not in head["kernel"]] + [
         entry("relation_bias_bwd_kernel (pairwise-geometry bias MLP 4->32->32->4, backward, one of two layers; side stream since "
               "the split backward)", "relation_bias_bwd", "mfma", rel_flops, PEAK_BF16_MFMA_TFLOPS / 16, "TFLOP/s", None,
@@ -292,6 +311,7 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
               ("bq_bbox", "bq_header", "bq_count", "bq_scan", "bq_scatter", "bq_query"), "hbm", bq_bytes, PEAK_HBM_GBS, "GB/s", bq_ms,
               in_step("vlp3d_ball_query_grid", lambda a: 40000 in a), tests_per_s_T=round(B * m * n / (bq_ms * 1e-3) / 1e12, 3),
               valu_frac_of_dense_tests=round(B * m * n * 8.0 / (bq_ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4)),
+    ] + chain_entries + [
         entry(sdpa_name + " match self-attention 64x(256x256) h4 d32", "sdpa_fwd", "hbm", att_alg, PEAK_HBM_GBS, "GB/s", att_ms,
               in_step("vlp3d_sdpa_fwd", lambda a: a[1:5] == (BL, 4, 256, 256)), algorithmic_bytes=att_alg, moved_bytes=att_moved,
               mfma_TFLOPs=round(4.0 * BL * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),

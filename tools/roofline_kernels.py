@@ -63,4 +63,19 @@ for bf in (True, False):
             fa.sdpa(q, kc, kc, 4, bf16_mma=bf)
         else:
             fa.sdpa(q, q, q, 4, bf16_mma=bf)
+# the decoder layer's row chain (fc_o -> add & norm -> FFN -> add & norm -> the next layer's q|k|v) and its backward, R = 16 384
+if mode == "self":
+    rc = importlib.import_module("3dvlp_amd.row_chain")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    lin = lambda n_, k_: torch.nn.Linear(k_, n_).to(dev)
+    fo, l1, l2, nx = lin(128, 128), lin(256, 128), lin(128, 256), lin(384, 128)
+    n1, n2 = torch.nn.LayerNorm(128).to(dev), torch.nn.LayerNorm(128).to(dev)
+    a0 = torch.randn(16384, 128, device=dev, requires_grad=True)
+    x0 = torch.randn(16384, 128, device=dev, requires_grad=True)
+    g3, gq = torch.randn(16384, 128, device=dev), torch.randn(16384, 384, device=dev)
+    with ml.bf16_mma(True):
+        for _ in range(3):
+            t = rc.run(a0, [rc.linear_add_norm(fo.weight, fo.bias, n1, x0, 0.1), rc.linear(l1.weight, l1.bias, "relu", 0.1),
+                            rc.linear_add_norm(l2.weight, l2.bias, n2, ("tile", 1), 0.1), rc.linear(nx.weight, nx.bias)])
+            torch.autograd.backward([t[2], t[3]], [g3, gq])
 torch.cuda.synchronize()
