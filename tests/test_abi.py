@@ -68,3 +68,41 @@ def test_state_dict_keys_match_reference_layout(golden, built):
     g = golden("shared_mlp")
     m = pt.SharedMLP([135, 64, 64, 128], bn=True)
     assert sorted(m.state_dict().keys()) == sorted(g["meta/keys"].tolist())
+
+
+def test_descriptor_structs_have_the_header_layout(tmp_path):
+    """The batched / chained entry points take arrays of plain C structs (include/vlp3d.h); the ctypes mirrors in _lib.py must
+    agree with what a C compiler makes of the header: size and every field offset, from a probe compiled with gcc."""
+    import subprocess
+    _lib = importlib.import_module("3dvlp_amd._lib")
+    pairs = {"vlp3d_copy_desc": _lib.CopyDesc, "vlp3d_transpose_desc": _lib.TransposeDesc, "vlp3d_chain_stage": _lib.ChainStage,
+             "vlp3d_chain_bwd_point": _lib.ChainBwdPoint, "vlp3d_chain_bwd_gemm": _lib.ChainBwdGemm}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vlp3d.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "probe.c", tmp_path / "probe"
+    src.write_text("\n".join(lines))
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, field, val = ln.split()
+        got[(cname, field)] = int(val)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert got[(cname, field)] == getattr(cls, field).offset, (cname, field)
+
+
+def test_row_chain_declines_what_its_kernels_do_not_cover():
+    """Host logic of row_chain.supported: CPU tensors, the exact-fp32 configuration, row counts that fill no 64-row pair of
+    tiles and widths outside the 128-column weight blocks go to the layer modules' own launches."""
+    rc = importlib.import_module("3dvlp_amd.row_chain")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    w = torch.zeros(128, 128)
+    st = [rc.linear(w, None)]
+    with ml.bf16_mma(True):
+        assert not rc.supported(torch.zeros(64, 128), st)            # CPU
+    assert not rc.supported(torch.zeros(64, 128), st)                # exact-fp32 configuration
