@@ -375,11 +375,17 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
     }
   };
   load_tile(0, kreg, vreg, kcol);
+  float bnext[16];  // the next tile's bias values travel with its K / V rows (16 B / lane x 4 loads behind two products otherwise)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bnext[i] = 0.f;
+  load_bias_tile(bias, bias_mode, bias_row, 0, half, nk, bnext);
   for (int k0 = 0; k0 < nk; k0 += 32) {
     float knext[16], vnext[16], kcnext[16];  // next tile in flight while this one is computed
     load_tile(min(k0 + 32, nk - 1), knext, vnext, kcnext);
     float bt[16], db[16] = {};
-    load_bias_tile(bias, bias_mode, bias_row, k0, half, nk, bt);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bt[i] = bnext[i];
+    if (k0 + 32 < nk) load_bias_tile(bias, bias_mode, bias_row, k0 + 32, half, nk, bnext);
     f32x16 s = mfma_rows<BF>(kreg, qreg, zero16());    // S^T  [key][query]
     f32x16 dp = mfma_rows<BF>(vreg, doreg, zero16());  // dP^T [key][query] = V dO^T
 #pragma unroll
@@ -632,6 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
 // converted to bf16 ONCE while staging, row-major (S = Q K^T, dP = dO V^T: a lane's operand = two ds_read_b128) and
 // transposed (dV^T += dO^T P, dK^T += Q^T dS: four ds_read_b64 in the accumulator's row order); lse / delta as fp32.
 // ---------------------------------------------------------------------------------------------
+template <bool BIAS>  // BIAS = false: no bias registers in the match cores' instantiation (16 more cost them 12 %)
 __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
@@ -698,6 +705,14 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
   f32x16 dka = zero16(), dva = zero16();
   for (int q0 = tile_ok ? 32 * qs : nq; q0 < nq; q0 += 32 * qsplit) {
     f32x16 s = zero16(), dp = zero16();
+    // the tile's 16 bias values of this lane (key ki, queries q0 + acc_row): ALL loads issued here, in front of the products,
+    // under one wave-uniform branch (read where they are used, each sat behind its own bounds test: 16 dependent L2 round
+    // trips per tile — the relation module's cores took 40 us for 0.17 GF)
+    float bt[BIAS ? 16 : 1];
+    if (BIAS) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bt[i] = bias[(stat0 + min(q0 + acc_row(i, half), nq - 1)) * nk + ki];
+    }
     const short *qr = sQ + (q0 + r) * KS + 16 * half, *dr = sDO + (q0 + r) * KS + 16 * half;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {  // S[query][key], dP[query][key]: lane = key
@@ -717,11 +732,11 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
         float pv = 0.f, ds = 0.f;
         if (qq < nq && k_ok) {
           const float raw = s[i] * scale;
-          float x = apply_bias(raw, bias_mode, bias, (stat0 + qq) * nk + ki);
+          float x = BIAS ? apply_bias_value(raw, bias_mode, bt[BIAS ? i : 0]) : raw;
           if (masked) x = -10000.f;
           pv = __expf(x - lv[e]);
           ds = masked ? 0.f : pv * (dp[i] - dl[e]);
-          if (bias_mode == 2) ds *= bias[(stat0 + qq) * nk + ki];
+          if (BIAS && bias_mode == 2) ds *= bt[BIAS ? i : 0];
         }
         p[i] = pv;
         s[i] = ds;
@@ -872,14 +887,21 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
       size_t lds_all = lds_kv;
       const size_t lds_red = (size_t)(qsplit >> 1) * wpb * 2048 * sizeof(float);
       if (lds_red > lds_all) lds_all = lds_red;
+      const bool with_bias = bias_mode != 0;
       if (lds_all > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel),
+        hipError_t e = hipFuncSetAttribute(with_bias ? reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<true>)
+                                                     : reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s, q,
-                         k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
-                         qsplit);
+      if (with_bias)
+        hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel<true>, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s,
+                           q, k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
+                           qsplit);
+      else
+        hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel<false>, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s,
+                           q, k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
+                           qsplit);
     } else
       hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
                          H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
