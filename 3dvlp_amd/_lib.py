@@ -60,6 +60,7 @@ SIGNATURES = {
     "vlp3d_sa_stat_slabs": [ctypes.c_longlong],
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_sa_pool_tstats_slabs": [ctypes.c_longlong],
     "vlp3d_sa_pool_tstats": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "vlp3d_sa_prep_weights": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "vlp3d_joint_loss_rows": [_i, _i, _i, _i],

@@ -1847,8 +1847,8 @@ __global__ __launch_bounds__(256) void pool_tstats_kernel(const float *__restric
     s1 += d;
     s2 += d * ((o - b) * inv);
   }
-  atomicAdd(t + c, s1);
-  atomicAdd(t + C + c, s2);
+  t[((size_t)blockIdx.y * 2 + 0) * C + c] = s1;
+  t[((size_t)blockIdx.y * 2 + 1) * C + c] = s2;
 }
 
 void set_pool(RowGemmArgs &a, const float *pool_g, const unsigned char *pool_sel, int pool_S) {
@@ -2205,12 +2205,21 @@ extern "C" int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, cons
   return VLP3D_OK;
 }
 
-// t (2 x C) f64 += [sum g, sum g*yhat] of the last layer from the pooled tensors (t zeroed by the caller).
+// t (slabs x 2 x C) f64 = per-workgroup [sum g, sum g*yhat] of the last layer from the pooled tensors: one slab per row
+// group (the fp64 atomics into one (2 x C) buffer needed a clear launch in front of every SA backward).
+static long long pool_tstats_rows_per_block(long long BM) {
+  const long long rpb = (BM + 127) / 128;
+  return rpb < 16 ? 16 : rpb;
+}
+extern "C" int vlp3d_sa_pool_tstats_slabs(long long BM) {
+  if (BM < 1) return 0;
+  const long long rpb = pool_tstats_rows_per_block(BM);
+  return (int)((BM + rpb - 1) / rpb);
+}
 extern "C" int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta,
                                     long long BM, int C, double *t, float *gsel, void *stream) {
   if (!dP || !out || !gamma || !beta || !t || !gsel || BM < 1 || C < 1) return VLP3D_EINVAL;
-  long long rpb = (BM + 127) / 128;
-  if (rpb < 16) rpb = 16;
+  const long long rpb = pool_tstats_rows_per_block(BM);
   const dim3 grid((C + 255) / 256, (unsigned)((BM + rpb - 1) / rpb));
   hipLaunchKernelGGL(pool_tstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dP, out, gamma, beta, BM, C, rpb, t,
                      gsel);

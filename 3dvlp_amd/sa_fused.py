@@ -119,20 +119,22 @@ class FusedSAMLP(Function):
         need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
         dparams = [None] * 9
 
-        # BN-backward reductions: per-workgroup slabs for layers 1-2 (written by the MASK epilogue), one zeroed
-        # (2 x C) buffer for the last layer (pool_tstats adds into it)
+        # BN-backward reductions: per-workgroup slabs for layers 1-2 (written by the MASK epilogue) and for the last layer
+        # (pool_tstats: one slab per row group — nothing to clear)
         nslab = int(_ext.load().vlp3d_sa_stat_slabs(R))
-        # ONE zero-filled arena per backward (one fill launch): [t3 (2 x C3 fp64) | d(features) | d(xyz) | d(new_xyz)]
-        n_t3 = 4 * cout[2]
+        ns3 = int(_ext.load().vlp3d_sa_pool_tstats_slabs(B * M))
+        # ONE zero-filled arena per backward for the scatter-add targets (one fill launch; none with the CSR adjoint and no
+        # coordinate gradients): [d(features) | d(xyz) | d(new_xyz)]
+        n_t3 = 0
         csr = ctx.inv is not None and need[3] and not need[0] and not need[1] and cout[0] in (64, 128)
         n_df = B * N * C if (need[3] and not csr) else 0
         n_dx = B * N * 3 if need[0] else 0
         n_dn = B * M * 3 if need[1] else 0
-        arena = torch.zeros((n_t3 + n_df + n_dx + n_dn,), dtype=torch.float32, device=dev)
+        arena = torch.zeros((n_df + n_dx + n_dn,), dtype=torch.float32, device=dev) if n_df + n_dx + n_dn else None
         t = [torch.empty((nslab, 2, cout[0]), dtype=torch.float64, device=dev),
              torch.empty((nslab, 2, cout[1]), dtype=torch.float64, device=dev),
-             arena[:n_t3].view(torch.float64).view(1, 2, cout[2])]
-        tn = [nslab, nslab, 1]
+             torch.empty((ns3, 2, cout[2]), dtype=torch.float64, device=dev)]
+        tn = [nslab, nslab, ns3]
 
         # layer 3: the masked gradient lives only at the selected sample of each ball — it is synthesised inside the
         # loaders from (dP, out, sel), and its BN reductions come from the pooled tensors

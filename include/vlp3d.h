@@ -204,8 +204,10 @@ int vlp3d_sa_bn_fold(const double *stats, int nslab, const float *gamma, const f
 /* bn5 (5 x C) backward constants, dgamma, dbeta (C) from vec, gamma and the reductions t (2 x C) f64. */
 int vlp3d_sa_bn_bwd_consts(const float *vec, const float *gamma, const double *t, int nslab, int C, long long R,
                            int training, float *bn5, float *dgamma, float *dbeta, void *stream);
-/* t (2 x C) f64 += [sum g, sum g*yhat] of the LAST layer computed from the pooled tensors (t zeroed by caller);
+/* t (vlp3d_sa_pool_tstats_slabs(BM) x 2 x C) f64 = per-workgroup [sum g, sum g*yhat] of the LAST layer computed from the
+ * pooled tensors (slabs for vlp3d_sa_bn_bwd_consts's nslab: nothing to clear, the sums do not depend on an atomic order);
  * gsel (BM x C) f32 = dP where out > 0 else 0 (the ReLU-masked pooled gradient the last-layer loaders read). */
+int vlp3d_sa_pool_tstats_slabs(long long BM);
 int vlp3d_sa_pool_tstats(const float *dP, const float *out, const float *gamma, const float *beta, long long BM, int C,
                          double *t, float *gsel, void *stream);
 
