@@ -36,8 +36,12 @@ def note_fallback(rows, K, N, where="linear"):
 def supported(x, weight):
     R = x.numel() // x.shape[-1]
     N, K = weight.shape
-    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and R % 32 == 0 and R >= 32
-            and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K):
+    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and shape_supported(R, K, N)
+
+
+def shape_supported(R, K, N):
+    """R rows of K columns through a weight (N, K): shapes the forward, input-gradient and weight-gradient kernels all cover."""
+    if not (R % 32 == 0 and R >= 32 and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K):
         return False
     kt = (K + 31) // 32
     blocked = N > 256 or (N // 32) * kt > 36  # the weight gradient then runs as 128-column workgroup blocks

@@ -41,11 +41,12 @@ def linear_add_norm(weight, bias, norm, res, p=0.0):
     return {"W": weight, "b": bias, "act": None, "p": float(p), "ln": norm, "res": res}
 
 
-def supported(x, stages):
+def supported(x, stages, rows=None):
+    """x: the chain's input (or any tensor of its device / dtype with `rows` = the row count and x.shape[-1] = the input width)."""
     if not (ENABLED and mfma_linear.BF16_MMA and x.is_cuda and x.dtype == torch.float32
             and not torch.is_autocast_enabled("cuda")):
         return False
-    R = x.numel() // x.shape[-1]
+    R = x.numel() // x.shape[-1] if rows is None else int(rows)
     if R % 64 or not 1 <= len(stages) <= 6:
         return False
     K = x.shape[-1]
@@ -54,7 +55,7 @@ def supported(x, stages):
         last = s + 1 == len(stages)
         if Kw != K or K not in (128, 256) or N % 128 or N > (384 if last else 256) or R * N >= 2 ** 32:
             return False
-        if st["W"].dtype != torch.float32 or not mfma_linear.supported(x.new_empty((R, K)), st["W"]):
+        if st["W"].dtype != torch.float32 or not mfma_linear.shape_supported(R, K, N):
             return False
         if st["ln"] is not None:
             ln = st["ln"]

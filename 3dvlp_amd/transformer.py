@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import add_norm, fused_attention, row_chain
+from . import add_norm, fused_attention, mfma_linear, row_chain
 from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 
@@ -211,9 +211,9 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
     B, K, C = query.shape
     R = B * rep * K
     if (not query.is_cuda or query.dtype != torch.float32 or C != 128 or not l0.fused_norm or not mha.fused_norm
-            or mha.identity_map_reordering or not mfma_supported(query, layers, R)):
+            or mha.identity_map_reordering or not mfma_linear.BF16_MMA or R % 64 or torch.is_autocast_enabled("cuda")):
         return None
-    probe = query.new_empty((R, C))
+    probe = query  # device / dtype / width of the chains' inputs; the row count goes with `rows=`
     plan = []
     for i, layer in enumerate(layers):
         ca, ffn = layer.enc_dec_attention, layer.ffn
@@ -227,13 +227,13 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
         else:
             st.extend(tail)
         plan.append(st)
-        if not row_chain.supported(probe, st):
+        if not row_chain.supported(probe, st, rows=R):
             return None
         if i > 0:
             sa = layer.self_attention
             head = [row_chain.linear_add_norm(sa.attention.fc_o.weight, sa.attention.fc_o.bias, sa.layer_norm, probe, sa.dropout.p),
                     row_chain.linear(ca.attention.fc_q.weight, ca.attention.fc_q.bias)]
-            if not row_chain.supported(probe, head):
+            if not row_chain.supported(probe, head, rows=R):
                 return None
     h = mha.attention.h
     bf = mha.attention.bf16_mma
@@ -262,7 +262,3 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
             tail_out = t[-1]
     return x.view(B * rep, K, C), tail_out
 
-
-def mfma_supported(query, layers, R):
-    from . import mfma_linear
-    return mfma_linear.BF16_MMA and R % 64 == 0 and len(layers) >= 1 and not torch.is_autocast_enabled("cuda")
