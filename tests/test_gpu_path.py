@@ -1223,7 +1223,10 @@ def test_deferred_slab_reduce_equals_immediate(bf16):
     # ulp-level difference flips the rounding of a few stored gradient elements (4e-3 each), which the layers below amplify:
     # identical backbone inputs give weight gradients 1e-4 .. 5e-4 apart (Frobenius) from one pass to the next, and two
     # passes are often bit-identical while the third is not (tools/sa_determinism.py) — hence three baseline runs and a floor.
-    floor = 2e-3 if bf16 else 2e-5
+    # (the floor is a bound on that noise, not on the queue: a slab missing from the batched sum is an O(1) error, and the
+    # bit-equality of batched and per-layer launches on identical inputs is test_linear_wgrad_batch_equals_single_launches'.
+    # One run in ~8 of the full suite exceeded 2e-3 once the atomic-ordered inverse maps fed the SA backward.)
+    floor = 5e-3 if bf16 else 2e-5
     for n, g0 in grads[0].items():
         noise = max(_rel(grads[1][n], g0), _rel(grads[2][n], g0), _rel(grads[2][n], grads[1][n]))
         g1 = grads[3][n]
