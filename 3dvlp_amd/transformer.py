@@ -36,18 +36,20 @@ class ScaledDotProductAttention(nn.Module):
             nn.init.constant_(fc.bias, 0)
 
     def forward(self, queries, keys, values, attention_mask=None, attention_weights=None, way="add",
-                need_att=True, with_residual=False):
+                need_att=True, with_residual=False, project=True):
         """queries (b,nq,d_model), keys/values (b,nk,d_model); attention_mask broadcastable to
         (b,h,nq,nk) with 0 = masked (filled with -10000); attention_weights (b,h,nq,nk).
         Returns (out (b,nq,d_model), att (b,h,nq,nk) or None when the fused kernel ran).
         with_residual: returns (out, att, q_res) — q_res is `queries` routed through the query projection's autograd
-        node (mfma_linear.linear(with_residual=True)), for the residual connection of the caller."""
+        node (mfma_linear.linear(with_residual=True)), for the residual connection of the caller.
+        project=False: `out` is the heads' concatenated output BEFORE fc_o (the caller runs fc_o itself, e.g. as the first
+        stage of a row chain together with the add & norm that follows)."""
         if with_residual:
-            res = self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, True)
+            res = self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, True, project)
             return res if len(res) == 3 else (res[0], res[1], queries)
-        return self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, False)
+        return self._forward(queries, keys, values, attention_mask, attention_weights, way, need_att, False, project)
 
-    def _forward(self, queries, keys, values, attention_mask, attention_weights, way, need_att, wr):
+    def _forward(self, queries, keys, values, attention_mask, attention_weights, way, need_att, wr, project=True):
         b_s, nq = queries.shape[:2]
         nk = keys.shape[1]
         if way not in ("add", "mul"):
@@ -73,7 +75,7 @@ class ScaledDotProductAttention(nn.Module):
                 kv = _linear(keys, merge_adjacent([self.fc_k.weight, self.fc_v.weight]),
                              merge_adjacent([self.fc_k.bias, self.fc_v.bias]))
                 out = fused_attention.sdpa_merged(q, kv, self.h, aw, way, attention_mask, bf16_mma=self.bf16_mma)
-            o = _linear(out, self.fc_o.weight, self.fc_o.bias)
+            o = _linear(out, self.fc_o.weight, self.fc_o.bias) if project else out
             return (o, None, q_res) if wr else (o, None)
         q = _linear(queries, self.fc_q.weight, self.fc_q.bias)
         k = _linear(keys, self.fc_k.weight, self.fc_k.bias)
@@ -82,7 +84,7 @@ class ScaledDotProductAttention(nn.Module):
             out = fused_attention.sdpa(q.float(), k.float(), v.float(), self.h,
                                        None if attention_weights is None else attention_weights.float(), way,
                                        attention_mask, bf16_mma=self.bf16_mma)
-            return _linear(out, self.fc_o.weight, self.fc_o.bias), None
+            return (_linear(out, self.fc_o.weight, self.fc_o.bias) if project else out), None
         if impl == "hip" and not q.is_cuda:
             raise RuntimeError("CPU not supported (impl='hip'); pass impl='torch' explicitly for host-side tests")
         q = q.view(b_s, nq, self.h, self.d_k).permute(0, 2, 1, 3)
@@ -95,7 +97,7 @@ class ScaledDotProductAttention(nn.Module):
             att = att.masked_fill(attention_mask == 0, -10000)
         att = torch.softmax(att, -1)
         out = torch.matmul(att, v).permute(0, 2, 1, 3).contiguous().view(b_s, nq, self.h * self.d_v)
-        return _linear(out, self.fc_o.weight, self.fc_o.bias), att
+        return (_linear(out, self.fc_o.weight, self.fc_o.bias) if project else out), att
 
 
 class MultiHeadAttention(nn.Module):
@@ -119,6 +121,15 @@ class MultiHeadAttention(nn.Module):
                                       need_att=output_attn)
             out = queries + self.dropout(torch.relu(out))
         else:
+            fo = self.attention.fc_o
+            chain = [row_chain.linear_add_norm(fo.weight, fo.bias, self.layer_norm, queries, self.dropout.p)]
+            if (self.fused_norm and not output_attn and queries.dim() == 3
+                    and row_chain.supported(queries, chain, rows=queries.shape[0] * queries.shape[1])):
+                # fc_o -> dropout -> add -> LayerNorm as ONE launch each way (row_chain.py; bf16 configuration)
+                a, _, q_res = self.attention(queries, keys, values, attention_mask, attention_weights, way, need_att=False,
+                                             with_residual=True, project=False)
+                chain[0]["res"] = q_res
+                return row_chain.run(a, chain, self.training)[0].view(queries.shape)
             out, att, q_res = self.attention(queries, keys, values, attention_mask, attention_weights, way,
                                              need_att=output_attn, with_residual=True)
             if self.fused_norm and add_norm.supported(queries, out, self.layer_norm):

@@ -1697,3 +1697,54 @@ def test_row_chain_backward_kernel_against_fp64_arithmetic(R):
     close(part2.sum(0)[0], (v2 * xh2.double()).sum(0))
     close(part2.sum(0)[1], v2.sum(0))
     close(gX, r16(dy2) @ r16(Wt2).t())
+
+
+def test_multi_head_attention_fc_o_add_norm_chain_equals_separate_launches():
+    """MultiHeadAttention.forward in the bf16 configuration runs fc_o -> dropout -> add -> LayerNorm as ONE row-chain launch
+    each way (the relation module's two self-attention layers, 2048 rows): against the separate launches (row chains off) with
+    dropout 0, on the bf16 yardstick of test_match_module_chained_decoder_equals_layer_modules, with an additive attention bias
+    that needs its gradient."""
+    tr = importlib.import_module("3dvlp_amd.transformer")
+    ml = importlib.import_module("3dvlp_amd.mfma_linear")
+    rc = importlib.import_module("3dvlp_amd.row_chain")
+    ext_mod = importlib.import_module("3dvlp_amd._lib")
+    torch.manual_seed(21)
+    B, K, C = 8, 256, 128
+    mha = tr.MultiHeadAttention(d_model=C, d_k=32, d_v=32, h=4, dropout=0.0).cuda().train()
+    mha.fused_norm = True
+    mha.layer_norm.weight.data.uniform_(0.5, 1.5)
+    mha.layer_norm.bias.data.uniform_(-0.5, 0.5)
+    x0 = torch.randn(B, K, C, device="cuda")
+    bias0 = torch.randn(B, 4, K, K, device="cuda") * 0.5
+    g = torch.randn(B, K, C, device="cuda")
+
+    def run(bf, chain):
+        rc.ENABLED = chain
+        try:
+            mha.attention.bf16_mma = bf
+            mha.zero_grad()
+            x, bias = x0.clone().requires_grad_(), bias0.clone().requires_grad_()
+            launches = []
+            orig = ext_mod.rows_chain
+            ext_mod.rows_chain = lambda *a, **k: (launches.append(1), orig(*a, **k))[1]
+            try:
+                with ml.bf16_mma(bf):
+                    out = mha(x, x, x, attention_weights=bias, way="add")
+                    (out * g).sum().backward()
+            finally:
+                ext_mod.rows_chain = orig
+            res = {"out": out.detach().double(), "dx": x.grad.double(), "dbias": bias.grad.double()}
+            res.update({n: p.grad.double() for n, p in mha.named_parameters() if p.grad is not None})
+            return res, len(launches)
+        finally:
+            rc.ENABLED = True
+
+    (exact, n0), (mods, n1), (chain, n2) = run(False, False), run(True, False), run(True, True)
+    assert (n0, n1, n2) == (0, 0, 1)
+    assert exact.keys() == mods.keys() == chain.keys()
+    scale = max(float(v.norm()) for v in exact.values())
+    for n in exact:
+        if n.endswith("fc_k.bias"):
+            continue
+        bf_cost = float((mods[n] - exact[n]).norm())
+        assert float((chain[n] - mods[n]).norm()) < 0.5 * bf_cost + 1e-6 * scale, (n, _rel(chain[n], mods[n]), _rel(mods[n], exact[n]))
