@@ -487,7 +487,8 @@ def main():
                                "SoftmaxRankingLoss reference, OCC/OSC; epoch 50) + bwd + flat grad all-reduce + AdamW",
                        "precision": ("bf16 storage + bf16 MFMA (fp32 accumulate) in the grouped per-ball MLPs; bf16 MFMA operands "
                                      "rounded in registers (fp32 I/O, softmax, statistics, accumulate) in the attention cores, the "
-                                     "plain linear layers and the Conv1d rows stacks; fp32 in the remaining element-wise kernels. "
+                                     "plain linear layers (incl. the decoder stack's row chains, csrc/rows_chain.hip) and the Conv1d rows "
+                                     "stacks; fp32 in the remaining element-wise kernels. "
                                      "NOT the 1e-4 parity configuration: that is --dtype fp32 (exact-fp32 MFMA everywhere)"
                                      if bf else "fp32 everywhere (exact-fp32 MFMA): the 1e-4 parity configuration"),
                        "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd)",
