@@ -2431,7 +2431,11 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
       return VLP3D_EINVAL;
     const int KP = (K + 31) & ~31;
     const int per_wave = (2 * (KP / 32) + 3) / 4;  // output tiles per wave of a 64-column block
-    const int maxt = per_wave <= 1 ? 1 : (per_wave <= 3 ? 3 : (per_wave <= 4 ? 4 : 6));
+    // accumulator buckets 1 / 4 / 6: a job runs in any instantiation with at least its tile count, and every bucket is one more
+    // serialised launch of a few hundred workgroups (with a bucket 3 the K = 128 and K = 256 layers shared nothing: 8 launches
+    // per step instead of 4, 4.42 -> 4.39 ms; all four loader combinations behind ONE launch — a workgroup-uniform branch
+    // over four inlined bodies — was measured too: 4.42 -> 4.43 ms, not kept)
+    const int maxt = per_wave <= 1 ? 1 : (per_wave <= 4 ? 4 : 6);
     key[i] = ((q.a_scale ? 1 : 0) << 8) | ((q.bn5 ? 1 : 0) << 4) | maxt;
     done[i] = false;
   }
