@@ -171,15 +171,20 @@ __global__ __launch_bounds__(1024) void fps_scan_kernel(int *__restrict__ hist) 
     loc[i] = s;
     s += h[i];
   }
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  // inclusive scan of the 1024 thread sums: shuffles inside a wave, the 16 wave totals through LDS (the Hillis-Steele form
+  // over LDS took 20 barriers: 11.9 us for the 8 scenes, in front of the longest dependent chain of the step)
+  const int lane = tid & 63, wave = tid >> 6;
+  int inc = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
   }
-  const int base = part[tid] - s;
+  if (lane == 63) part[wave] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += part[w];
+  const int base = before + inc - s;
 #pragma unroll
   for (int i = 0; i < 32; ++i) h[i] = base + loc[i];
 }
