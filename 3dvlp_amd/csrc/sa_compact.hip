@@ -32,16 +32,20 @@ __global__ __launch_bounds__(256) void sa_cnt_kernel(const int *__restrict__ idx
   cnt[bm] = c;
 }
 
-// in-place exclusive scan of v[0..n) by ONE workgroup; v[n] = total
+// in-place exclusive scan of v[0..n) by ONE workgroup; v[n] = total.  Four consecutive entries per thread and round (16 384
+// balls: 4 rounds instead of 16), shuffle scan inside a wave, every wave scans the 16 wave totals.
 __global__ __launch_bounds__(1024) void sa_scan_kernel(int *__restrict__ v, int n) {
   __shared__ int wtot[16];
   __shared__ int carry_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += 1024) {
-    const int i = c0 + threadIdx.x;
-    const int mine = i < n ? v[i] : 0;
+  for (int c0 = 0; c0 < n; c0 += 4096) {
+    const int i = c0 + 4 * threadIdx.x;
+    int a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = i + k < n ? v[i + k] : 0;
+    const int mine = (a[0] + a[1]) + (a[2] + a[3]);
     int inc = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -57,8 +61,13 @@ __global__ __launch_bounds__(1024) void sa_scan_kernel(int *__restrict__ v, int 
       if (lane >= off) w += t;
     }
     const int before = wave > 0 ? __shfl(w, wave - 1) : 0, all = __shfl(w, 15);
-    if (i < n) v[i] = carry_s + before + inc - mine;
-    __syncthreads();
+    int run = carry_s + before + inc - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < n) v[i + k] = run;
+      run += a[k];
+    }
+    __syncthreads();  // every wave has read carry_s and wtot
     if (threadIdx.x == 0) carry_s += all;
     __syncthreads();
   }
