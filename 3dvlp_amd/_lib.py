@@ -112,6 +112,7 @@ SIGNATURES = {
     "vlp3d_probe_mfma_bf16": [_i, _i, _vp, _vp],
     "vlp3d_probe_fma_f32": [_i, _i, _vp, _vp],
     "vlp3d_fps_pruned_profile": [_vp, _i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp],
+    "vlp3d_fps_pruned_trace": [_vp, _i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _i, _i, _vp],
     "vlp3d_stamp": [_vp, _vp],
     "vlp3d_probe_empty": [_i, _i, _vp, _vp],
     "vlp3d_gather_xyz": [_vp, _vp, _i, _i, _i, _vp, _vp],

@@ -67,6 +67,20 @@ static __device__ __forceinline__ unsigned seed_mix_of(const unsigned long long 
   return pcg_hash((unsigned)s ^ pcg_hash((unsigned)(s >> 32) + 0x9E3779B9u * (unsigned)(call_id + 1)));
 }
 
+// Opt a kernel in to more than 64 KB of dynamic LDS — once per DEVICE (the attribute is per device; a process-wide flag left a
+// second GPU without it: ADVICE r3).  `done` is one word per call site: bit d = device d has the attribute.
+#include <atomic>
+static inline int vlp3d_opt_in_lds(const void *fn, int bytes, std::atomic<unsigned long long> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return VLP3D_EINVAL;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return VLP3D_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return VLP3D_OK;
+}
+
 #define VLP3D_LAUNCH_CHECK()                         \
   do {                                               \
     hipError_t e__ = hipGetLastError();              \

@@ -250,7 +250,8 @@ template <int NS, bool PROF = false>
 __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restrict__ xyz_all, float4 *__restrict__ pts_all,
                                                            const int *__restrict__ perm_all, int *__restrict__ idx_all,
                                                            int N, int m, int log2P, int L, int m_lds,
-                                                           unsigned long long *__restrict__ prof = nullptr) {
+                                                           unsigned long long *__restrict__ prof = nullptr,
+                                                           unsigned *__restrict__ trace = nullptr) {
   // The kernel is one dependent chain per scene on 8 of the 256 CUs while the step's dense kernels fill the chip: waves of
   // those kernels that land on the same SIMDs compete for instruction issue (3.4 ms inside the step against 2.8 ms alone).
   // Highest wave priority: the arbiter serves these waves first; the dense kernels lose nothing measurable.
@@ -341,14 +342,17 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
   __syncthreads();
 
   unsigned long long ph[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tq = 0ull;
+  unsigned tr[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // per-wave trace of one iteration: 5 phase deltas, LDS / global / re-reduced slots
 #define FPS_MARK(k)                                        \
   if (PROF) {                                              \
     const unsigned long long now_ = __builtin_readcyclecounter(); \
     ph[k] += now_ - tq;                                    \
+    tr[k] = (unsigned)(now_ - tq);                         \
     tq = now_;                                             \
   }
   if (PROF) tq = __builtin_readcyclecounter();
   for (int j = 1; j < m; ++j) {
+    if (PROF) tr[5] = tr[6] = tr[7] = 0u;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       const float ex = fmaxf(0.f, fmaxf(blo[q][0] - x1, x1 - bhi[q][0]));
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
           if (u < nb) {  // uniform
             const int pos = si[u] * 1024 + wave * 64 + lane;
             const bool valid = pos < N;
+            if (PROF) tr[si[u] < L ? 5 : 6] += 1u;
             const float d = vlp3d_sumsq3(p[u].x - x1, p[u].y - y1, p[u].z - z1);
             const float t = vmin(d, p[u].w);
             if (si[u] < L) lpts[si[u] * 1024 + tid].w = t;
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
             // not by the latency of a wave's own chain.
             const int wl_old = __builtin_amdgcn_readlane(swl[q], si[u] - 64 * q);
             if (__ballot(lane == wl_old && t < p[u].w) != 0ull) {  // wave-uniform
+              if (PROF) tr[7] += 1u;
               const unsigned v = value_of(t, valid);
               const unsigned vmax = wave_max_u32(v);
               int wl = 0;
@@ -462,11 +468,234 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float *__restric
     }
     par ^= 1;
     FPS_MARK(4)  // block reduction over the 16 wave candidates, next sample's coordinates from LDS
+    if (PROF && trace != nullptr && lane == 0) {
+      uint4 *t4 = reinterpret_cast<uint4 *>(trace + (((size_t)b * m + j) * 16 + wave) * 8);
+      t4[0] = make_uint4(tr[0], tr[1], tr[2], tr[3]);
+      t4[1] = make_uint4(tr[4], tr[5], tr[6], tr[7]);
+    }
   }
 #undef FPS_MARK
   if (PROF && tid == 0)
     for (int k = 0; k < 5; ++k) prof[(size_t)b * 8 + k] = ph[k];
   if (m_lds) {  // sorted position -> original index, all threads
+    __syncthreads();
+    for (int j = 1 + tid; j < m; j += 1024) idx[j] = s_out[j] < 0 ? 0 : perm[s_out[j]];
+  }
+}
+
+// ---- main kernel, round 4: running minima in REGISTERS, read-only coordinates ------------------------------------------------
+// What the round-3 kernel paid for (tools/fps_trace.py, profiles/r04_fps_trace_*.txt): a slot update cost a wave ~740 (LDS
+// slot) / ~930 (L2 slot) cycles + ~410 when the slot was reduced again, and beside a streaming load on the other 248 CUs the
+// kernel ran 1.9x slower although its CU is its own: gfx9 returns vector-memory operations IN ORDER, so the load of a slot's
+// points could not be consumed before the acknowledgement of the temp stores of earlier iterations — microseconds under load.
+// Here the running minimum of every point lives in the register file: lane l of wave w keeps temp of point
+// (slot * 1024 + w * 64 + l) in VGPR 64 + slot (a workgroup of 16 waves owns its CU's whole file anyway: 128 per lane; the
+// compiler is held to v0..v63 by amdgpu_num_vgpr, v64..v127 are addressed with s_set_gpr_idx by the wave-uniform slot number —
+// hipcc's own dynamic indexing of a 32-wide vector copies the whole vector at every control-flow join).  The loop issues NO
+// store (the sample list stays in LDS), the coordinates are read-only: the first L slots of every wave from LDS as three
+// dword arrays (12 KB per slot: 12 instead of 9 slots), the others from L2, a slot ahead of its use.  The update loop handles
+// one slot per trip (the four-at-a-time form compiled to a dozen scalar branches per slot), and a wave whose slot maxima did
+// not change re-publishes its cached candidate instead of reducing 64 lanes again.
+__device__ __forceinline__ float fps_treg_read(int slot) {  // slot is wave-uniform, 0..63 (gfx9 has no v_movrel)
+  float r;
+  asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\ts_set_gpr_idx_off" : "=v"(r) : "s"(slot));
+  return r;
+}
+__device__ __forceinline__ void fps_treg_write(int slot, float v) {
+  asm volatile("s_set_gpr_idx_on %1, gpr_idx(DST)\n\tv_mov_b32 v64, %0\n\ts_set_gpr_idx_off" ::"v"(v), "s"(slot));
+}
+
+// ABL (timing experiments of tools/fps_trace.py only; the outputs are then NOT the sampling): 1 = no slot is ever updated,
+// 2 = a slot is never reduced again, 4 = the wave candidate is reduced every iteration
+template <bool PROF, int ABL = 0>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(64))) void fps_pruned_reg_kernel(
+    const float *__restrict__ xyz_all, const float4 *__restrict__ pts_all, const int *__restrict__ perm_all,
+    int *__restrict__ idx_all, int N, int m, int log2P, int L, int m_lds, unsigned *__restrict__ trace) {
+  __builtin_amdgcn_s_setprio(3);
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");  // the kernel descriptor claims 128 VGPRs: v64..v127 hold the running minima
+  extern __shared__ float lxyz[];  // x[L][1024], y[L][1024], z[L][1024]; then int s_out[m_lds]
+  int *s_out = reinterpret_cast<int *>(lxyz + (size_t)3 * L * 1024);
+  __shared__ uint2 s_vp[2][16];
+  __shared__ float4 s_xyz4[2][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const float *__restrict__ xyz = xyz_all + (size_t)b * N * 3;
+  const float4 *__restrict__ pts = pts_all + (size_t)b * N;
+  const int *__restrict__ perm = perm_all + (size_t)b * N;
+  int *__restrict__ idx = idx_all + (size_t)b * m;
+  const int nslots = (N + 1023) / 1024;  // <= 64: lane i of a wave holds the state of the wave's slot i
+  const unsigned Pm1 = (1u << log2P) - 1u;
+  const int lstride = L * 1024;
+  auto tiekey = [&](int orig) -> unsigned {
+    const unsigned k = (unsigned)orig;
+    return 0xFFFFFFFFu - (__brev(k & Pm1) | (k >> log2P));
+  };
+  auto value_of = [](float t) -> unsigned { return t >= 0.f ? __float_as_uint(t) + 1u : 0u; };  // absent points carry -1
+  auto winner_lane = [&](unsigned v, unsigned vmax, int pos) -> int {
+    const unsigned long long w = __ballot(v == vmax);
+    if (__popcll(w) == 1) return __builtin_ctzll(w);
+    const unsigned tk = (v == vmax) ? tiekey(perm[pos]) : 0u;  // exact tie: the reference's order decides
+    const unsigned tmax = wave_max_u32(tk);
+    return __builtin_ctzll(__ballot(v == vmax && tk == tmax));
+  };
+
+  float blo0 = 0.f, blo1 = 0.f, blo2 = 0.f, bhi0 = 0.f, bhi1 = 0.f, bhi2 = 0.f;
+  unsigned sval = 0u;
+  int swl = 0;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int i = 0; i < 64; ++i) {
+    if (i >= nslots) {  // uniform
+      fps_treg_write(i, -1.f);
+      continue;
+    }
+    const int pos = i * 1024 + wave * 64 + lane;
+    const bool valid = pos < N;
+    float4 p = pts[valid ? pos : N - 1];
+    if (!valid) p.w = -1.f;
+    fps_treg_write(i, p.w);
+    if (i < L) {
+      lxyz[i * 1024 + tid] = p.x;
+      lxyz[lstride + i * 1024 + tid] = p.y;
+      lxyz[2 * lstride + i * 1024 + tid] = p.z;
+    }
+    const float lo0 = wave_minmax_f32<false>(valid ? p.x : 3.0e38f), hi0 = wave_minmax_f32<true>(valid ? p.x : -3.0e38f);
+    const float lo1 = wave_minmax_f32<false>(valid ? p.y : 3.0e38f), hi1 = wave_minmax_f32<true>(valid ? p.y : -3.0e38f);
+    const float lo2 = wave_minmax_f32<false>(valid ? p.z : 3.0e38f), hi2 = wave_minmax_f32<true>(valid ? p.z : -3.0e38f);
+    const unsigned v = value_of(p.w);
+    const unsigned vmax = wave_max_u32(v);
+    int wl = 0;
+    if (vmax != 0u) wl = winner_lane(v, vmax, valid ? pos : N - 1);
+    const float wx = readlane_f32(p.x, wl), wy = readlane_f32(p.y, wl), wz = readlane_f32(p.z, wl);
+    if (lane == i) {
+      blo0 = lo0; blo1 = lo1; blo2 = lo2; bhi0 = hi0; bhi1 = hi1; bhi2 = hi2;
+      sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz;
+    }
+  }
+  if (tid == 0) idx[0] = 0;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  int par = 0;
+  __syncthreads();
+
+  unsigned tr[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned long long tq = 0ull;
+#define FPS_MARK(k)                                               \
+  if (PROF) {                                                     \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tr[k] = (unsigned)(now_ - tq);                                \
+    tq = now_;                                                    \
+  }
+  if (PROF) tq = __builtin_readcyclecounter();
+  // the wave's candidate, cached across iterations: value, sorted position, coordinates (all wave-uniform)
+  unsigned c_v = 0u, c_pos = 0u;
+  float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+  int c_slot = 0;
+  bool changed = true;
+  const int lane_off = wave * 64 + lane;
+  for (int j = 1; j < m; ++j) {
+    if (PROF) tr[5] = tr[6] = tr[7] = 0u;
+    const float ex = fmaxf(0.f, fmaxf(blo0 - x1, x1 - bhi0));
+    const float ey = fmaxf(0.f, fmaxf(blo1 - y1, y1 - bhi1));
+    const float ez = fmaxf(0.f, fmaxf(blo2 - z1, z1 - bhi2));
+    const float lb2 = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
+    const bool active = (lane < nslots) && (sval != 0u) && (lb2 < __uint_as_float(sval - 1u));
+    unsigned long long todo = __ballot(active);
+    FPS_MARK(0)
+    if ((ABL & 1) == 0 && todo != 0ull) {  // wave-uniform
+      auto fetch = [&](int slot, float &px, float &py, float &pz) {
+        if (slot < L) {  // uniform
+          const int a = slot * 1024 + tid;
+          px = lxyz[a]; py = lxyz[lstride + a]; pz = lxyz[2 * lstride + a];
+        } else {
+          const int pos = slot * 1024 + lane_off;
+          const float4 g = pts[pos < N ? pos : N - 1];
+          px = g.x; py = g.y; pz = g.z;
+        }
+      };
+      int cur = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      float px, py, pz;
+      fetch(cur, px, py, pz);
+      for (;;) {
+        int nxt = -1;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (todo != 0ull) {  // uniform: the next slot's coordinates are requested before this slot is worked on
+          nxt = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          fetch(nxt, qx, qy, qz);
+        }
+        if (PROF) tr[cur < L ? 5 : 6] += 1u;
+        const float told = fps_treg_read(cur);
+        const float d = vlp3d_sumsq3(px - x1, py - y1, pz - z1);
+        const float t = vmin(d, told);
+        fps_treg_write(cur, t);
+        // the slot's cached maximum stays valid unless the point that HOLDS it moved (values only decrease)
+        const int wl_old = __builtin_amdgcn_readlane(swl, cur);
+        if ((ABL & 2) == 0 && __ballot(lane == wl_old && t < told) != 0ull) {  // wave-uniform
+          if (PROF) tr[7] += 1u;
+          const unsigned v = value_of(t);
+          const unsigned vmax = wave_max_u32(v);
+          int wl = 0;
+          if (vmax != 0u) wl = winner_lane(v, vmax, min(cur * 1024 + lane_off, N - 1));
+          const float wx = readlane_f32(px, wl), wy = readlane_f32(py, wl), wz = readlane_f32(pz, wl);
+          if (lane == cur) { sval = vmax; swl = wl; sx = wx; sy = wy; sz = wz; }
+          // the wave's candidate can only change when the slot that HOLDS it was reduced again: another slot's new maximum is
+          // <= its old one, and among equal values the old candidate already preceded every point of that slot in the
+          // reference's order (it preceded the slot's old holder, which preceded the slot's other points)
+          if (cur == c_slot) changed = true;
+        }
+        if (nxt < 0) break;
+        cur = nxt; px = qx; py = qy; pz = qz;
+      }
+    }
+    FPS_MARK(1)
+    if (changed || (ABL & 4)) {  // wave-uniform: the maximum of the candidate's slot changed (or first iteration)
+      const unsigned mine = lane < nslots ? sval : 0u;
+      c_v = wave_max_u32(mine);
+      int cl = 0;
+      if (c_v != 0u) cl = winner_lane(mine, c_v, min(lane * 1024 + wave * 64 + swl, N - 1));
+      c_slot = cl;
+      c_pos = (unsigned)(cl * 1024 + wave * 64 + __builtin_amdgcn_readlane(swl, cl));
+      c_x = readlane_f32(sx, cl); c_y = readlane_f32(sy, cl); c_z = readlane_f32(sz, cl);
+      changed = false;
+    }
+    FPS_MARK(2)
+    if (lane == 0) {
+      s_vp[par][wave] = make_uint2(c_v, c_pos);
+      s_xyz4[par][wave] = make_float4(c_x, c_y, c_z, 0.f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FPS_MARK(3)
+    const uint2 vp = s_vp[par][lane & 15];
+    const float4 cxyz = s_xyz4[par][lane & 15];
+    const unsigned bv = lane < 16 ? vp.x : 0u;
+    const unsigned bpos = lane < 16 ? vp.y : 0u;
+    const unsigned bmax = row0_max_u32(bv);
+    if (bmax != 0u) {
+      const int wi = winner_lane(bv, bmax, (int)min(bpos, (unsigned)(N - 1)));
+      x1 = readlane_f32(cxyz.x, wi); y1 = readlane_f32(cxyz.y, wi); z1 = readlane_f32(cxyz.z, wi);
+      if (tid == 0) {
+        const unsigned wpos = (unsigned)__builtin_amdgcn_readlane((int)vp.y, wi);
+        if (m_lds) s_out[j] = (int)wpos;
+        else idx[j] = perm[wpos];
+      }
+    } else {  // no candidate left (every point skipped): the reference returns index 0
+      x1 = xyz[0]; y1 = xyz[1]; z1 = xyz[2];
+      if (tid == 0) {
+        if (m_lds) s_out[j] = -1;
+        else idx[j] = 0;
+      }
+    }
+    par ^= 1;
+    FPS_MARK(4)
+    if (PROF && trace != nullptr && lane == 0) {
+      uint4 *t4 = reinterpret_cast<uint4 *>(trace + (((size_t)b * m + j) * 16 + wave) * 8);
+      t4[0] = make_uint4(tr[0], tr[1], tr[2], tr[3]);
+      t4[1] = make_uint4(tr[4], tr[5], tr[6], tr[7]);
+    }
+  }
+#undef FPS_MARK
+  if (m_lds) {
     __syncthreads();
     for (int j = 1 + tid; j < m; j += 1024) idx[j] = s_out[j] < 0 ? 0 : perm[s_out[j]];
   }
@@ -492,8 +721,10 @@ extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
 // Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
 // Requires N <= 131072 (64 slots per wave and lane-slot; two lane-slots above 65536); same output as
 // vlp3d_furthest_point_sampling.
+// variant: 0 = the register-resident kernel (N <= 65536; round 4), 1 = the round-3 kernel (temps in LDS / L2; always above 65536)
 static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
-                             unsigned long long *prof, void *stream);
+                             unsigned long long *prof, void *stream, unsigned *trace = nullptr, int lds_slots = -1,
+                             int variant = 0);
 
 extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int N, int m, void *workspace,
                                                     long long workspace_bytes, int *idx, void *stream) {
@@ -506,11 +737,23 @@ extern "C" int vlp3d_furthest_point_sampling_pruned(const float *xyz, int B, int
 extern "C" int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes,
                                         int *idx, unsigned long long *phases, void *stream) {
   if (!phases || N > 65536) return VLP3D_EINVAL;
-  return fps_pruned_launch(xyz, B, N, m, workspace, workspace_bytes, idx, phases, stream);
+  return fps_pruned_launch(xyz, B, N, m, workspace, workspace_bytes, idx, phases, stream, nullptr, -1, 1);  // round-3 kernel
+}
+
+// Diagnostic form (tools/fps_trace.py): variant 0 = register-resident kernel, 1 = round-3 kernel; lds_slots >= 0 overrides
+// the number of slots per wave whose points live in LDS (0..12 / 0..9); with `phases` the profiling instantiation runs (variant
+// 0 fills `phases` only through `trace`) and, when `trace` is given too, lane 0 of every wave writes 8 words per iteration — trace[((b*m + j)*16 + wave)*8 + k]: shader-clock cycles of the five phases, then the number of LDS-resident /
+// L2-resident slots the wave updated and how many of them were reduced again.  N <= 65536 with phases.
+extern "C" int vlp3d_fps_pruned_trace(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes,
+                                      int *idx, unsigned long long *phases, unsigned *trace, int lds_slots, int variant,
+                                      void *stream) {
+  if ((phases && N > 65536) || (trace && !phases) || lds_slots > 12 || variant < 0 || (variant > 1 && variant < 16) || (variant != 1 && N > 65536))
+    return VLP3D_EINVAL;
+  return fps_pruned_launch(xyz, B, N, m, workspace, workspace_bytes, idx, phases, stream, trace, lds_slots, variant);
 }
 
 static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
-                             unsigned long long *prof, void *stream) {
+                             unsigned long long *prof, void *stream, unsigned *trace, int lds_slots, int variant) {
   if (!xyz || !workspace || !idx || B < 1 || N < 1 || N > 131072 || m < 0 ||
       workspace_bytes < vlp3d_fps_workspace_bytes(B, N))
     return VLP3D_EINVAL;
@@ -532,29 +775,65 @@ static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *worksp
   hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
   hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
   const int nslots = (N + 1023) / 1024;
-  const int L = nslots < 9 ? nslots : 9;  // 9 x 16 KB of the 160 KB LDS hold slots 0..8 of every wave
   const int m_lds = m <= 2048 ? m : 0;  // the sample list is collected in LDS (8 KB) and written out at the end
-  const size_t lds = (size_t)L * 1024 * sizeof(float4) + (size_t)m_lds * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int max_lds = 9 * 1024 * (int)sizeof(float4) + 2048 * (int)sizeof(int);
-    hipError_t e = hipFuncSetAttribute((const void *)fps_pruned_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)fps_pruned_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)fps_pruned_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  const int log2P = reference_log2_block(N);
+  if (nslots > 64 && variant == 0) variant = 1;
+  if (variant == 0) {
+    int L = nslots < 12 ? nslots : 12;  // 12 x 12 KB of the 160 KB LDS hold the coordinates of slots 0..11 of every wave
+    if (lds_slots >= 0 && lds_slots < L) L = lds_slots;
+    const size_t lds = (size_t)L * 1024 * 12 + (size_t)m_lds * sizeof(int);
+    const int max_lds = 12 * 1024 * 12 + 2048 * (int)sizeof(int);
+    static std::atomic<unsigned long long> done_p{0}, done_r{0};
+    const int e = prof ? vlp3d_opt_in_lds((const void *)fps_pruned_reg_kernel<true>, max_lds, done_p)
+                       : vlp3d_opt_in_lds((const void *)fps_pruned_reg_kernel<false>, max_lds, done_r);
+    if (e != VLP3D_OK) return e;
+    if (prof)
+      hipLaunchKernelGGL(fps_pruned_reg_kernel<true>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds, trace);
+    else
+      hipLaunchKernelGGL(fps_pruned_reg_kernel<false>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds,
+                         (unsigned *)nullptr);
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
   }
+  if (variant >= 16) {  // timing experiments (tools/fps_trace.py): the kernel with a part of its iteration left out
+    if (nslots > 64 || prof) return VLP3D_EINVAL;
+    const int L = nslots < 12 ? nslots : 12;
+    const size_t lds = (size_t)L * 1024 * 12 + (size_t)m_lds * sizeof(int);
+    const int max_lds = 12 * 1024 * 12 + 2048 * (int)sizeof(int);
+    static std::atomic<unsigned long long> d1{0}, d2{0}, d4{0};
+#define FPS_ABL(A, D)                                                                                                          \
+  case 16 + A: {                                                                                                               \
+    const int e = vlp3d_opt_in_lds((const void *)fps_pruned_reg_kernel<false, A>, max_lds, D);                                 \
+    if (e != VLP3D_OK) return e;                                                                                               \
+    hipLaunchKernelGGL((fps_pruned_reg_kernel<false, A>), dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds, \
+                       (unsigned *)nullptr);                                                                                   \
+  } break;
+    switch (variant) {
+      FPS_ABL(1, d1)
+      FPS_ABL(2, d2)
+      FPS_ABL(4, d4)
+      default: return VLP3D_EINVAL;
+    }
+#undef FPS_ABL
+    VLP3D_LAUNCH_CHECK();
+    return VLP3D_OK;
+  }
+  int L = nslots < 9 ? nslots : 9;  // 9 x 16 KB of the 160 KB LDS hold slots 0..8 of every wave
+  if (lds_slots >= 0 && lds_slots < L) L = lds_slots;
+  const size_t lds = (size_t)L * 1024 * sizeof(float4) + (size_t)m_lds * sizeof(int);
+  const int max_lds = 9 * 1024 * (int)sizeof(float4) + 2048 * (int)sizeof(int);
+  static std::atomic<unsigned long long> done1{0}, done2{0}, done1p{0};
+  int e = vlp3d_opt_in_lds((const void *)fps_pruned_kernel<1>, max_lds, done1);
+  if (e == VLP3D_OK) e = vlp3d_opt_in_lds((const void *)fps_pruned_kernel<2>, max_lds, done2);
+  if (e == VLP3D_OK) e = vlp3d_opt_in_lds((const void *)fps_pruned_kernel<1, true>, max_lds, done1p);
+  if (e != VLP3D_OK) return e;
   if (prof)
-    hipLaunchKernelGGL((fps_pruned_kernel<1, true>), dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N),
-                       L, m_lds, prof);
+    hipLaunchKernelGGL((fps_pruned_kernel<1, true>), dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds, prof,
+                       trace);
   else if (nslots <= 64)
-    hipLaunchKernelGGL(fps_pruned_kernel<1>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N), L,
-                       m_lds);
+    hipLaunchKernelGGL(fps_pruned_kernel<1>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds);
   else
-    hipLaunchKernelGGL(fps_pruned_kernel<2>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, reference_log2_block(N), L,
-                       m_lds);
+    hipLaunchKernelGGL(fps_pruned_kernel<2>, dim3(B), dim3(1024), lds, s, xyz, pts, perm, idx, N, m, log2P, L, m_lds);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

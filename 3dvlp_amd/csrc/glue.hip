@@ -695,13 +695,9 @@ extern "C" int vlp3d_smallk_bwd(const float *dy, const float *x, int ldx, long l
   const size_t lds = (size_t)64 * N * sizeof(float);  // + 8 KB static: above 64 KB per workgroup at N = 256
   if (lds > 96 * 1024) return VLP3D_EINVAL;
   if (lds + 64 * SMALLK_KP * sizeof(float) > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(smallk_bwd_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static std::atomic<unsigned long long> done{0};
+    const int e = vlp3d_opt_in_lds(reinterpret_cast<const void *>(smallk_bwd_kernel), 96 * 1024, done);
+    if (e != VLP3D_OK) return e;
   }
   hipLaunchKernelGGL(smallk_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), lds, (hipStream_t)stream, dy, x, ldx, R, K, N,
                      slabs);

@@ -502,15 +502,10 @@ extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_s
     a.st[s] = S;
   }
   static const int tr = getenv("VLP3D_CHAIN_TILE_ROWS") ? atoi(getenv("VLP3D_CHAIN_TILE_ROWS")) : 32;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(rows_chain_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds_bytes(64)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(rows_chain_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds_bytes(32)) != hipSuccess)
-      return VLP3D_EINVAL;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done64{0}, done32{0};
+  if (vlp3d_opt_in_lds(reinterpret_cast<const void *>(rows_chain_kernel<64>), lds_bytes(64), done64) != VLP3D_OK ||
+      vlp3d_opt_in_lds(reinterpret_cast<const void *>(rows_chain_kernel<32>), lds_bytes(32), done32) != VLP3D_OK)
+    return VLP3D_EINVAL;
   if (tr == 64)
     hipLaunchKernelGGL(rows_chain_kernel<64>, dim3((unsigned)((R + 63) / 64)), dim3(256), lds_bytes(64), (hipStream_t)stream, a);
   else
@@ -550,13 +545,8 @@ extern "C" int vlp3d_rows_chain_bwd(const float *G, long long R, const vlp3d_cha
     if (R * (long long)N >= (1ll << 32)) return VLP3D_EINVAL;
     a.pt[j] = P;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(rows_chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            BWD_LDS) != hipSuccess)
-      return VLP3D_EINVAL;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  if (vlp3d_opt_in_lds(reinterpret_cast<const void *>(rows_chain_bwd_kernel), BWD_LDS, done) != VLP3D_OK) return VLP3D_EINVAL;
   hipLaunchKernelGGL(rows_chain_bwd_kernel, dim3((unsigned)((R + BT - 1) / BT)), dim3(256), BWD_LDS, (hipStream_t)stream, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

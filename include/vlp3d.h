@@ -529,10 +529,17 @@ int vlp3d_probe_mfma_bf16(int iters, int blocks, float *sink, void *stream);
 int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
 /* vlp3d_stamp: one thread writes the 100 MHz device clock to *slot (in-stream time stamps bracketing a kernel inside a
  * captured step); vlp3d_probe_empty: a kernel that does nothing on a (blocks, threads) grid — the launch floor. */
-/* vlp3d_fps_pruned_profile: vlp3d_furthest_point_sampling_pruned + per-phase shader-clock counts of the main kernel's
+/* vlp3d_fps_pruned_profile: the ROUND-3 pruned kernel + per-phase shader-clock counts of its
  * iteration (phases: (B, 8) u64, entries 0..4: slot test | slot updates | wave candidate | LDS + barrier | block reduction). */
 int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
                              unsigned long long *phases, void *stream);
+/* vlp3d_fps_pruned_trace: diagnostic form.  variant 0 = the register-resident kernel (round 4, N <= 65536), 1 = the round-3
+ * kernel (running minima in LDS / L2); lds_slots >= 0 overrides the number of slots per wave whose points live in LDS
+ * (0..12 / 0..9); with `phases` (any non-null pointer for variant 0) the profiling instantiation runs; with `trace` too (u32,
+ * B*m*16*8 words) lane 0 of every wave writes per iteration j: trace[((b*m + j)*16 + wave)*8 + k] = cycles of the five
+ * phases, then LDS-resident / L2-resident slots updated and slots reduced again (tools/fps_trace.py). */
+int vlp3d_fps_pruned_trace(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
+                           unsigned long long *phases, unsigned *trace, int lds_slots, int variant, void *stream);
 int vlp3d_stamp(unsigned long long *slot, void *stream);
 int vlp3d_probe_empty(int blocks, int threads, int *sink, void *stream);
 
