@@ -143,6 +143,64 @@ SIGNATURES = {
 
 _lib = None
 
+# ---- fp32 evaluation order of the index-producing ops (include/vlp3d.h vlp3d_fp_contract) --------------
+# The main library evaluates a*a + b*b + c*c as fma(c,c, fma(a,a, b*b)) (mode 1: what LLVM's NVPTX back end makes of the
+# reference's expression under nvcc's default -fmad=true).  Whether the reference build really emits that form cannot be
+# checked in this image, so the geometry ops also exist in the two other orders (libvlp3d_geom_c0.so: no contraction;
+# libvlp3d_geom_c2.so: the left chain fma(c,c, fma(b,b, a*a))).  set_fp_contract(mode) — or VLP3D_FP_CONTRACT=0|1|2 in the
+# environment at import — routes the nine `_ext` functions, the pruned / prefix FPS forms, the grid ball query and three_nn
+# through the matching library; everything else (the fused layers) is independent of the mode.
+GEOM_ENTRY_POINTS = (
+    "vlp3d_abi_version", "vlp3d_fp_contract", "vlp3d_furthest_point_sampling", "vlp3d_fps_prefix_check",
+    "vlp3d_furthest_point_sampling_cond", "vlp3d_fps_workspace_bytes", "vlp3d_furthest_point_sampling_pruned",
+    "vlp3d_fps_pruned_profile", "vlp3d_fps_pruned_trace", "vlp3d_ball_query", "vlp3d_ball_query_grid_workspace_bytes",
+    "vlp3d_ball_query_grid", "vlp3d_three_nn", "vlp3d_three_interpolate", "vlp3d_three_interpolate_grad", "vlp3d_gather_xyz",
+    "vlp3d_gather_xyz_grad", "vlp3d_three_nn_weights", "vlp3d_gather_points", "vlp3d_gather_points_grad", "vlp3d_group_points",
+    "vlp3d_group_points_grad")
+_geom_libs = {}
+_contract = None   # None = the main library's own mode
+
+
+def _geom_path(mode):
+    return os.path.join(_HERE, "csrc", "libvlp3d_geom_c%d.so" % mode)
+
+
+def set_fp_contract(mode):
+    """Select the fp32 evaluation order of the geometry ops: 0, 1 or 2 (None = the main library's, i.e. 1).  Returns the
+    previous setting.  Fails loudly when the variant library has not been built (python 3dvlp_amd/build.py)."""
+    global _contract
+    prev = _contract
+    if mode is not None:
+        mode = int(mode)
+        if mode not in (0, 1, 2):
+            raise ValueError("fp contract mode must be 0, 1 or 2")
+        if mode == load().vlp3d_fp_contract():
+            mode = None
+        elif mode not in _geom_libs:
+            path = _geom_path(mode)
+            if not os.path.exists(path):
+                raise ImportError("%s not found — build it with `python 3dvlp_amd/build.py`" % path)
+            lib = ctypes.CDLL(path)
+            for name in GEOM_ENTRY_POINTS:
+                fn = getattr(lib, name)
+                fn.argtypes = SIGNATURES[name]
+                fn.restype = ctypes.c_longlong if name.endswith(("_bytes", "_sums", "_rows")) else ctypes.c_int
+            if lib.vlp3d_fp_contract() != mode:
+                raise ImportError("%s reports fp contract mode %d" % (path, lib.vlp3d_fp_contract()))
+            _geom_libs[mode] = lib
+    _contract = mode
+    return prev
+
+
+def fp_contract():
+    """The mode the geometry ops currently run in (0 / 1 / 2)."""
+    return load().vlp3d_fp_contract() if _contract is None else _contract
+
+
+def _geom():
+    """The library that serves the geometry entry points under the current fp contract mode."""
+    return load() if _contract is None else _geom_libs[_contract]
+
 
 def load():
     """Load the library (once). Raises ImportError with build instructions when it is missing."""
@@ -158,6 +216,9 @@ def load():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name.endswith(("_bytes", "_sums", "_rows")) else ctypes.c_int
         _lib = lib
+        env = os.environ.get("VLP3D_FP_CONTRACT")
+        if env not in (None, ""):
+            set_fp_contract(int(env))
     return _lib
 
 
@@ -225,22 +286,22 @@ def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False,
         flag = torch.empty((1,), dtype=torch.int32, device=points.device)
         tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
         with torch.cuda.device(points.device):
-            _check(load().vlp3d_fps_prefix_check(_p(points), B, N, int(nsamples), _p(v), _p(flag), _stream()),
+            _check(_geom().vlp3d_fps_prefix_check(_p(points), B, N, int(nsamples), _p(v), _p(flag), _stream()),
                    "fps_prefix_check")
-            _check(load().vlp3d_furthest_point_sampling_cond(_p(points), B, N, int(nsamples), _p(tmp), _p(out),
+            _check(_geom().vlp3d_furthest_point_sampling_cond(_p(points), B, N, int(nsamples), _p(tmp), _p(out),
                                                              _p(flag), _stream()), "furthest_point_sampling_cond")
         return (out, flag) if return_flag else out
     if algorithm is None:
         algorithm = "pruned" if FPS_PRUNED_MIN_N <= N <= FPS_PRUNED_MAX_N else "dense"
     with torch.cuda.device(points.device):
         if algorithm == "pruned":
-            nbytes = int(load().vlp3d_fps_workspace_bytes(B, N))
+            nbytes = int(_geom().vlp3d_fps_workspace_bytes(B, N))
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
-            _check(load().vlp3d_furthest_point_sampling_pruned(_p(points), B, N, int(nsamples), _p(ws), nbytes,
+            _check(_geom().vlp3d_furthest_point_sampling_pruned(_p(points), B, N, int(nsamples), _p(ws), nbytes,
                                                                _p(out), _stream()), "furthest_point_sampling_pruned")
         else:
             tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
-            _check(load().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
+            _check(_geom().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
                    "furthest_point_sampling")
     return out
 
@@ -253,7 +314,7 @@ def gather_points(points, idx):
     M = idx.shape[1]
     out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        _check(load().vlp3d_gather_points(_p(points), _p(idx), B, C, N, M, _p(out), _stream()), "gather_points")
+        _check(_geom().vlp3d_gather_points(_p(points), _p(idx), B, C, N, M, _p(out), _stream()), "gather_points")
     return out
 
 
@@ -264,7 +325,7 @@ def gather_points_grad(grad_out, idx, n):
     B, C, M = grad_out.shape
     out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        _check(load().vlp3d_gather_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, _p(out), _stream()),
+        _check(_geom().vlp3d_gather_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, _p(out), _stream()),
                "gather_points_grad")
     return out
 
@@ -284,12 +345,12 @@ def ball_query(new_xyz, xyz, radius, nsample, algorithm=None):
         algorithm = os.environ.get("VLP3D_BALL_QUERY") or ("grid" if N >= BALL_QUERY_GRID_MIN_N else "scan")
     with torch.cuda.device(xyz.device):
         if algorithm == "grid":
-            nbytes = int(load().vlp3d_ball_query_grid_workspace_bytes(B, N))
+            nbytes = int(_geom().vlp3d_ball_query_grid_workspace_bytes(B, N))
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
-            _check(load().vlp3d_ball_query_grid(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(ws), nbytes,
+            _check(_geom().vlp3d_ball_query_grid(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(ws), nbytes,
                                                 _p(idx), _stream()), "ball_query_grid")
         else:
-            _check(load().vlp3d_ball_query(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(idx),
+            _check(_geom().vlp3d_ball_query(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(idx),
                                            _stream()), "ball_query")
     return idx
 
@@ -302,7 +363,7 @@ def group_points(points, idx):
     _, M, S = idx.shape
     out = torch.empty((B, C, M, S), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        _check(load().vlp3d_group_points(_p(points), _p(idx), B, C, N, M, S, _p(out), _stream()), "group_points")
+        _check(_geom().vlp3d_group_points(_p(points), _p(idx), B, C, N, M, S, _p(out), _stream()), "group_points")
     return out
 
 
@@ -313,7 +374,7 @@ def group_points_grad(grad_out, idx, n):
     B, C, M, S = grad_out.shape
     out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        _check(load().vlp3d_group_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, S, _p(out), _stream()),
+        _check(_geom().vlp3d_group_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, S, _p(out), _stream()),
                "group_points_grad")
     return out
 
@@ -327,7 +388,7 @@ def three_nn(unknowns, knows):
     dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
     idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
     with torch.cuda.device(unknowns.device):
-        _check(load().vlp3d_three_nn(_p(unknowns), _p(knows), B, n, m, _p(dist2), _p(idx), _stream()), "three_nn")
+        _check(_geom().vlp3d_three_nn(_p(unknowns), _p(knows), B, n, m, _p(dist2), _p(idx), _stream()), "three_nn")
     return dist2, idx
 
 
@@ -340,7 +401,7 @@ def gather_xyz(xyz, idx):
     M = idx.shape[1]
     out = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _check(load().vlp3d_gather_xyz(_p(xyz), _p(idx), B, N, M, _p(out), _stream()), "gather_xyz")
+        _check(_geom().vlp3d_gather_xyz(_p(xyz), _p(idx), B, N, M, _p(out), _stream()), "gather_xyz")
     return out
 
 
@@ -350,7 +411,7 @@ def gather_xyz_grad(g, idx, N):
     B, M, _ = g.shape
     out = torch.empty((B, int(N), 3), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        _check(load().vlp3d_gather_xyz_grad(_p(g), _p(idx), B, int(N), M, _p(out), _stream()), "gather_xyz_grad")
+        _check(_geom().vlp3d_gather_xyz_grad(_p(g), _p(idx), B, int(N), M, _p(out), _stream()), "gather_xyz_grad")
     return out
 
 
@@ -360,7 +421,7 @@ def three_nn_weights(dist2):
     _chk_dev(dist2)
     w = torch.empty_like(dist2)
     with torch.cuda.device(dist2.device):
-        _check(load().vlp3d_three_nn_weights(_p(dist2), dist2.numel() // 3, _p(w), ctypes.c_void_p(0), _stream()), "three_nn_weights")
+        _check(_geom().vlp3d_three_nn_weights(_p(dist2), dist2.numel() // 3, _p(w), ctypes.c_void_p(0), _stream()), "three_nn_weights")
     return w
 
 
@@ -373,7 +434,7 @@ def three_interpolate(points, idx, weight):
     n = idx.shape[1]
     out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        _check(load().vlp3d_three_interpolate(_p(points), _p(idx), _p(weight), B, C, m, n, _p(out), _stream()),
+        _check(_geom().vlp3d_three_interpolate(_p(points), _p(idx), _p(weight), B, C, m, n, _p(out), _stream()),
                "three_interpolate")
     return out
 
@@ -386,7 +447,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     B, C, n = grad_out.shape
     out = torch.empty((B, C, m), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        _check(load().vlp3d_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, int(m), _p(out),
+        _check(_geom().vlp3d_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, int(m), _p(out),
                                                    _stream()), "three_interpolate_grad")
     return out
 
@@ -433,7 +494,7 @@ def three_interpolate_grad_asshipped(grad_out, idx, weight, m):
                            "(the reference does, too)")
     out = torch.empty((B, C, m), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        _check(load().vlp3d_three_interpolate(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(out), _stream()),
+        _check(_geom().vlp3d_three_interpolate(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(out), _stream()),
                "three_interpolate (as-shipped gradient)")
     return out
 
@@ -880,7 +941,8 @@ def call(name, *args):
     """Raw checked call of a C entry point on torch's current stream (stream appended automatically).
     Tensors are passed as pointers, None as NULL; ints/floats as they are."""
     conv = [(_opt(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
-    _check(getattr(load(), name)(*conv, _stream()), name)
+    lib = _geom() if name in GEOM_ENTRY_POINTS else load()
+    _check(getattr(lib, name)(*conv, _stream()), name)
 
 
 # ---- in-step kernel timing (bench.py: roofline.ms) ---------------------------------------------------------------------

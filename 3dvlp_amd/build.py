@@ -18,14 +18,28 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
     os.environ.get("VLP3D_EXTRA_HIPCC_FLAGS", "").split()  # experiments: e.g. -DVLP3D_GATHER_PREFETCH=1
 
 
+# The index-producing geometry ops (FPS, ball query, three_nn; plus gather / group / interpolate so that the nine `_ext`
+# functions come from ONE library) are also built with the two OTHER fp32 evaluation orders of a*a + b*b + c*c
+# (include/vlp3d.h vlp3d_fp_contract: 0 = no contraction, 2 = left chain; the main library is 1): which form the reference's
+# `nvcc -O2` build emits cannot be checked in this image, so all three exist, are tested against the oracle with the matching
+# `contract`, and `_lib.set_fp_contract(mode)` / VLP3D_FP_CONTRACT selects one at run time.
+GEOM_SOURCES = ["abi.hip", "fps.hip", "fps_pruned.hip", "ball_query.hip", "ball_query_grid.hip", "interpolate.hip",
+                "gather_group.hip"]
+GEOM_MODES = (0, 2)
+
+
+def geom_lib(mode):
+    return os.path.join(CSRC, "libvlp3d_geom_c%d.so" % mode)
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not all(os.path.exists(geom_lib(k)) for k in GEOM_MODES):
         return True
-    t = os.path.getmtime(LIB)
+    t = min([os.path.getmtime(LIB)] + [os.path.getmtime(geom_lib(k)) for k in GEOM_MODES])
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "vlp3d.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
@@ -39,10 +53,20 @@ def build(force=False, verbose=True):
         obj = src[:-4] + ".o"
         objs.append(obj)
         procs.append((src, subprocess.Popen([HIPCC] + FLAGS + ["-c", src, "-o", obj])))
+    # the geometry variants: the same sources with -DVLP3D_CONTRACT=k, objects kept apart (name.c<k>.o)
+    vobjs = {k: [] for k in GEOM_MODES}
+    for k in GEOM_MODES:
+        for name in GEOM_SOURCES:
+            src = os.path.join(CSRC, name)
+            obj = src[:-4] + ".c%d.o" % k
+            vobjs[k].append(obj)
+            procs.append((src, subprocess.Popen([HIPCC] + FLAGS + ["-DVLP3D_CONTRACT=%d" % k, "-c", src, "-o", obj])))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for k in GEOM_MODES:
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", geom_lib(k)] + vobjs[k])
     if verbose:
         print("built", LIB)
     return LIB

@@ -33,10 +33,12 @@ class Prefetcher:
     """Iterates `loader` (an iterable of dicts of numpy arrays / CPU tensors / plain Python values), keeping ONE batch in
     flight on a copy stream.  `prepare(batch_dict_on_device) -> batch_dict` runs on that stream after the upload."""
 
-    def __init__(self, loader, device="cuda", prepare=None):
+    def __init__(self, loader, device="cuda", prepare=None, stream=None):
         self.loader = iter(loader)
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        # (stream: reuse a copy stream created earlier — every new HIP stream takes one of the few hardware queues, and a
+        # stream created late in a process can land on the queue of the step's main or side stream and serialise with it)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
         self.prepare = prepare
         self._pinned = [{}, {}]  # two sets of staging buffers: the copy of batch t+1 may still read its set while t+2 is staged
         self._uploaded = [None, None]  # per set: event recorded after its H2D copies; waited for before the set is overwritten

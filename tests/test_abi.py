@@ -39,6 +39,28 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.vlp3d_fp_contract() in (0, 1, 2)
 
 
+def test_geometry_variant_libraries_export_the_geometry_entry_points(built):
+    """libvlp3d_geom_c0.so / _c2.so (build.py: the geometry sources under the two other fp32 evaluation orders) export every
+    entry point _lib routes through them and report their mode; set_fp_contract switches and restores."""
+    build = importlib.import_module("3dvlp_amd.build")
+    _lib = importlib.import_module("3dvlp_amd._lib")
+    for mode in build.GEOM_MODES:
+        lib = ctypes.CDLL(build.geom_lib(mode))
+        for name in _lib.GEOM_ENTRY_POINTS:
+            assert hasattr(lib, name), (mode, name)
+        assert lib.vlp3d_fp_contract() == mode
+        assert lib.vlp3d_three_nn(None, None, 0, 1, 1, None, None, None) == -22
+    assert _lib.fp_contract() == 1
+    prev = _lib.set_fp_contract(2)
+    try:
+        assert _lib.fp_contract() == 2 and _lib._geom() is not _lib.load()
+        with pytest.raises(ValueError):
+            _lib.set_fp_contract(3)
+    finally:
+        _lib.set_fp_contract(prev)
+    assert _lib.fp_contract() == 1 and _lib._geom() is _lib.load()
+
+
 def test_binding_table_matches_header(built):
     _lib = importlib.import_module("3dvlp_amd._lib")
     assert sorted(_lib.SIGNATURES) == _declared()

@@ -32,6 +32,74 @@ def scene(rng, B, N):
 
 def test_fp_contract_matches_oracle_default(ext):
     assert ext.load().vlp3d_fp_contract() == orc.DEFAULT_CONTRACT
+    assert ext.fp_contract() == orc.DEFAULT_CONTRACT
+
+
+@pytest.fixture
+def contract_mode(ext, request):
+    """Runs the test body with the geometry ops in fp contract mode request.param, restoring the default afterwards."""
+    prev = ext.set_fp_contract(request.param)
+    yield request.param
+    ext.set_fp_contract(prev)
+
+
+def _lattice(rng, n_side, spacing=0.1, origin=0.35):
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    return (origin + g * spacing)[rng.permutation(n_side ** 3)].astype(np.float32)
+
+
+@pytest.mark.parametrize("contract_mode", [0, 1, 2], indirect=True)
+def test_contract_vectors_file_all_modes(ext, contract_mode):
+    """tests/golden/contract_vectors.npz (oracle indices under the three fp32 evaluation orders; the point sets are chosen
+    so that the orders disagree): the HIP library in mode k reproduces the file's mode-k indices, entry for entry."""
+    import os
+    V = np.load(os.path.join(os.path.dirname(__file__), "golden", "contract_vectors.npz"))
+    assert ext.fp_contract() == contract_mode
+    for name in sorted({k.split("/")[0] for k in V.files}):
+        want = V[f"{name}/idx_mode{contract_mode}"]
+        if name.startswith("fps"):
+            t = dev(V[name + "/xyz"])
+            got = ext.furthest_point_sampling(t, int(V[name + "/npoint"])).cpu().numpy()
+        elif name.startswith("bq"):
+            a = (dev(V[name + "/new_xyz"]), dev(V[name + "/xyz"]), float(V[name + "/radius"]), int(V[name + "/nsample"]))
+            got = ext.ball_query(*a, algorithm="scan").cpu().numpy()
+        else:
+            got = ext.three_nn(dev(V[name + "/unknown"]), dev(V[name + "/known"]))[1].cpu().numpy()
+        assert (got == want).all(), (name, contract_mode, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("contract_mode", [0, 1, 2], indirect=True)
+def test_geometry_ops_all_contract_modes_vs_oracle(ext, contract_mode):
+    """Every kernel form of the index-producing ops (dense / four-wave / pruned / prefix-proof FPS, scan / grid ball query,
+    three_nn) in fp contract mode k against the oracle with contract=k, on lattices whose exact and near ties the three
+    evaluation orders resolve differently, plus a bench-like scene."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    k = contract_mode
+    rng = np.random.default_rng(77 + k)
+    lat_small = np.stack([_lattice(rng, 10), _lattice(rng, 10, origin=-0.45)])            # 1000 points: four-wave kernel
+    lat_mid = np.stack([_lattice(rng, 16)])                                                # 4096 points: dense kernel
+    lat_big = np.stack([_lattice(rng, 22, 0.1, -1.05)])                                    # 10 648 points: pruned kernel
+    scene_ = np.stack([synth.make_scene(3000 + i, 20000)["xyz"] for i in range(2)])
+    for xyz, m, algo in ((lat_small, 400, None), (lat_mid, 700, "dense"), (lat_big, 500, "pruned"), (lat_big, 500, "dense"),
+                         (scene_, 1024, "pruned")):
+        got = ext.furthest_point_sampling(dev(xyz), m, algo).cpu().numpy()
+        assert (got == orc.furthest_point_sampling(xyz, m, contract=k)).all(), ("fps", xyz.shape, algo, k)
+    # FPS of an FPS-ordered level: the proof kernels evaluate the same expression
+    inds = orc.furthest_point_sampling(scene_, 2048, contract=k)
+    lvl = np.take_along_axis(scene_, inds[..., None].astype(np.int64), 1)
+    got, flag = ext.furthest_point_sampling(dev(lvl), 1024, prefix_hint=True, return_flag=True)
+    assert (got.cpu().numpy() == orc.furthest_point_sampling(lvl, 1024, contract=k)).all()
+    for new_xyz, xyz, r, ns in ((lat_mid[:, :200].copy(), lat_mid, 0.3, 16), (lat_big[:, :300].copy(), lat_big, 0.2, 32),
+                                (lvl[:, :512].copy(), scene_, 0.2, 64)):
+        want = orc.ball_query(new_xyz, xyz, r, ns, contract=k)
+        for algo in ("scan", "grid"):
+            got = ext.ball_query(dev(new_xyz), dev(xyz), r, ns, algorithm=algo).cpu().numpy()
+            assert (got == want).all(), ("ball_query", algo, xyz.shape, k)
+    known = lat_small[:1]
+    unknown = (known[:, :500] + np.float32(0.05)).astype(np.float32)
+    d2, idx = ext.three_nn(dev(unknown), dev(known))
+    wd2, widx = orc.three_nn(unknown, known, contract=k)
+    assert (idx.cpu().numpy() == widx).all() and (d2.cpu().numpy() == wd2).all()
 
 
 @pytest.mark.parametrize("B,N,m", [(2, 1, 1), (2, 3, 3), (3, 64, 64), (2, 700, 128), (2, 1024, 512), (2, 2048, 1024),

@@ -83,3 +83,26 @@ def test_nce_loss_occ_row_has_zero_transpose_term():
     logits = rng.normal(size=(1, 17))
     target = (rng.random((1, 17)) > 0.5).astype(np.float64)
     assert abs(orc.nce_loss(logits, target) - orc.soft_cross_entropy(logits, target) / 2) < 1e-12
+
+
+def test_contract_vectors_file_is_what_the_oracle_returns():
+    """tests/golden/contract_vectors.npz holds the oracle's indices under the three fp32 evaluation orders
+    (tests/golden/make_contract_vectors.py); the orders disagree on the lattice cases, so the file can tell a build's mode."""
+    import os
+    V = np.load(os.path.join(os.path.dirname(__file__), "golden", "contract_vectors.npz"))
+    names = sorted({k.split("/")[0] for k in V.files})
+    assert len(names) == 11
+    differ = {0: 0, 1: 0}
+    for name in names:
+        for mode in (0, 1, 2):
+            if name.startswith("fps"):
+                got = orc.furthest_point_sampling(V[name + "/xyz"], int(V[name + "/npoint"]), contract=mode)
+            elif name.startswith("bq"):
+                got = orc.ball_query(V[name + "/new_xyz"], V[name + "/xyz"], float(V[name + "/radius"]), int(V[name + "/nsample"]),
+                                     contract=mode)
+            else:
+                got = orc.three_nn(V[name + "/unknown"], V[name + "/known"], contract=mode)[1]
+            assert (got == V[f"{name}/idx_mode{mode}"]).all(), (name, mode)
+        differ[0] += int((V[name + "/idx_mode0"] != V[name + "/idx_mode1"]).sum())
+        differ[1] += int((V[name + "/idx_mode1"] != V[name + "/idx_mode2"]).sum())
+    assert differ[0] > 100 and differ[1] > 100
