@@ -225,16 +225,73 @@ class FlatGradBucket:
         if dst:
             torch._foreach_copy_(dst, src)
 
-    def all_reduce(self):
-        """Average over ranks with ONE collective on the flat buffer.  RCCL (backend "nccl"): ReduceOp.AVG — the division
-        rides inside the all-reduce, no second launch; gloo (CPU rehearsals) has no AVG: SUM, then one in-place division.
-        No-op without an initialised process group."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _use_avg(self):
+        """RCCL (backend "nccl"): ReduceOp.AVG — the division rides inside the all-reduce, no second launch.  Probed ONCE on a
+        one-element tensor (no recorded run had executed that branch; a build that rejects AVG must not fail the
+        first step): on any error, and on gloo (no AVG), SUM followed by one in-place division."""
+        if getattr(self, "_avg_ok", None) is None:
+            ok = False
             if dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat.div_(dist.get_world_size(self.group))
+                try:
+                    probe = torch.ones(1, dtype=torch.float32, device=self.flat.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+                    ok = bool(abs(float(probe.item()) - 1.0) < 1e-6)
+                except Exception:  # noqa: BLE001 — whatever the backend raises for an unsupported op
+                    ok = False
+            self._avg_ok = ok
+        return self._avg_ok
+
+    def all_reduce(self):
+        """Average over ranks with ONE collective on the flat buffer.  No-op without an initialised process group."""
+        if self._distributed():
+            self.all_reduce_range(0, self.flat.numel()).wait()
+
+    def param_range(self, params):
+        """[a, b) of the flat buffer covered by `params` if they are exactly one contiguous run of it, else None."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or len(idx) != len(ids) or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        a = self.offsets[idx[0]]
+        b = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else self.flat.numel()
+        return a, b
+
+    def all_reduce_range(self, a, b):
+        """Start the averaging all-reduce of flat[a:b] and return a handle whose wait() completes it (for the CURRENT stream:
+        with RCCL the collective runs on the process group's own stream, ordered behind the stream that was current when it was
+        issued — issue it under `torch.cuda.stream(s)` right after the kernels that complete those gradients and it overlaps
+        whatever the other streams still do).  The step driver reduces the head parameters' slice as soon as the deferred
+        graph has completed it, beside the backward of SA2 / SA1, and the rest afterwards: same sums as ONE all-reduce of the
+        whole buffer (tests/test_ddp_gloo.py).  Without a process group: a no-op handle."""
+        if not self._distributed() or b <= a:
+            return _Done()
+        piece = self.flat[a:b]
+        if self._use_avg():
+            return _Pending(dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, 1)
+        return _Pending(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True), piece,
+                        dist.get_world_size(self.group))
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
+class _Pending:
+    """An all-reduce in flight (+ the division that completes the average where the backend has no AVG)."""
+
+    def __init__(self, work, piece, world):
+        self.work, self.piece, self.world = work, piece, world
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.piece is not None:
+                self.piece.div_(self.world)
 
 
 class FlatAdamW:

@@ -223,6 +223,12 @@ class GroundingStep:
         self._static_batch = self._static_next = None
         self._static_loss = None
         self._last_out = self._static_out = None
+        # gradient all-reduce in two pieces (split backward only): the head parameters' slice of the flat buffer is complete when
+        # the deferred graph gD ends — SA2 / SA1 backward (gM2, ~0.95 ms) still runs then — and is reduced beside it; the tail's
+        # slice follows gM2.  Ranges of the flat buffer, or None (one all-reduce after the step, as in every other mode).
+        self._head_range = self._tail_range = None
+        self._pending_head = None
+        self.comm_events = None    # set to [] to collect (event before, event after) the exposed all-reduce section of run()
 
     def forward_loss(self, batch, geometry=None):
         d = dict(batch)
@@ -403,6 +409,11 @@ class GroundingStep:
                     torch.autograd.backward([loss], inputs=head + boundary, retain_graph=True)
                 head_ids = {id(p) for p in head}
                 tail = [p for p in self.model.parameters() if id(p) not in head_ids]
+                rh, rt = self.bucket.param_range(head), self.bucket.param_range([p for p in tail if p.requires_grad])
+                if (rh is not None and rt is not None and sorted([rh, rt])[0][1] == sorted([rh, rt])[1][0]
+                        and rh[1] - rh[0] + rt[1] - rt[0] == self.bucket.flat.numel()
+                        and os.environ.get("VLP3D_OVERLAP_ALLREDUCE", "1") != "0"):
+                    self._head_range, self._tail_range = rh, rt
                 with torch.cuda.graph(self._gD, stream=self._side):
                     queue.flush()
                     # the head parameters' gradients are complete HERE, on this stream: their copy into the flat buffer must
@@ -454,6 +465,10 @@ class GroundingStep:
             self._side.wait_stream(cur)      # the deferred weight-gradient work reads what gM left behind
             with torch.cuda.stream(self._side):
                 self._gD.replay()
+                if self._head_range is not None:
+                    # issued under the side stream: the collective (RCCL: on the process group's own stream) is ordered behind
+                    # gD and runs beside gM2; a no-op handle without a process group
+                    self._pending_head = self.bucket.all_reduce_range(*self._head_range)
             self._gM2.replay()
         cur.wait_stream(self._side)          # join
 
@@ -476,6 +491,7 @@ class GroundingStep:
                 # epoch 50, OCC / OSC from epoch 50 on; loss_joint.py:208, loss_grounding.py) no longer matches: recapture
                 self._graph = self._gC = self._gS = self._gM = self._gD = self._gM2 = None
                 self._static_out = None
+                self._head_range = self._tail_range = None
             if self._graph is None:
                 self._regime = self.epoch < 50
                 self._capture(batch, next_batch)
@@ -495,7 +511,19 @@ class GroundingStep:
             loss = self._static_loss
         else:
             loss = self._fwd_bwd(batch, next_batch)
-        self.bucket.all_reduce()
+        ev = None
+        if self.comm_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self._pending_head is not None:
+            self.bucket.all_reduce_range(*self._tail_range).wait()
+            self._pending_head.wait()
+            self._pending_head = None
+        else:
+            self.bucket.all_reduce()
+        if ev is not None:   # what the step WAITS for the collectives: from the end of backward to the optimiser's start
+            ev[1].record()
+            self.comm_events.append(ev)
         self.opt.step()
         return loss
 

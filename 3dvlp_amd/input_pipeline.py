@@ -144,13 +144,17 @@ def augment_on_device(batch, params, mean_size_arr=None, height_col=None):
     mask_f = torch.empty((B, N), dtype=torch.float32, device=dev) if vm.is_floating_point() else None
     _ext.call("vlp3d_augment_votes", pc, B, N, C, inst, I, ibox, valid, vote, mask_f, mask_i)
     batch["vote_label"], batch["vote_label_mask"] = vote, (mask_f if mask_i is None else mask_i)
-    boxes = torch.cat([batch["center_label"][..., :3].float(), batch["box_sizes"].float()], -1).contiguous()
+    present = batch["box_label_mask"].to(torch.float32).unsqueeze(-1)
+    # absent GT rows are ZERO boxes before the augmentation (dataset.py:631,649-650) and go through it like every other row
+    boxes = (torch.cat([batch["center_label"][..., :3].float(), batch["box_sizes"].float()], -1) * present).contiguous()
     M = boxes.shape[1]
     out = torch.empty_like(boxes)
     _ext.call("vlp3d_augment_boxes", boxes, B, M, p, out)
     mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32, device=dev)
-    present = batch["box_label_mask"].to(torch.float32).unsqueeze(-1)
-    batch["center_label"] = out[..., :3] * present
+    # dataset.py:823 exports target_bboxes[:, 0:3] UNMASKED: an absent row's centre is the translation vector (utils_fn.py:
+    # 137-139 adds it to all MAX_NUM_OBJ rows), not the origin — it takes part in nn_distance(aggregated_vote_xyz, gt_center)
+    # (loss_detection.py:88-92).  Sizes of absent rows are zero boxes' sizes (zero), their residuals stay zero (dataset.py:688).
+    batch["center_label"] = out[..., :3].contiguous()
     batch["box_sizes"] = out[..., 3:6] * present
     batch["size_residual_label"] = (out[..., 3:6] - mean[batch["size_class_label"]]) * present
     tgt = batch["ref_box_label_list"].long().unsqueeze(-1).expand(-1, -1, 6)
@@ -163,9 +167,13 @@ def augment_on_device(batch, params, mean_size_arr=None, height_col=None):
 AUGMENT_ONLY_KEYS = ("instance_labels", "instance_valid", "box_sizes")
 
 
-def augmenting_prepare(rng, prepare=None, mean_size_arr=None, height_col=-1):
+def augmenting_prepare(rng, prepare=None, mean_size_arr=None, height_col=3):
     """-> a `prepare` callable for Prefetcher: draw this batch's parameters (host, reference call order), augment on the
-    device, drop the loader-only arrays the step never reads, then `prepare` (grounding_step.prepare_batch)."""
+    device, drop the loader-only arrays the step never reads, then `prepare` (grounding_step.prepare_batch).
+    height_col: the column that scale_augment multiplies by the z scale.  Default 3 = the reference AS SHIPPED
+    (utils_fn.py:119-120 scales point_cloud[:, 3]; dataset.py:603-607 appends the height as the LAST column, so with normals /
+    multiview features the reference scales the first feature channel and leaves the height alone); pass -1 to scale the
+    true height channel instead, None for no height scaling (use_height off)."""
     def run(batch):
         B = batch["point_clouds"].shape[0]
         batch = augment_on_device(batch, draw_augment_params(rng, B), mean_size_arr, height_col)

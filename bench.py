@@ -478,6 +478,8 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sync()
+    if world > 1:
+        step.comm_events = []
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -491,6 +493,10 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    exposed = None
+    if step.comm_events:
+        ex = sorted(a.elapsed_time(b) for a, b in step.comm_events)
+        exposed = round(ex[len(ex) // 2], 4)
     pct = lambda p: round(per_step[min(len(per_step) - 1, int(p * len(per_step)))], 3)
 
     checks = None
@@ -536,6 +542,12 @@ def main():
                                  "input_pipeline.Prefetcher" + (", device-side training augmentation" if args.augment else "") + ")"
                                  if args.host_batches else "resident in HBM before the timed region"),
                        "loss": float(loss.detach())},
+            "allreduce_exposed_ms": exposed,
+            "allreduce": ("two pieces: the head parameters' slice of the flat fp32 gradient buffer is reduced beside the backward of "
+                          "SA2 / SA1 (issued behind the deferred graph on the side stream), the rest after it; "
+                          "allreduce_exposed_ms = median time the launch stream spends between the end of backward and the "
+                          "optimiser (null on one GPU: no collective)") if step._head_range is not None else
+                         "one all-reduce of the flat fp32 gradient buffer after backward",
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
                         "how": "events on the launch stream between consecutive steps (this rank)"},
             "roofline_step": {"flops_per_step": flops, "bytes_per_step": byts,

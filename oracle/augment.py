@@ -141,14 +141,18 @@ def augment_batch(batch, params, mean_size_arr, height_col):
     out = {k: np.array(batch[k]) for k in ("point_clouds", "vote_label", "vote_label_mask", "center_label",
                                             "size_residual_label", "ref_center_label_list", "ref_size_residual_label_list")}
     for b in range(B):
+        nb = int(batch["box_label_mask"][b].sum())
+        # dataset.py:631,649-650: target_bboxes = zeros((MAX_NUM_OBJ, 6)), rows [0:num_bbox] filled — the ABSENT rows go through
+        # flip / rotate / scale as zeros and then take the translation like every other row (utils_fn.py:137-139: bbox[:, :3] +=
+        # factor), and dataset.py:823 exports target_bboxes[:, 0:3] unmasked: padded GT centres sit at (tx, ty, tz), not at the
+        # origin (they feed nn_distance in loss_detection.py:88-92).  Sizes and size residuals of absent rows stay zero.
         boxes = np.concatenate([batch["center_label"][b], batch["box_sizes"][b]], 1)
+        boxes[nb:] = 0
         pc, bb = augment_scene(batch["point_clouds"][b], boxes, params[b], height_col)
         votes, mask = votes_after_augmentation(pc[:, :3], batch["instance_labels"][b], batch["instance_valid"][b])
         out["point_clouds"][b] = pc
         out["vote_label"][b], out["vote_label_mask"][b] = votes, mask
-        nb = int(batch["box_label_mask"][b].sum())
-        out["center_label"][b] = 0
-        out["center_label"][b, :nb] = bb[:nb, :3]
+        out["center_label"][b] = bb[:, :3]                                               # dataset.py:823: ALL rows
         cls = batch["size_class_label"][b, :nb]
         out["size_residual_label"][b] = 0
         out["size_residual_label"][b, :nb] = bb[:nb, 3:6] - mean_size_arr[cls]          # dataset.py:688-689

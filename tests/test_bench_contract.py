@@ -35,8 +35,13 @@ def test_bench_json_line_contract():
     assert 0 < sm["p10"] <= sm["median"] <= sm["p90"] and sm["median"] < 1.5 * d["ms_per_step"]
     rs = d["roofline_step"]
     assert rs["flops_per_step"] > 3e11 and 0 < rs["frac_mfma"] < 1 and 0 < rs["frac_hbm"] < 1
+    # the headline is the kernel that dominates the rocprofv3 summary: SA1's pruned FPS, against the VALU rate of its 8 CUs
+    assert "fps_pruned" in r["kernel"] and r["bound"] == "valu" and r["cus_used"] == 8 and r["ms_is"].startswith("in-step")
     names = " ".join(k["kernel"] for k in d["roofline_kernels"])
-    assert "fps" in names and "ball query" in names and "cross-attention" in names
+    assert "MAIN-stream" in names and "ball query" in names and "cross-attention" in names
+    for key in ("ms_per_step_padded", "ms_per_step_fp32", "ms_per_step_host_batches"):
+        assert d[key] > 0.5 * d["step_ms"]["median"], key
+    assert d["allreduce_exposed_ms"] is None      # one GPU: no collective
     hw = d["hw"]
     assert 2000 < hw["hbm_read_GBs"] < 9000 and 500 < hw["bf16_mfma_TFLOPs"] < 3000 and 50 < hw["fp32_fma_TFLOPs"] < 200
 
@@ -62,6 +67,7 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["scaling"] == "weak" and abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert d["allreduce_exposed_ms"] is not None and d["allreduce_exposed_ms"] >= 0 and "two pieces" in d["allreduce"]
     a, b = d["replica_param_checksums"]
     assert a == b, (a, b)                      # identical replicas after averaged-gradient steps
     assert d["config"]["loss"] == d["config"]["loss"] and d["config"]["loss"] > 0   # finite

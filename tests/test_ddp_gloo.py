@@ -115,6 +115,63 @@ def test_flat_bucket_allreduce_world8():
     assert torch.allclose(ret[0][6], mean_local, atol=1e-6)
 
 
+def _worker_buckets(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ddp = importlib.import_module("3dvlp_amd.ddp")
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    bucket = ddp.FlatGradBucket(model)
+    lo, hi = ddp.shard_range(4 * world, rank, world)
+    torch.manual_seed(11)
+    x = torch.randn(4 * world, 6)
+    tail = list(model[0].parameters())                              # the layers whose backward finishes LAST (SA1 / SA2 there)
+    head = [p for p in model.parameters() if all(p is not q for q in tail)]
+    rt, rh = bucket.param_range(tail), bucket.param_range(head)
+    assert rt == (0, 6 * 8 + 8) and rh == (rt[1], bucket.flat.numel())
+    assert bucket.param_range([tail[0], head[-1]]) is None          # not one contiguous run
+
+    def grads():
+        bucket.zero()
+        model(x[lo:hi]).pow(2).mean().backward()
+        bucket.collect()
+    grads()
+    bucket.all_reduce()
+    one = bucket.flat.clone()
+    grads()
+    pending = bucket.all_reduce_range(*rh)      # issued while the "tail" is still being produced in the real step
+    bucket.all_reduce_range(*rt).wait()
+    pending.wait()
+    two = bucket.flat.clone()
+    ret[rank] = (one, two)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _two_bucket_case(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_buckets, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        one, two = ret[r]
+        # the two overlapped pieces give the single all-reduce's averages (a ring all-reduce adds the ranks' terms in an order
+        # that depends on where an element sits in its message: equal up to the order of eight float additions)
+        assert torch.allclose(one, two, rtol=1e-6, atol=1e-9)
+        assert torch.equal(two, ret[0][1]) and torch.equal(one, ret[0][0])   # and every rank holds the same buffer
+
+
+def test_two_bucket_overlapped_allreduce_equals_single_world2():
+    """the head parameters' slice of the flat gradient buffer is reduced while the tail's gradients are still
+    being computed, the tail's slice afterwards — same averaged buffer as ONE all-reduce, on every rank."""
+    _two_bucket_case(2)
+
+
+def test_two_bucket_overlapped_allreduce_equals_single_world8():
+    _two_bucket_case(8)
+
+
 def test_collect_subsets_equal_one_collect():
     """FlatGradBucket.collect_subset over two disjoint parameter sets (the step driver's split backward: each stream copies the
     gradients IT completed) leaves the same flat buffer, .grad views and touched flags as one collect()."""

@@ -79,6 +79,43 @@ def test_augment_oracle_invariants():
     assert r[0, 3] >= 2.0 * np.cos(0.3) - 1e-9 and r[0, 5] == 0.6
 
 
+def test_augment_absent_gt_rows_follow_the_reference_statements():
+    """the padded (absent) GT rows.  dataset.py:631 target_bboxes = zeros((MAX_NUM_OBJ, 6)); :649-650 rows
+    [0:num_bbox] filled; flip / rotate / scale leave zero rows zero; utils_fn.py:137-139 `bbox[:, :3] += factor` moves ALL
+    rows; dataset.py:823 exports target_bboxes[:, 0:3] unmasked; :688 size_residuals only for [0:num_bbox].  Restated here
+    statement by statement for the absent rows and compared with the oracle's batch function; and scale_augment multiplies
+    point_cloud[:, 3] (utils_fn.py:119-120), whatever that column holds."""
+    from oracle import augment as oa
+    synth = importlib.import_module("3dvlp_amd.synth")
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    b = synth.make_batch(2, 2, 2048, 2, instances=True)
+    mean = synth.mean_size_arr()
+    params = ip.draw_augment_params(np.random.default_rng(5), 2).astype(np.float64)
+    params[0, 0] = params[1, 1] = 1.0
+    o = oa.augment_batch(b, params, mean, 3)
+    for i in range(2):
+        nb = int(b["box_label_mask"][i].sum())
+        M = b["center_label"].shape[1]
+        assert 0 < nb < M
+        target_bboxes = np.zeros((M, 6))                                        # dataset.py:631
+        fx, fy = params[i, 0], params[i, 1]
+        if fx:
+            target_bboxes[:, 0] = -1 * target_bboxes[:, 0]                      # utils_fn.py:33
+        if fy:
+            target_bboxes[:, 1] = -1 * target_bboxes[:, 1]                      # :38
+        scale = np.diag(params[i, 5:8])
+        target_bboxes[:, 0:3] = np.dot(target_bboxes[:, 0:3], scale)            # :121 (rotations of a zero box: a zero box)
+        target_bboxes[:, 3:6] = np.dot(target_bboxes[:, 3:6], scale)            # :122
+        target_bboxes[:, :3] += list(params[i, 8:11])                           # :137-139
+        assert np.allclose(o["center_label"][i, nb:], target_bboxes[nb:, :3].astype(np.float32), atol=1e-7)
+        assert np.abs(o["center_label"][i, nb:]).max() > 1e-3                   # really the translation, not the origin
+        assert (o["size_residual_label"][i, nb:] == 0).all()
+        # the column scale_augment touches: column 3 (first feature channel here), the true height column stays
+        col3 = b["point_clouds"][i, :, 3].astype(np.float64) * params[i, 7]
+        assert np.allclose(o["point_clouds"][i, :, 3], col3, atol=1e-6)
+        assert np.array_equal(o["point_clouds"][i, :, -1], b["point_clouds"][i, :, -1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [4096, 40000])
 def test_augment_on_device_equals_oracle(N):
@@ -91,9 +128,12 @@ def test_augment_on_device_equals_oracle(N):
     host = synth.make_batch(4, B, N, 4, instances=True)
     params = ip.draw_augment_params(np.random.default_rng(11), B)
     params[0, 0], params[1, 1], params[2, :2] = 1.0, 1.0, 0.0     # every flip branch taken at least once
-    want = oa.augment_batch(host, params.astype(np.float64), synth.mean_size_arr(), -1)
+    hc = -1 if N == 4096 else 3    # the true height column / the column the reference as shipped scales (utils_fn.py:119-120)
+    want = oa.augment_batch(host, params.astype(np.float64), synth.mean_size_arr(), hc)
     dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
-    got = ip.augment_on_device(dev, params, height_col=-1)
+    got = ip.augment_on_device(dev, params, height_col=hc)
+    nb = int(host["box_label_mask"][0].sum())
+    assert np.abs(want["center_label"][0, nb:]).max() > 1e-3   # absent GT rows carry the translation (dataset.py:823)
     for k, tol in (("point_clouds", 2e-6), ("center_label", 2e-6), ("size_residual_label", 5e-6), ("ref_center_label_list", 2e-6),
                    ("ref_size_residual_label_list", 5e-6), ("vote_label", 5e-6)):
         np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=0, atol=tol * 10, err_msg=k)
