@@ -31,7 +31,7 @@ from .grounding import ContrastModule, MatchModule
 class GroundingNet(nn.Module):
     def __init__(self, num_class=18, num_heading_bin=1, num_size_cluster=18, mean_size_arr=None,
                  input_feature_dim=132, num_proposal=256, vote_factor=1, sampling="vote_fps", use_con=True,
-                 use_answer=False, num_answers=0):
+                 use_answer=False, num_answers=0, use_caption=False, caption_kwargs=None):
         super().__init__()
         mean_size_arr = synth.mean_size_arr() if mean_size_arr is None else mean_size_arr
         assert mean_size_arr.shape[0] == num_size_cluster
@@ -48,6 +48,10 @@ class GroundingNet(nn.Module):
         if use_con:
             self.constrast = ContrastModule(config=self.dataset_config)
         self.match = MatchModule(num_proposals=num_proposal, lang_size=256, det_channel=128)
+        self.use_caption = use_caption
+        if use_caption:  # the Scan2Cap head on the shared proposal features (jointnet.py:103-104, 214-215; BASELINE cfg4)
+            from .caption import TransformerDecoderModel
+            self.caption = TransformerDecoderModel(30522, **(caption_kwargs or {}))
         self.use_answer = use_answer
         if use_answer:  # the ScanQA head of the joint QA + grounding task (jointnet.py:109-110, 217-218; BASELINE cfg5)
             from .answer import AnswerModule
@@ -69,6 +73,8 @@ class GroundingNet(nn.Module):
         data_dict = self.match(data_dict)
         if self.use_con:
             data_dict = self.constrast(data_dict)
+        if self.use_caption:
+            data_dict = self.caption(data_dict)
         if self.use_answer:
             data_dict = self.answer(data_dict)
         return data_dict
@@ -77,11 +83,11 @@ class GroundingNet(nn.Module):
 LOSS_IMPL = None  # None -> losses.DEFAULT_IMPL ("hip": csrc/joint_loss.hip); "torch" = batched op-by-op form (tests)
 
 
-def grounding_loss(d, config, args=None, impl=None):
+def grounding_loss(d, config, args=None, impl=None, caption=False):
     """The reference's training loss for this path: losses.get_joint_loss == lib/loss_helper/loss_joint.py:26-227 with
     detection + reference (+ DIoU + OCC/OSC, run.sh:1); the language-classification term belongs to the out-of-scope
     language encoder and is included only when the batch carries `lang_scores`."""
-    losses.get_joint_loss(args, d, config=config, caption=False, impl=impl or LOSS_IMPL)
+    losses.get_joint_loss(args, d, config=config, caption=caption, impl=impl or LOSS_IMPL)
     return d["loss"]
 
 
@@ -177,10 +183,16 @@ class GroundingStep:
     all-reduce and the optimiser step stay outside the graph."""
 
     def __init__(self, device, epoch=50, lr=1e-3, autocast_dtype=None, seed=0, use_graph=False, pipeline=False,
-                 sa_dtype=None, use_answer=False, num_answers=0, side_stream=None):
+                 sa_dtype=None, use_answer=False, num_answers=0, side_stream=None, use_caption=False, caption_kwargs=None):
+        """use_caption: the caption head (3dvlp_amd.caption.TransformerDecoderModel(30522), jointnet.py:104) is part of the
+        model — its parameters live in the flat parameter / gradient / AdamW buffers, `cap_loss` is added inside the captured
+        graph (loss_joint.py:222-223), ONE backward, the same all-reduce (BASELINE cfg4).  The batch then carries `input_ids`
+        (B, L, T) token ids."""
         torch.manual_seed(seed)
         self.device = device
-        self.model = GroundingNet(use_answer=use_answer, num_answers=num_answers).to(device)
+        self.use_caption = bool(use_caption)
+        self.model = GroundingNet(use_answer=use_answer, num_answers=num_answers, use_caption=use_caption,
+                                  caption_kwargs=caption_kwargs).to(device)
         self.loss_args = type("Args", (losses._Args,), {"use_answer": bool(use_answer)})
         self.model.train()
         if torch.device(device).type == "cuda":
@@ -242,7 +254,7 @@ class GroundingStep:
                     d = self.model(d)
             else:
                 d = self.model(d)
-        return grounding_loss(d, self.model.dataset_config, self.loss_args), d
+        return grounding_loss(d, self.model.dataset_config, self.loss_args, caption=self.use_caption), d
 
     @staticmethod
     def _copy_geometry(dst, src):

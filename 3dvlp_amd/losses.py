@@ -18,7 +18,7 @@ Two implementations of the same arithmetic:
 
 Deliberate, documented differences from the reference:
   * the per-(scene, sentence) Python loops with `.cpu()` syncs are batched;
-  * out-of-scope switches (`caption`, `use_reg_head`, `use_kl_loss`, `use_attr_loss`, `use_vote_weight`,
+  * out-of-scope switches (`use_reg_head`, `use_kl_loss`, `use_attr_loss`, `use_vote_weight`,
     `use_mlm`, `orientation`, `distance`) raise NotImplementedError when turned on;
   * the language-classification term reads `lang_scores` of the (out-of-scope) language encoder: it is included when the
     data_dict carries `lang_scores` + `object_cat_list`, else reported as zero.
@@ -344,8 +344,9 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
     for flag in ("use_reg_head", "use_kl_loss", "use_attr_loss", "use_vote_weight", "use_mlm"):
         if getattr(args, flag, False):
             raise NotImplementedError(flag + " is outside the grounding hot path (SURVEY.md §8)")
-    if caption or orientation or distance or not detection or not reference:
-        raise NotImplementedError("only detection + reference (the run.sh:1 configuration) is on the grounding hot path")
+    if orientation or distance or not detection or not reference:
+        raise NotImplementedError("only detection + reference (the run.sh:1 configuration; + caption for BASELINE cfg4) is on "
+                                  "the grounding hot path")
     impl = impl or DEFAULT_IMPL
     d = data_dict
     dev = d["vote_xyz"].device
@@ -407,7 +408,14 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
     if getattr(args, "use_answer", False):  # loss_joint.py:118-119, 219-220 (the ScanQA + grounding joint task, cfg5)
         d["answer_loss"] = compute_answer_classification_loss(d)
         loss = loss + d["answer_loss"]
-    for k in ("cap_loss", "cap_acc", "ori_loss", "ori_acc", "dist_loss", "mlm_loss"):
+    zero_keys = ["ori_loss", "ori_acc", "dist_loss", "mlm_loss"]
+    if caption:  # loss_joint.py:122-127, 222-223 (Scan2Cap head on the shared proposal features, BASELINE cfg4)
+        from .caption import compute_cap_loss
+        d["cap_loss"], d["cap_acc"] = compute_cap_loss(d, pad_token_id=0 if pad_token_id is None else pad_token_id)
+        loss = loss + d["cap_loss"]
+    else:
+        zero_keys += ["cap_loss", "cap_acc"]
+    for k in zero_keys:
         d[k] = _const("zero", lambda: torch.zeros(()), dev)
     d["loss"] = loss
     return d

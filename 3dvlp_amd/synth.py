@@ -102,10 +102,13 @@ def make_scene(seed, num_points=40000, skip_points=0):
                 sem_cls_label=pad(size_class.astype(np.int64)))
 
 
-def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000, num_answers=0, instances=False):
+def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_base=1000, num_answers=0, instances=False,
+               caption_tokens=0):
     """Batch dict of numpy arrays with the keys the grounding step reads (jointnet.py / loss_joint.py).  num_answers > 0
     adds the ScanQA targets of the joint QA + grounding task: `answer_cat_scores` (B*L, num_answers) soft scores (1-3
     annotated answers per question, VQA-style min(1, 0.3 count)) and `answer_cat` (B*L) the first of them.
+    caption_tokens = T > 0: `input_ids` becomes (B, L, T) BERT-like token ids for the caption head (BASELINE cfg4): [CLS] = 101,
+    8 .. T - 2 random word ids in [1000, 30000), [SEP] = 102, then pads (0) — the description tokens of lib/joint/dataset.py.
     instances=True adds what the training-time augmentation needs (input_pipeline.augment_on_device): `instance_labels`
     (B,N) int32, `instance_valid` (B, NUM_BOXES + 1) uint8 and `box_sizes` (B, MAX_NUM_OBJ, 3)."""
     scenes = [make_scene(seed_base + first_scene + i, num_points) for i in range(batch_size)]
@@ -151,4 +154,15 @@ def make_batch(first_scene, batch_size, num_points=40000, lang_num_max=8, seed_b
             sc[q, picks] = np.minimum(1.0, 0.3 * rng.integers(1, 5, size=len(picks))).astype(np.float32)
             first[q] = picks[0]
         out["answer_cat_scores"], out["answer_cat"] = sc, first
+    if caption_tokens:
+        T = int(caption_tokens)
+        r2 = np.random.default_rng(4242 + first_scene)    # its own stream: the other arrays do not depend on this switch
+        ids = np.zeros((batch_size, L, T), np.int64)
+        ids[..., 0] = 101
+        for b in range(batch_size):
+            for l in range(L):
+                n = int(r2.integers(min(8, T - 2), T - 1))
+                ids[b, l, 1:1 + n - 1] = r2.integers(1000, 30000, n - 1)
+                ids[b, l, n] = 102
+        out["input_ids"] = ids
     return out

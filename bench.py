@@ -421,6 +421,10 @@ def main():
                          "votes recomputed after it; lib/joint/dataset.py:653-690) on the device, on the copy stream")
     ap.add_argument("--scenes-per-gpu", type=int, default=B_PER_GPU,
                     help="scenes per GPU and step (default 8 = BASELINE cfg2, the headline; 32 = cfg3's per-GPU batch)")
+    ap.add_argument("--caption", action="store_true",
+                    help="BASELINE cfg4: the Scan2Cap caption head (30 522 words, 6 layers) attached to the step on the shared "
+                         "proposal features — its parameters in the flat buffers, cap_loss inside the captured graph, one backward, "
+                         "one all-reduce (never the headline `value`, which is cfg2)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute the backbone geometry (FPS / ball query) inline instead of one batch ahead")
@@ -449,10 +453,10 @@ def main():
     ext = importlib.import_module("3dvlp_amd._lib")
 
     first, _ = ddp.shard_range(B_PER_GPU * world, rank, world)
-    batch_np = synth.make_batch(first, B_PER_GPU, NUM_POINTS, LANG_NUM)
+    batch_np = synth.make_batch(first, B_PER_GPU, NUM_POINTS, LANG_NUM, caption_tokens=32 if args.caption else 0)
     batch = gs.batch_to_device(batch_np, device)
     step = gs.GroundingStep(device, epoch=50, sa_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
-                            use_graph=not args.no_graph, pipeline=not args.no_pipeline)
+                            use_graph=not args.no_graph, pipeline=not args.no_pipeline, use_caption=args.caption)
     ddp.broadcast_parameters(step.model, layout=step.layout)
     copy_stream = torch.cuda.Stream(device=device)  # the loader's upload stream, created right behind the step's side stream
 
@@ -525,7 +529,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("cfg2" if B_PER_GPU == 8 else "cfg3 per-GPU batch (%d scenes)" % B_PER_GPU) +
-                       ": ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene",
+                       ": ScanRefer grounding step, 40k pts, 256 proposals, 8 sentences/scene" +
+                       (" + cfg4's Scan2Cap caption head on the shared proposal features (32 tokens/sentence, 30 522 words)"
+                        if args.caption else ""),
                        "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                        "step": "fwd + the reference's loss (loss_joint.py: vote, objectness, box + sem-cls, DIoU + "
                                "SoftmaxRankingLoss reference, OCC/OSC; epoch 50) + bwd + flat grad all-reduce + AdamW",
@@ -561,7 +567,7 @@ def main():
         if not args.no_kernels:
             out["roofline"], out["roofline_kernels"], extra = kernel_rooflines(args, batch, ext, gs, side_stream=step._side)
             out.update(extra)
-            if bf and B_PER_GPU == 8 and not args.host_batches and world == 1:
+            if bf and B_PER_GPU == 8 and not args.host_batches and world == 1 and not args.caption:
                 # the other configurations of the same step a reader needs beside the headline: the data-independent
                 # form, the 1e-4 parity configuration and the PCIe-inclusive rate — never `value`
                 out["ms_per_step_padded"] = round(extra_config_ms(args, batch, gs, step._side, padded=True), 3)

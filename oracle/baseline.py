@@ -63,15 +63,17 @@ def _fp_cpu(fp, unknown, known, unknow_feats, known_feats):
 class CpuStep:
     """The whole step on the CPU.  `net` is a 3dvlp_amd.grounding_step.GroundingNet built on the CPU."""
 
-    def __init__(self, seed=0, lr=1e-3, dtype=torch.float32, use_answer=False, num_answers=0):
+    def __init__(self, seed=0, lr=1e-3, dtype=torch.float32, use_answer=False, num_answers=0, use_caption=False,
+                 caption_kwargs=None):
         """dtype=torch.float64: the dense layers, the loss and AdamW in double precision (geometry stays the fp32 C
         restatement: indices are defined by fp32 bits) — the yardstick of tests/test_step_parity.py."""
         self.gs = importlib.import_module("3dvlp_amd.grounding_step")
         self.losses = importlib.import_module("3dvlp_amd.losses")
         tr = importlib.import_module("3dvlp_amd.transformer")
         torch.manual_seed(seed)
-        self.net = self.gs.GroundingNet(use_answer=use_answer, num_answers=num_answers).train().to(dtype)
-        self.use_answer = use_answer
+        self.net = self.gs.GroundingNet(use_answer=use_answer, num_answers=num_answers, use_caption=use_caption,
+                                        caption_kwargs=caption_kwargs).train().to(dtype)
+        self.use_answer, self.use_caption = use_answer, use_caption
         self.dtype = dtype
         for m in self.net.modules():
             if isinstance(m, tr.ScaledDotProductAttention):
@@ -132,11 +134,29 @@ class CpuStep:
         d = prop.decode_scores(prop.proposal(af, d))
         d = net.match(net.relation(d))
         d = net.constrast(d)
+        cap_loss = None
+        if self.use_caption:
+            # the caption head by the op-by-op restatement oracle/captioner.py (eval-mode arithmetic: dropout and the MLM
+            # corruption off — the caller builds the GPU step the same way) on the head's parameters under the reference's
+            # key names (caption.py's reference_view: autograd reaches the module's own parameters through it), and
+            # loss_captioning.py:25-48; every proposal is a good box (d2 > -1, transformer_captioner.py:476-480)
+            from . import captioner as ocap
+            cap = net.caption
+            sd = cap.reference_view({n: p for n, p in cap.named_parameters()})
+            for k, v in cap.state_dict().items():
+                sd.setdefault(k, v)
+            lang_cap, idx = ocap.forward_train(sd, d, N=cap.N, h=cap.h, early_guide=cap.early_guide)
+            good = torch.ones(lang_cap.shape[0], dtype=lang_cap.dtype)
+            cap_loss = ocap.cap_loss(lang_cap, d["input_ids"], good)
+            d["match_idx"], d["lang_cap"] = idx, lang_cap
         args = None
         if self.use_answer:
             d = net.answer(d)
             args = type("Args", (self.losses._Args,), {"use_answer": True})
         self.losses.get_joint_loss(args, d, config=net.dataset_config, impl="torch")
+        if cap_loss is not None:                       # loss_joint.py:222-223
+            d["cap_loss"] = cap_loss
+            d["loss"] = d["loss"] + cap_loss
         self.last = d
         return d["loss"]
 

@@ -1,5 +1,6 @@
 """Step time of the other BASELINE configurations' per-GPU shapes on ONE MI355X (captured, pipelined, bf16): cfg3's
-pre-training batch (32 scenes on 8 GPUs = 4 per GPU, and all 32 on one GPU), cfg5's 80 000-point joint QA + grounding step."""
+pre-training batch (32 scenes on 8 GPUs = 4 per GPU, and all 32 on one GPU), cfg4's caption head attached to the step
+(GroundingStep(use_caption=True): 8 sentences x 32 tokens, 30 522 words), cfg5's 80 000-point joint QA + grounding step."""
 import importlib
 import os
 import sys
@@ -14,9 +15,12 @@ dev = torch.device("cuda:0")
 side = None
 for name, B, npts, kw in (("cfg2  8 x 40k", 8, 40000, {}), ("cfg3  4 x 40k (32 scenes / 8 GPUs)", 4, 40000, {}),
                           ("cfg3 32 x 40k (one GPU)", 32, 40000, {}),
+                          ("cfg4  8 x 40k, grounding + caption", 8, 40000, dict(use_caption=True)),
+                          ("cfg4  4 x 40k, grounding + caption", 4, 40000, dict(use_caption=True)),
                           ("cfg5  4 x 80k, QA + grounding", 4, 80000, dict(use_answer=True, num_answers=512)),
                           ("cfg5  8 x 80k, QA + grounding", 8, 80000, dict(use_answer=True, num_answers=512))):
-    batch = gs.batch_to_device(synth.make_batch(0, B, npts, 8, num_answers=kw.get("num_answers", 0)), dev)
+    batch = gs.batch_to_device(synth.make_batch(0, B, npts, 8, num_answers=kw.get("num_answers", 0),
+                                                caption_tokens=32 if kw.get("use_caption") else 0), dev)
     step = gs.GroundingStep(dev, epoch=50, sa_dtype=torch.bfloat16, use_graph=True, pipeline=True, side_stream=side, **kw)
     side = step._side
     for _ in range(12):
