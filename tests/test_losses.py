@@ -151,7 +151,21 @@ def test_eval_mode_and_unsupported_switches():
     out = L.get_joint_loss(None, t, config=config, impl="torch")   # eval: no `random` key needed, no gating
     assert abs(float(out["loss"]) - ref["loss"]) <= 2e-5 * abs(ref["loss"])
     with pytest.raises(NotImplementedError):
-        L.get_joint_loss(None, t, config=config, caption=True, impl="torch")
+        L.get_joint_loss(None, t, config=config, orientation=True, impl="torch")
+    # caption=True (BASELINE cfg4, loss_joint.py:122-127, 222-223): loss += cap_loss of loss_captioning.py:25-48 over the caption
+    # head's outputs in the data_dict — here a materialised (B*L, T-1, V) log-probability tensor, against oracle/captioner.py
+    from oracle import captioner as ocap
+    g = torch.Generator().manual_seed(0)
+    BL, T, V = t["cluster_ref"].shape[0], 9, 50
+    ids = torch.randint(1, V, (BL, T), generator=g)
+    ids[:, 6:] = 0
+    lang_cap = torch.log_softmax(torch.randn(BL, T - 1, V, generator=g), -1)
+    good = torch.ones(BL, dtype=torch.bool)
+    tc = dict(t, lang_cap=lang_cap, input_ids=ids.view(-1, BL // t["vote_xyz"].shape[0], T), good_bbox_masks=good)
+    with_cap = L.get_joint_loss(None, tc, config=config, caption=True, impl="torch")
+    want = ocap.cap_loss(lang_cap.double(), ids, good.double())
+    assert abs(float(with_cap["cap_loss"]) - float(want)) < 1e-5 * float(want)
+    assert abs(float(with_cap["loss"]) - float(out["loss"]) - float(want)) < 1e-5 * float(with_cap["loss"])
     with pytest.raises(NotImplementedError):
         L.get_joint_loss(SimpleNamespace(use_reg_head=True), t, config=config, impl="torch")
     with pytest.raises(RuntimeError, match="CPU not supported"):
