@@ -28,6 +28,7 @@ SIGNATURES = {
     "vlp3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "vlp3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "vlp3d_ball_query_sorted": [_vp, _vp, _i, _i, _i, _f, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "vlp3d_ball_query_grid_workspace_bytes": [_i, _i],
     "vlp3d_ball_query_grid": [_vp, _vp, _i, _i, _i, _f, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "vlp3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
@@ -154,7 +155,7 @@ GEOM_ENTRY_POINTS = (
     "vlp3d_abi_version", "vlp3d_fp_contract", "vlp3d_furthest_point_sampling", "vlp3d_fps_prefix_check",
     "vlp3d_furthest_point_sampling_cond", "vlp3d_fps_workspace_bytes", "vlp3d_furthest_point_sampling_pruned",
     "vlp3d_fps_pruned_profile", "vlp3d_fps_pruned_trace", "vlp3d_ball_query", "vlp3d_ball_query_grid_workspace_bytes",
-    "vlp3d_ball_query_grid", "vlp3d_three_nn", "vlp3d_three_interpolate", "vlp3d_three_interpolate_grad", "vlp3d_gather_xyz",
+    "vlp3d_ball_query_grid", "vlp3d_ball_query_sorted", "vlp3d_three_nn", "vlp3d_three_interpolate", "vlp3d_three_interpolate_grad", "vlp3d_gather_xyz",
     "vlp3d_gather_xyz_grad", "vlp3d_three_nn_weights", "vlp3d_gather_points", "vlp3d_gather_points_grad", "vlp3d_group_points",
     "vlp3d_group_points_grad")
 _geom_libs = {}
@@ -270,13 +271,14 @@ FPS_PRUNED_MAX_N = 131072  # 64 slots per wave and lane-slot, two lane-slots abo
 FPS_PREFIX_MAX_N = 65536
 
 
-def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False, return_flag=False):
+def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False, return_flag=False, return_workspace=False):
     """algorithm: None = pick by N, "dense" (csrc/fps.hip) or "pruned" (csrc/fps_pruned.hip) — identical output.
 
     prefix_hint=True says the caller EXPECTS `points` to be an earlier FPS's samples in sampling order (every backbone
     level after the first): two parallel kernels then try to prove that the result is 0..nsamples-1 and the sequential
     kernel runs only if the proof fails — the output is the same with or without the hint.  return_flag adds the
-    device int (0 = proven) for tests."""
+    device int (0 = proven) for tests.  return_workspace=True: -> (indices, workspace or None) — the pruned algorithm's
+    workspace holds the cloud's spatial sort afterwards, which ball_query_sorted reads for the same cloud."""
     _chk_float(points, "points")
     _chk_dev(points)
     B, N, _ = points.shape
@@ -293,6 +295,7 @@ def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False,
         return (out, flag) if return_flag else out
     if algorithm is None:
         algorithm = "pruned" if FPS_PRUNED_MIN_N <= N <= FPS_PRUNED_MAX_N else "dense"
+    ws = None
     with torch.cuda.device(points.device):
         if algorithm == "pruned":
             nbytes = int(_geom().vlp3d_fps_workspace_bytes(B, N))
@@ -303,7 +306,22 @@ def furthest_point_sampling(points, nsamples, algorithm=None, prefix_hint=False,
             tmp = torch.empty((B, N), dtype=torch.float32, device=points.device)
             _check(_geom().vlp3d_furthest_point_sampling(_p(points), B, N, int(nsamples), _p(tmp), _p(out), _stream()),
                    "furthest_point_sampling")
-    return out
+    return (out, ws) if return_workspace else out
+
+
+def ball_query_sorted(new_xyz, xyz, radius, nsample, fps_workspace):
+    """ball_query(new_xyz, xyz, radius, nsample) — identical output — in one launch on the spatial sort of `xyz` that
+    furthest_point_sampling(xyz, ., "pruned", return_workspace=True) left in `fps_workspace` (csrc/ball_query_sorted.hip)."""
+    _chk_float(new_xyz, "new_xyz")
+    _chk_float(xyz, "xyz")
+    _chk_dev(new_xyz, ("xyz", xyz), ("fps_workspace", fps_workspace))
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(_geom().vlp3d_ball_query_sorted(_p(new_xyz), _p(xyz), B, N, M, float(radius), int(nsample), _p(fps_workspace),
+                                               fps_workspace.numel(), _p(idx), _stream()), "ball_query_sorted")
+    return idx
 
 
 def gather_points(points, idx):

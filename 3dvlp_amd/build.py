@@ -23,7 +23,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # (include/vlp3d.h vlp3d_fp_contract: 0 = no contraction, 2 = left chain; the main library is 1): which form the reference's
 # `nvcc -O2` build emits cannot be checked in this image, so all three exist, are tested against the oracle with the matching
 # `contract`, and `_lib.set_fp_contract(mode)` / VLP3D_FP_CONTRACT selects one at run time.
-GEOM_SOURCES = ["abi.hip", "fps.hip", "fps_pruned.hip", "ball_query.hip", "ball_query_grid.hip", "interpolate.hip",
+GEOM_SOURCES = ["abi.hip", "fps.hip", "fps_pruned.hip", "ball_query.hip", "ball_query_grid.hip", "ball_query_sorted.hip", "interpolate.hip",
                 "gather_group.hip"]
 GEOM_MODES = (0, 2)
 

@@ -16,11 +16,12 @@
 // Tie order (the reference's reduction tree prefers the smallest (bitrev_P(k mod P), k) among equal values), skip
 // rule (|p|^2 <= 1e-3 -> never a candidate) and the fp32 distance expression are those of the dense kernel.
 #include "common.h"
+#include "fps_cells.h"
 
 namespace {
 
-constexpr int CELL_BITS = 5;                  // per axis
-constexpr int NCELL = 1 << (3 * CELL_BITS);   // 32768 Morton cells per scene
+using vlp3d_cells::BBOX_PARTS;
+using vlp3d_cells::NCELL;
 
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
@@ -60,13 +61,8 @@ __device__ __forceinline__ float vmin(float a, float b) {
   return r;
 }
 
-__device__ __forceinline__ unsigned spread5(unsigned v) {  // 5 bits -> every third bit
-  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
-}
-
 // ---- pre-pass 1: bounding boxes of BBOX_PARTS chunks of every scene, histogram cleared ------------------------
 // (one workgroup per scene read its 480 KB alone: 16.5 us; the cell kernel folds the partial boxes itself)
-constexpr int BBOX_PARTS = 16;
 __global__ __launch_bounds__(256) void fps_bbox_kernel(const float *__restrict__ xyz, int N, float *__restrict__ bbox,
                                                        int *__restrict__ hist) {
   __shared__ float red[6][4];
@@ -101,7 +97,7 @@ __global__ __launch_bounds__(256) void fps_bbox_kernel(const float *__restrict__
 // ---- pre-pass 2: Morton cell of every point + histogram ------------------------------------------------------
 __global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__ xyz, int N,
                                                        const float *__restrict__ bbox, int *__restrict__ cellid,
-                                                       int *__restrict__ hist) {
+                                                       int *__restrict__ hist, float *__restrict__ box) {
   __shared__ float bb[6];
   const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
   if (threadIdx.x < 6) {
@@ -111,51 +107,16 @@ __global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__
       v = threadIdx.x < 3 ? fminf(v, o) : fmaxf(v, o);
     }
     bb[threadIdx.x] = v;
+    if (blockIdx.x == 0) box[b * 8 + threadIdx.x] = v;  // the folded box, kept for the sorted ball query
   }
   __syncthreads();
   if (k >= N) return;
   const float *p = xyz + ((size_t)b * N + k) * 3;
-  unsigned q[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float lo = bb[a], hi = bb[3 + a];
-    const float ext = hi - lo;
-    float t = ext > 0.f ? (p[a] - lo) / ext * 32.f : 0.f;
-    int c = (int)t;
-    c = c < 0 ? 0 : (c > 31 ? 31 : c);  // also catches NaN -> 0
-    q[a] = (unsigned)c;
-  }
-#ifdef VLP3D_FPS_MORTON
-  const int cell = (int)(spread5(q[0]) | (spread5(q[1]) << 1) | (spread5(q[2]) << 2));
-#else
-  // position of the cell on the 3-D Hilbert curve (Skilling's transpose form, 5 bits per axis): consecutive cells are face
-  // neighbours, so a slot (64 consecutive sorted points) never straddles one of the Z-order curve's long jumps and its
-  // bounding box is tighter — fewer (slot, wave) pairs pass the pruning test per iteration.  Only the ORDER of the cells
-  // changes; histogram, scan and scatter are the same.
-  {
-    const unsigned M = 1u << (CELL_BITS - 1);
-    for (unsigned Q = M; Q > 1; Q >>= 1) {
-      const unsigned P = Q - 1;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        if (q[a] & Q) {
-          q[0] ^= P;
-        } else {
-          const unsigned t = (q[0] ^ q[a]) & P;
-          q[0] ^= t;
-          q[a] ^= t;
-        }
-      }
-    }
-    q[1] ^= q[0];
-    q[2] ^= q[1];
-    unsigned t = 0;
-    for (unsigned Q = M; Q > 1; Q >>= 1)
-      if (q[2] & Q) t ^= Q - 1;
-    q[0] ^= t; q[1] ^= t; q[2] ^= t;
-  }
-  const int cell = (int)((spread5(q[0]) << 2) | (spread5(q[1]) << 1) | spread5(q[2]));
-#endif
+  // 32 x 32 x 32 cells over the bounding box, numbered along the 3-D Hilbert curve (fps_cells.h: the sorted ball query of
+  // csrc/ball_query_sorted.hip evaluates the same two functions for its cell ranges)
+  const int cell = vlp3d_cells::cell_code((unsigned)vlp3d_cells::axis_cell(p[0], bb[0], bb[3]),
+                                          (unsigned)vlp3d_cells::axis_cell(p[1], bb[1], bb[4]),
+                                          (unsigned)vlp3d_cells::axis_cell(p[2], bb[2], bb[5]));
   cellid[(size_t)b * N + k] = cell;
   atomicAdd(hist + (size_t)b * NCELL + cell, 1);
 }
@@ -708,14 +669,11 @@ int reference_log2_block(int n) {
   return p;
 }
 
-size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
 }  // namespace
 
 extern "C" long long vlp3d_fps_workspace_bytes(int B, int N) {
   if (B < 1 || N < 1) return 0;
-  return (long long)(align256((size_t)B * N * 16) + align256((size_t)B * N * 4) * 2 + align256((size_t)B * NCELL * 4) +
-                     align256((size_t)B * BBOX_PARTS * 6 * 4));
+  return vlp3d_cells::workspace_bytes(B, N);
 }
 
 // Pruned FPS.  workspace: vlp3d_fps_workspace_bytes(B, N) bytes of device scratch (contents ignored / clobbered).
@@ -759,19 +717,13 @@ static int fps_pruned_launch(const float *xyz, int B, int N, int m, void *worksp
     return VLP3D_EINVAL;
   if (m == 0) return VLP3D_OK;
   hipStream_t s = (hipStream_t)stream;
-  char *w = (char *)workspace;
-  float4 *pts = (float4 *)w;
-  w += align256((size_t)B * N * 16);
-  int *perm = (int *)w;
-  w += align256((size_t)B * N * 4);
-  int *cellid = (int *)w;
-  w += align256((size_t)B * N * 4);
-  int *hist = (int *)w;
-  w += align256((size_t)B * NCELL * 4);
-  float *bbox = (float *)w;
+  const vlp3d_cells::Workspace ws = vlp3d_cells::workspace_layout(workspace, B, N);
+  float4 *pts = ws.pts;
+  int *perm = ws.perm, *cellid = ws.cellid, *hist = ws.hist;
+  float *bbox = ws.bbox;
   const dim3 gridN((N + 255) / 256, B);
   hipLaunchKernelGGL(fps_bbox_kernel, dim3(BBOX_PARTS, B), dim3(256), 0, s, xyz, N, bbox, hist);
-  hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist);
+  hipLaunchKernelGGL(fps_cell_kernel, gridN, dim3(256), 0, s, xyz, N, bbox, cellid, hist, ws.box);
   hipLaunchKernelGGL(fps_scan_kernel, dim3(B), dim3(1024), 0, s, hist);
   hipLaunchKernelGGL(fps_scatter_kernel, gridN, dim3(256), 0, s, xyz, N, cellid, hist, pts, perm);
   const int nslots = (N + 1023) / 1024;

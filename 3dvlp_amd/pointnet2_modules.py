@@ -69,9 +69,20 @@ class PointnetSAModuleVotes(nn.Module):
         """The weight-independent part of the layer: (inds, new_xyz, ball-query idx).  Depends only on the
         coordinates, so a step driver may compute it ahead of time on a side stream (grounding_step.py).
         fps_ordered: xyz is the previous level's new_xyz (FPS samples in sampling order) — a hint, see _lib."""
-        inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, fps_ordered)
-        new_xyz = sa_fused_ext.gather_xyz(xyz.contiguous(), inds)  # == gather_operation on the transposed cloud, one launch
-        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        N = xyz.shape[1]
+        if (xyz.is_cuda and xyz.dtype == torch.float32 and not fps_ordered and sa_fused_ext.FPS_PRUNED_MIN_N <= N <=
+                sa_fused_ext.FPS_PRUNED_MAX_N and N >= sa_fused_ext.BALL_QUERY_GRID_MIN_N and self.npoint is not None
+                and os.environ.get("VLP3D_BALL_QUERY") in (None, "", "sorted")):
+            # a large first level (SA1: 40 000 points): ONE spatial sort serves both — the pruned FPS builds it, the ball
+            # query reads it again (csrc/ball_query_sorted.hip: one launch instead of the grid form's six); same outputs
+            xyz = xyz.contiguous()
+            inds, ws = sa_fused_ext.furthest_point_sampling(xyz, self.npoint, "pruned", return_workspace=True)
+            new_xyz = sa_fused_ext.gather_xyz(xyz, inds)
+            idx = sa_fused_ext.ball_query_sorted(new_xyz, xyz, self.radius, self.nsample, ws)
+        else:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint, fps_ordered)
+            new_xyz = sa_fused_ext.gather_xyz(xyz.contiguous(), inds)  # == gather_operation on the transposed cloud, one launch
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         if self._use_compact(xyz):
             cmap = tuple(sa_fused_ext.sa_compact(idx, xyz.shape[1]))                       # + (rowptr, crow)
             if self.csr_backward and os.environ.get("VLP3D_SA_CSR", "1") != "0":

@@ -100,8 +100,11 @@ class _Chain(Function):
         # (refreshed once per forward pass; a weight seen for the first time is served from the next pass on — this pass then
         # walks the unfused entry points), or a transposed copy made here when no PreparedWeights context is open
         ctx.wt = None
+        ctx.prep = ctx.prep_pass = None
         if FUSED_BACKWARD:
             prep = row_mlp._ACTIVE
+            if prep is not None:
+                ctx.prep, ctx.prep_pass = prep, prep.pass_id
             ctx.wt = [(prep.lookup(tensors[st[0]]) if prep is not None else tensors[st[0]].detach().t().contiguous())
                       if max(tensors[st[0]].shape) <= 256 else None for st in spec]
         ctx.spec = spec
@@ -167,6 +170,8 @@ class _Chain(Function):
             that are tiles of the chain above t_0."""
             if ctx.wt is None or pend[top + 1] is None or not ctx.needs_input_grad[2]:
                 return False
+            if ctx.prep is not None and not ctx.prep.current(ctx.prep_pass):
+                return False   # the K-major copies were refreshed by a later forward pass: walk the unfused stages (W itself)
             for s in range(top + 1):
                 st = spec[s]
                 N, K = tensors[st[0]].shape

@@ -36,16 +36,24 @@ class PreparedWeights:
     so a stale copy can never be read.  The parameters keep the reference's (N, K[, 1]) storage and state_dict layout."""
 
     def __init__(self):
-        self.entries = {}   # data_ptr -> (weight view (Np, K), K-major copy (K, Np))
+        self.entries = {}   # (data_ptr, shape) -> (weight view (Np, K), K-major copy (K, Np))
         self.fresh = set()  # registered since the last refresh: not served yet
+        self.pass_id = 0    # number of refreshes: the copies handed out belong to THIS pass (ADVICE r3)
 
     def __enter__(self):
         global _ACTIVE
         if self.entries:
             _ext.transpose_batch([t for _, t in self.entries.values()], [w for w, _ in self.entries.values()])
         self.fresh.clear()
+        self.pass_id += 1
         self._outer, _ACTIVE = _ACTIVE, self
         return self
+
+    def current(self, pass_id):
+        """True while the copies served in pass `pass_id` have not been overwritten by a later refresh: a backward that kept
+        them (row_chain: ctx.wt) must check this before multiplying — after another forward pass under this context (gradient
+        accumulation, an interleaved eval forward after a parameter update) they hold the transposes of the NEW weights."""
+        return pass_id == self.pass_id
 
     def __exit__(self, *exc):
         global _ACTIVE
@@ -54,9 +62,9 @@ class PreparedWeights:
 
     def lookup(self, w):
         """w: contiguous (Np, K) view of a parameter's storage -> its K-major copy (K, Np), or None (then registered)."""
-        key = w.data_ptr()
+        key = (w.data_ptr(), tuple(w.shape))   # two views of one address with different shapes are two entries
         e = self.entries.get(key)
-        if e is None or e[0].shape != w.shape:
+        if e is None:
             self.entries[key] = (w.detach(), torch.zeros((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device))
             self.fresh.add(key)
             return None

@@ -533,6 +533,12 @@ int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
  * iteration (phases: (B, 8) u64, entries 0..4: slot test | slot updates | wave candidate | LDS + barrier | block reduction). */
 int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
                              unsigned long long *phases, void *stream);
+/* vlp3d_ball_query_sorted: ball_query (same output as vlp3d_ball_query, ball_query_gpu.cu:14-59) in ONE launch on the spatial
+ * sort that vlp3d_furthest_point_sampling_pruned has just left in `fps_workspace` for the SAME xyz (same B, N; the workspace
+ * not overwritten since): the backbone's first level samples its centres from the cloud it then queries.  xyz is read only by
+ * the per-centre fall-back (more than 2048 candidates or 1024 hits in one neighbourhood). */
+int vlp3d_ball_query_sorted(const float *new_xyz, const float *xyz, int B, int N, int M, float radius, int nsample,
+                            const void *fps_workspace, long long fps_workspace_bytes, int *idx, void *stream);
 /* vlp3d_fps_pruned_trace: diagnostic form.  variant 0 = the register-resident kernel (round 4, N <= 65536), 1 = the round-3
  * kernel (running minima in LDS / L2); lds_slots >= 0 overrides the number of slots per wave whose points live in LDS
  * (0..12 / 0..9); with `phases` (any non-null pointer for variant 0) the profiling instantiation runs; with `trace` too (u32,

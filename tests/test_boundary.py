@@ -56,3 +56,25 @@ def test_reference_style_checkpoint_round_trip():
     sd["lang.fc.weight"] = torch.zeros(3)
     res = b.load_state_dict(sd, strict=False)
     assert res.missing_keys == [] and res.unexpected_keys == ["lang.fc.weight"]
+
+
+def test_prepared_weights_keys_and_pass_counter():
+    """Host logic of row_mlp.PreparedWeights: entries are keyed by (address, shape) — two views of one address
+    with different shapes do not evict each other — and every refresh advances `pass_id`, which a backward that kept
+    K-major copies (row_chain) compares before it multiplies by them."""
+    import importlib
+    import torch
+    rm = importlib.import_module("3dvlp_amd.row_mlp")
+    prep = rm.PreparedWeights()
+    w = torch.randn(64, 32)
+    a, b = w.view(64, 32), w.view(32, 64)
+    assert prep.lookup(a) is None and prep.lookup(b) is None          # first sight: registered, not served
+    assert len(prep.entries) == 2 and len(prep.fresh) == 2
+    assert prep.lookup(a) is None                                     # still not served inside the registering pass
+    prep.fresh.clear()                                                # (what __enter__ does after the batched transpose)
+    ta, tb = prep.lookup(a), prep.lookup(b)
+    assert ta.shape == (32, 64) and tb.shape == (64, 32) and ta.data_ptr() != tb.data_ptr()
+    p0 = prep.pass_id
+    assert prep.current(p0)
+    prep.pass_id += 1                                                 # a later forward pass refreshed the copies
+    assert not prep.current(p0) and prep.current(p0 + 1)

@@ -607,6 +607,31 @@ def test_ball_query_grid_equals_scan_and_oracle(ext, kind, B, N, M, r, ns):
     b = ext.ball_query(dev(new_xyz), dev(xyz), r, ns, "scan").cpu().numpy()
     assert (a == b).all()
     assert (a == orc.ball_query(new_xyz, xyz, r, ns)).all()
+    # the one-launch form on the pruned FPS's spatial sort of the same cloud (csrc/ball_query_sorted.hip)
+    t = dev(xyz)
+    _, ws = ext.furthest_point_sampling(t, 16, "pruned", return_workspace=True)
+    c = ext.ball_query_sorted(dev(new_xyz), t, r, ns, ws).cpu().numpy()
+    assert (c == b).all(), (kind, int((c != b).sum()))
+
+
+@pytest.mark.parametrize("contract_mode", [0, 1, 2], indirect=True)
+def test_ball_query_sorted_all_contract_modes_and_odd_shapes(ext, contract_mode):
+    """vlp3d_ball_query_sorted == the oracle in every fp contract mode on a lattice whose radius equals lattice distances
+    (hits decided by the last bit), with M not a multiple of the four centres a workgroup owns, nsample above the usual 64,
+    flat clouds (zero extent on an axis) and a 70 000-point cloud (two lane-slots in the FPS, same workspace layout)."""
+    synth = importlib.import_module("3dvlp_amd.synth")
+    k = contract_mode
+    rng = np.random.default_rng(9 + k)
+    lat = np.stack([_lattice(rng, 22, 0.1, -1.05), _lattice(rng, 22, 0.1, 0.35)])
+    flat = rng.uniform(0, 3, (2, 9000, 3)).astype(np.float32)
+    flat[..., 2] = 1.25
+    big = np.stack([synth.make_scene(7000, 70000)["xyz"]])
+    for xyz, M, r, ns in ((lat, 301, 0.3, 16), (lat, 64, 0.2, 100), (flat, 130, 0.15, 32), (big, 1000, 0.2, 64)):
+        new_xyz = xyz[:, rng.permutation(xyz.shape[1])[:M]].copy()
+        t = dev(xyz)
+        _, ws = ext.furthest_point_sampling(t, 8, "pruned", return_workspace=True)
+        got = ext.ball_query_sorted(dev(new_xyz), t, r, ns, ws).cpu().numpy()
+        assert (got == orc.ball_query(new_xyz, xyz, r, ns, contract=k)).all(), (xyz.shape, M, r, ns, k)
 
 
 @pytest.mark.gpu

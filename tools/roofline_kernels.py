@@ -17,10 +17,13 @@ pc = batch["point_clouds"]
 xyz, feat_pm = pc[..., :3].contiguous(), pc[..., 3:].contiguous()
 B, n, m = 8, 40000, 2048
 for _ in range(3):
-    inds = pu.furthest_point_sample(xyz, m)
+    inds, fps_ws = ext.furthest_point_sampling(xyz, m, "pruned", return_workspace=True)
 new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 for _ in range(3):
-    idx = pu.ball_query(0.2, 64, xyz, new_xyz)
+    idx = ext.ball_query_sorted(new_xyz, xyz, 0.2, 64, fps_ws)   # the step's form: one launch on the FPS's spatial sort
+for _ in range(3):
+    idx_grid = ext.ball_query(new_xyz, xyz, 0.2, 64, "grid")      # round 3's six-launch form, for comparison
+assert torch.equal(idx, idx_grid)
 rowptr_, crow_ = ext.sa_compact(idx, n)   # the bf16 step evaluates the distinct rows only
 cm = (crow_, rowptr_, B * m)
 for bf in (1, 0):

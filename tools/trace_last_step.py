@@ -9,7 +9,8 @@ path = sys.argv[1]
 f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel" in r["Kernel_Name"] or "fps_kernel<1024" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel" in r["Kernel_Name"] or "fps_pruned_reg_kernel" in r["Kernel_Name"]
+         or "fps_kernel<1024" in r["Kernel_Name"]]
 pairs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if marks[i + 1] - marks[i] > 200]
 a, b = pairs[-1]  # the last FULL step (bench.py launches the FPS kernel alone again in its per-kernel section)
 win = rows[a:b]
