@@ -59,6 +59,9 @@ SIGNATURES = {
     "vlp3d_rowdot_fwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_rowdot_bwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp],
     "vlp3d_sa_stat_slabs": [ctypes.c_longlong],
+    "vlp3d_sa_last_supported": [_i, _i],
+    "vlp3d_sa_last_dgrad": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "vlp3d_sa_last_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_bn_fold": [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _i, _vp, _vp],
     "vlp3d_sa_bn_bwd_consts": [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "vlp3d_sa_pool_tstats_slabs": [ctypes.c_longlong],

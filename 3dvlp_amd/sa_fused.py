@@ -23,6 +23,13 @@ WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a wo
 
 
 WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 16))  # cap on the partial-dW slabs of one launch
+# last layer's backward without its pre-activation (csrc/sa_last.hip, bf16 storage): "1" on, "0" the round-3 pooled loaders
+SA_LAST = os.environ.get("VLP3D_SA_LAST", "1") != "0"
+# padded rows (B * npoint * nsample) from which the new kernels are used (SA1: 1 048 576, SA2: 262 144, SA3: 65 536, SA4 / vote
+# aggregation: 32 768): measured in the step, see backward()
+SA_LAST_WGRAD_MIN_ROWS = int(os.environ.get("VLP3D_SA_LAST_WGRAD_MIN_ROWS", 500000))
+SA_LAST_DGRAD_MIN_ROWS = int(os.environ.get("VLP3D_SA_LAST_DGRAD_MIN_ROWS", 65536))
+SA_LAST_WBLOCKS = int(os.environ.get("VLP3D_SA_LAST_WBLOCKS", 512))  # most workgroups (= slabs) of the last layer's wgrad
 
 
 def _wgrad_blocks(R, cout, K):
@@ -102,7 +109,7 @@ class FusedSAMLP(Function):
         out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
         sel = torch.empty((B * M, cout[2]), dtype=torch.uint8, device=dev)
         _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf, cm[1])
-        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet)
+        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet, Wd[2])
         ctx.cm = cm
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
         return out
@@ -113,7 +120,7 @@ class FusedSAMLP(Function):
         cm = ctx.cm
         sv = ctx.saved_tensors
         xyz, new_xyz, idx, feat_pm, out, sel = sv[:6]
-        Y, vecs, WTs, gam, bet = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21]
+        Y, vecs, WTs, gam, bet, W3d = sv[6:9], sv[9:12], sv[12:15], sv[15:18], sv[18:21], sv[21]
         dev = xyz.device
         dP = dP.contiguous().float()
         need = ctx.needs_input_grad  # xyz, new_xyz, idx, feat_pm, ...
@@ -153,18 +160,41 @@ class FusedSAMLP(Function):
             dW = torch.empty((cout[l], Ks[l]) if (l > 0 or q is None) else (cout[0], C + 3), dtype=torch.float32, device=dev)
             nblk = _wgrad_blocks(R, cout[l], Ks[l])
             part = torch.empty((nblk, cout[l], Ks[l]), dtype=torch.float32, device=dev)
-            if l > 0:
+            last = (l == 2 and bf and SA_LAST and Ks[2] == cout[1] and int(_ext.load().vlp3d_sa_last_supported(cout[1], cout[2])))
+            # the last layer WITHOUT its pre-activation Y3 (csrc/sa_last.hip): dW3 slabs / the masked gradient of layer 2 from Y2
+            # and the balls' pooled rows alone.  Per kernel, where it is faster than the pooled loaders of csrc/sa_mlp.hip
+            # (in-step, cfg2: weight gradient SA1 153 -> 43 us; input gradient SA1 99 -> 52, SA2 93 -> 61, SA3 46 -> 39; the small
+            # modules are dominated by the per-workgroup constants — W3^T, Q = W3^T diag(beta) W3 — and keep the old kernels)
+            last_w = last and R >= SA_LAST_WGRAD_MIN_ROWS
+            last_d = last and R >= SA_LAST_DGRAD_MIN_ROWS
+            if l > 0 and last_w:
+                tiles = (R // 32) if cm[0] is None else max(1, R // 32 // 2)
+                nb3 = max(16, min(SA_LAST_WBLOCKS, tiles // 8, int(WGRAD_SLAB_MB * 2 ** 20 / (cout[2] * cout[1] * 4))))
+                part = torch.empty((nb3, cout[2], cout[1]), dtype=torch.float32, device=dev)
+                _ext.call("vlp3d_sa_last_wgrad", Y[1], vecs[1], c5, W3d, gsel, sel, B * M, S, cout[1], cout[2], part, nb3, *cm)
+                if q is not None:
+                    q.add(part, nb3, dW, cout[2] * cout[1], cout[1], cout[1])
+                else:
+                    torch.sum(part, dim=0, out=dW)
+                dparams[6] = dW.view(cout[2], cout[1], 1, 1)
+            elif l > 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[l], R, cout[l], c5, 0, Y[l - 1], Ks[l], vecs[l - 1][0],
                           vecs[l - 1][1], None, None, None, None, 0, 0, 0, 0, 1.0, dW, part, nblk,
                           *(pool if G is None else (None, None, 0)), bf, int(q is not None), *cm)
                 if q is not None:  # after the launch: the queue may sum right away
                     q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[l] * Ks[l], Ks[l], Ks[l])
                 dparams[3 * l] = dW.view(cout[l], Ks[l], 1, 1)
+            if l > 0 and last_d:
+                Gp = torch.empty((R, cout[1]), dtype=dt, device=dev)
+                _ext.call("vlp3d_sa_last_dgrad", Y[1], vecs[1], c5, WTs[2], gsel, sel, B * M, S, cout[1], cout[2], Gp, t[1], tn[1],
+                          *cm)
+                G = Gp
+            elif l > 0:
                 Gp = torch.empty((R, cout[l - 1]), dtype=dt, device=dev)
                 _ext.call("vlp3d_sa_bwd_layer", G, Y[l], R, cout[l], c5, WTs[l], cout[l - 1], Y[l - 1], vecs[l - 1], Gp,
                           t[l - 1], *(pool if G is None else (None, None, 0)), bf, *cm)
                 G = Gp
-            else:
+            if l == 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
                           feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None), *cm)
                 if q is not None:  # the batched slab sum writes [xyz | features] columns directly

@@ -141,7 +141,8 @@ def pmc_traffic():
 
 STAMPED = ("vlp3d_sa_fwd_gather", "vlp3d_sa_fwd_layer", "vlp3d_sa_bwd_layer", "vlp3d_sa_bwd_gather", "vlp3d_sa_wgrad",
            "vlp3d_sa_pool", "vlp3d_sdpa_fwd", "vlp3d_sdpa_bwd", "vlp3d_relation_bias_fwd", "vlp3d_relation_bias_bwd",
-           "vlp3d_furthest_point_sampling_pruned", "vlp3d_ball_query_grid", "vlp3d_ball_query_sorted", "vlp3d_rows_chain", "vlp3d_rows_chain_bwd",
+           "vlp3d_furthest_point_sampling_pruned", "vlp3d_ball_query_grid", "vlp3d_ball_query_sorted", "vlp3d_sa_last_dgrad",
+           "vlp3d_sa_last_wgrad", "vlp3d_rows_chain", "vlp3d_rows_chain_bwd",
            "vlp3d_probe_empty")
 
 
@@ -200,6 +201,8 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
 
     def entry(kernel, key, bound, work, peak, unit, ms_iso, ms_step, **extra):
         ms = ms_step if ms_step is not None else ms_iso
+        if ms is None:   # the entry point is not part of this configuration's step (e.g. csrc/sa_last.hip under --dtype fp32)
+            return {"kernel": kernel, "ms": None}
         ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
         d = {"kernel": kernel, "bound": bound, "achieved": round(ach, 4), "peak": round(peak, 4), "unit": unit,
              "frac": round(ach / peak, 4), "traffic": None, "ms": round(ms, 4), "ms_isolated": round(ms_iso, 4) if ms_iso else None,
@@ -262,7 +265,8 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     wg_bytes = B * n * C * 4 + rows * (2 * cout * esz + 16)
     # SA1 layer-3 input gradient (vlp3d_sa_bwd_layer, pooled-gradient loader + mask epilogue): Y3 and Y2 rows once, G2 written,
     # the row map, the pooled gradient / arg-max tensors of the balls
-    dg_bytes = rows * (128 * esz + 2 * 64 * esz + 16) + B * m * 128 * 5
+    dg_bytes = rows * (2 * 64 * esz + 16) + B * m * 128 * 5          # since round 4: Y2 in, G2 out, row map, pooled rows (no Y3)
+    wg3_bytes = rows * (64 * esz + 16) + B * m * 128 * 5 + 512 * 128 * 64 * 4   # Y2, row map, pooled rows, the dW3 slabs
     rel_pairs = B * 256 * 256
     rel_flops = rel_pairs * 2.0 * (4 * 32 + 32 * 32 + 32 * 4) * 3   # forward recomputation + both backward products per pair
     gname = ("row_gemm_lds_kernel<64,GATHER,STORE>" if bf else "row_gemm_kernel<float,64,GATHER,STORE>")
@@ -277,10 +281,15 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
                     "rows; `achieved` counts the bytes of the rows evaluated" % (100.0 * rows / R)) if compact else "padded rows"),
         entry("wgrad_kernel<bf16,...,GATHER> SA1 layer 1 weight gradient (dY1^T x gathered rows)", "wgrad_kernel", "hbm", wg_bytes,
               PEAK_HBM_GBS, "GB/s", None, in_step("vlp3d_sa_wgrad", is_sa1), algorithmic_bytes=wg_bytes),
-        entry("row_gemm_lds_kernel<64,BNBWD,MASK> SA1 layer 3 input gradient (pooled-gradient loader, 128->64 GEMM, ReLU mask + "
-              "BN-backward sums)", "row_gemm_lds_kernel<64, 2, 1>", "hbm", dg_bytes, PEAK_HBM_GBS, "GB/s", None,
-              in_step("vlp3d_sa_bwd_layer", lambda a: a[0] == R and a[1] == 128), algorithmic_bytes=dg_bytes,
-              note="runs beside the side stream's deferred weight-gradient graph (GroundingStep: split backward)"),
+        entry("sa_last_dgrad_kernel<64,128> SA1 layer 3 input gradient WITHOUT the layer's pre-activation (csrc/sa_last.hip: "
+              "(k1 G) W3 - w (W3^T alpha + a2 Q), ReLU mask + BN-backward sums; round 3: row_gemm_lds_kernel<64,BNBWD,MASK> read Y3)",
+              "sa_last_dgrad", "hbm", dg_bytes, PEAK_HBM_GBS, "GB/s", None,
+              in_step("vlp3d_sa_last_dgrad", lambda a: a[0] == B * m and a[2] == 64), algorithmic_bytes=dg_bytes,
+              note="Y2 rows once, G2 written, the row map, the balls' pooled gradient / arg-max rows; runs beside the side stream's "
+                   "deferred weight-gradient graph"),
+        entry("sa_last_wgrad_kernel<64,128> SA1 layer 3 weight gradient WITHOUT Y3 ((k1 G)^T a2 - alpha (x) s - diag(beta) W3 M)",
+              "sa_last_wgrad", "hbm", wg3_bytes, PEAK_HBM_GBS, "GB/s", None,
+              in_step("vlp3d_sa_last_wgrad", lambda a: a[0] == B * m and a[2] == 64), algorithmic_bytes=wg3_bytes),
     ]
     cands = [c for c in cands if c["ms"] is not None]
     Rm = BL * 256

@@ -533,6 +533,22 @@ int vlp3d_probe_fma_f32(int iters, int blocks, float *sink, void *stream);
  * iteration (phases: (B, 8) u64, entries 0..4: slot test | slot updates | wave candidate | LDS + barrier | block reduction). */
 int vlp3d_fps_pruned_profile(const float *xyz, int B, int N, int m, void *workspace, long long workspace_bytes, int *idx,
                              unsigned long long *phases, void *stream);
+/* Backward of the LAST layer of a grouped MLP without its pre-activation (csrc/sa_last.hip; bf16 storage; (C2, C3) one of
+ * (64,128), (128,256), (128,128): vlp3d_sa_last_supported).  With a2 = relu(bn(Y2)) the layer's input and y3 = a2 W3^T, the
+ * BatchNorm backward dY3 = k1 G - w (alpha + beta y3) (G: the pooled gradient at the arg-max sample of each ball) gives
+ * dA2 = (k1 G) W3 - w (W3^T alpha + a2 W3^T diag(beta) W3) and dW3 = (k1 G)^T a2 - alpha (x) sum w a2 - diag(beta) W3 sum w a2^T a2:
+ * neither reads Y3.  vlp3d_sa_last_dgrad == vlp3d_sa_bwd_layer(G = NULL, pool_g, pool_sel): G2 (rows x C2) bf16 masked gradient
+ * of the layer below + nslab [sum g | sum g yhat] slabs (unused ones zeroed); vlp3d_sa_last_wgrad == vlp3d_sa_wgrad(...pool...)
+ * with defer_reduce: `blocks` slabs (C3 x C2) fp32 in `partials`, to be summed.  gsel / sel: vlp3d_sa_pool_tstats / vlp3d_sa_pool;
+ * vec2: vlp3d_sa_bn_fold of the layer below; bn5: vlp3d_sa_bn_bwd_consts of the last layer; W3T (C2 x C3) / W3 (C3 x C2) bf16:
+ * vlp3d_sa_prep_weights; crow / rowptr / nballs: the compact row map or NULL / NULL / 0 (dense rows r = bm * S + s). */
+int vlp3d_sa_last_supported(int C2, int C3);
+int vlp3d_sa_last_dgrad(const void *Y2, const float *vec2, const float *bn5, const void *W3T, const float *gsel,
+                        const unsigned char *sel, long long BM, int S, int C2, int C3, void *G2, double *tstats, int nslab,
+                        const void *crow, const int *rowptr, int nballs, void *stream);
+int vlp3d_sa_last_wgrad(const void *Y2, const float *vec2, const float *bn5, const void *W3, const float *gsel,
+                        const unsigned char *sel, long long BM, int S, int C2, int C3, float *partials, int blocks,
+                        const void *crow, const int *rowptr, int nballs, void *stream);
 /* vlp3d_ball_query_sorted: ball_query (same output as vlp3d_ball_query, ball_query_gpu.cu:14-59) in ONE launch on the spatial
  * sort that vlp3d_furthest_point_sampling_pruned has just left in `fps_workspace` for the SAME xyz (same B, N; the workspace
  * not overwritten since): the backbone's first level samples its centres from the cloud it then queries.  xyz is read only by

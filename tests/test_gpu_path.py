@@ -1468,6 +1468,58 @@ def test_sa_compact_rows_equal_dense_rows(S, need_xyz_grad, C):
             assert _rel(bb, ba) < 1e-4
 
 
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("mlp,S", [([60, 64, 64, 128], 64), ([128, 128, 128, 256], 32), ([256, 128, 128, 128], 16)])
+def test_sa_last_layer_backward_without_its_preactivation(mlp, S, compact):
+    """csrc/sa_last.hip (round 4): the last layer's weight gradient and the masked gradient of the layer below from Y2 and the
+    balls' pooled rows alone — dY3 = k1 G - w (alpha + beta y3) with y3 = a2 W3^T, so dA2 = (k1 G) W3 - w (W3^T alpha + a2 Q) and
+    dW3 = (k1 G)^T a2 - alpha (x) s - diag(beta) W3 M — against (i) the round-3 kernels that read Y3 (VLP3D_SA_LAST=0: the same bf16
+    configuration, so the two differ by bf16 rounding of different intermediates) and (ii) the exact-fp32 configuration: every
+    parameter gradient and the feature gradient of the new form are as close to fp32 as the old form's (x 1.25 + 2e-3), on
+    compact and on padded rows, for the three (C2, C3) shapes of the path."""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    sf = importlib.import_module("3dvlp_amd.sa_fused")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    B, N, C = 2, 8192, mlp[0]
+    xyz = torch.from_numpy(np.stack([synth.make_scene(40 + i, N)["xyz"] for i in range(B)]).astype(np.float32)).cuda()
+    torch.manual_seed(3)
+    feats0 = torch.randn(B, C, N, device="cuda")
+    runs = {}
+    g = None
+    for name, dtype, last in (("fp32", None, False), ("old", torch.bfloat16, False), ("new", torch.bfloat16, True)):
+        torch.manual_seed(5)
+        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=S, mlp=list(mlp), use_xyz=True, normalize_xyz=True).cuda().train()
+        m.mlp_dtype, m.compact = dtype, compact
+        with torch.no_grad():   # BatchNorm parameters away from (1, 0): alpha / beta / k1 all matter
+            for bn in [l.bn.bn for l in m.mlp_module]:
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+        f = feats0.clone().requires_grad_(True)
+        old = sf.SA_LAST, sf.SA_LAST_WGRAD_MIN_ROWS, sf.SA_LAST_DGRAD_MIN_ROWS
+        sf.SA_LAST, sf.SA_LAST_WGRAD_MIN_ROWS, sf.SA_LAST_DGRAD_MIN_ROWS = last, 0, 0   # both kernels whatever the module's size
+        try:
+            _, out, _ = m(xyz, f)
+            if g is None:
+                g = torch.randn_like(out)
+            out.backward(g)
+        finally:
+            sf.SA_LAST, sf.SA_LAST_WGRAD_MIN_ROWS, sf.SA_LAST_DGRAD_MIN_ROWS = old
+        runs[name] = dict(out=out.detach(), df=f.grad, params=[p.grad for p in m.parameters()])
+    assert _rel(runs["new"]["out"], runs["old"]["out"]) < 1e-6          # same forward
+    names = [n for n, _ in m.named_parameters()]
+    worst = 0.0
+    for n, pf, po, pn in zip(names, runs["fp32"]["params"], runs["old"]["params"], runs["new"]["params"]):
+        eo, en = _rel(po, pf), _rel(pn, pf)
+        worst = max(worst, en)
+        assert en <= 1.25 * eo + 2e-3, (n, en, eo)
+        assert _rel(pn, po) < 3e-2, (n, _rel(pn, po))
+    eo, en = _rel(runs["old"]["df"], runs["fp32"]["df"]), _rel(runs["new"]["df"], runs["fp32"]["df"])
+    assert en <= 1.25 * eo + 2e-3, (en, eo)
+    diff = max(_rel(pn, po) for po, pn in zip(runs["old"]["params"], runs["new"]["params"]))
+    print(f"mlp {mlp} S {S} compact {compact}: worst parameter-gradient error vs fp32 {worst:.2e}; d(features) old {eo:.2e} new {en:.2e}; "
+          f"new vs old: parameters {diff:.2e}, d(features) {_rel(runs['new']['df'], runs['old']['df']):.2e}")
+
+
 @pytest.mark.parametrize("name,B,N", [("cfg3: 32 scenes per GPU", 32, 40000), ("cfg5: 80 000-point scenes", 4, 80000)])
 def test_step_runs_at_other_baseline_shapes(name, B, N):
     """BASELINE.json cfg3 (batch 32 per GPU, epoch >= 50: OCC/OSC active) and cfg5 (80k-point scenes: pruned FPS with two slot
