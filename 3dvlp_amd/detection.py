@@ -373,7 +373,7 @@ class ProposalModule(nn.Module):
 
 class _RelationBias(torch.autograd.Function):
     """Fused pairwise-geometry bias MLP (csrc/relation_bias.hip): centre (B,K,3), packed params -> (B,4,K,K)."""
-    SLAB_BLOCKS = int(os.environ.get("VLP3D_RELBIAS_BLOCKS", 512))  # workgroups of the backward kernel (one partial-gradient slab each)
+    SLAB_BLOCKS = int(os.environ.get("VLP3D_RELBIAS_BLOCKS", 256))  # workgroups of the backward kernel (one partial-gradient slab each)
 
     @staticmethod
     def forward(ctx, centre, params):
