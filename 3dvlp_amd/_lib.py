@@ -131,6 +131,8 @@ SIGNATURES = {
     "vlp3d_bce_logits_blocks": [ctypes.c_longlong],
     "vlp3d_bce_logits_fwd": [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
     "vlp3d_bce_logits_bwd": [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
+    "vlp3d_loss_tail_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
+    "vlp3d_loss_tail_bwd": [_vp, _i, _i, _f, _f, _f, _vp, _vp],
     "vlp3d_cap_attn_fwd": [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp],
     "vlp3d_cap_attn_bwd": [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "vlp3d_vocab_ce_splits": [ctypes.c_longlong, _i],

@@ -296,6 +296,37 @@ __global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float *__rest
   dx[i] = g[0] * inv_rows * (1.0f / (1.0f + __expf(-xv)) - t[i]);
 }
 
+// Tail of get_joint_loss (loss_joint.py:204-223): the weighted total of the fused core + the optional terms, in the reference's
+// fp32 order — ((core + w_lang lang) + (w_lcon lcon + w_icon icon)) + answer + caption — and the contrastive sum it reports.
+__global__ void loss_tail_fwd_kernel(const float *__restrict__ core, const float *__restrict__ lang, const float *__restrict__ lcon,
+                                     const float *__restrict__ icon, const float *__restrict__ ans, const float *__restrict__ cap,
+                                     float w_lang, float w_lcon, float w_icon, float *__restrict__ total) {
+  if (threadIdx.x != 0) return;
+  float loss = core[0];
+  if (lang) loss = loss + w_lang * lang[0];
+  float con = 0.f;
+  if (lcon && icon) {
+    con = w_lcon * lcon[0] + w_icon * icon[0];
+    loss = loss + con;
+  }
+  if (ans) loss = loss + ans[0];
+  if (cap) loss = loss + cap[0];
+  total[0] = loss;
+  total[1] = con;
+}
+// d[0..n) = g e_at (the core's vector of reported scalars: only its total carries gradient), then [g, w_lang g, w_lcon g, w_icon g]
+__global__ void loss_tail_bwd_kernel(const float *__restrict__ g, int n, int at, float w_lang, float w_lcon, float w_icon,
+                                     float *__restrict__ d) {
+  const float gv = g[0];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = i == at ? gv : 0.f;
+  if (threadIdx.x == 0) {
+    d[n] = gv;
+    d[n + 1] = w_lang * gv;
+    d[n + 2] = w_lcon * gv;
+    d[n + 3] = w_icon * gv;
+  }
+}
+
 }  // namespace
 
 extern "C" int vlp3d_roi_split(const float *out, int ld, long long R, int NH, int NC, float res_scale, float *hreg, float *hres,
@@ -745,6 +776,25 @@ extern "C" int vlp3d_bce_logits_bwd(const float *x, const float *t, long long ro
   const long long n = rows * cols;
   hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, t, n, g,
                      1.0f / (float)rows, dx);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+
+// total[0] = ((core[0] + w_lang lang[0]) + (w_lcon lcon[0] + w_icon icon[0])) + ans[0] + cap[0], total[1] = the contrastive sum;
+// lang / (lcon, icon) / ans / cap may be NULL (term absent).  One launch instead of the op-by-op scalar arithmetic.
+extern "C" int vlp3d_loss_tail_fwd(const float *core, const float *lang, const float *lcon, const float *icon, const float *ans,
+                                   const float *cap, float w_lang, float w_lcon, float w_icon, float *total, void *stream) {
+  if (!core || !total || ((lcon == nullptr) != (icon == nullptr))) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, core, lang, lcon, icon, ans, cap, w_lang,
+                     w_lcon, w_icon, total);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+// d (n + 4): d[0..n) = g[0] e_at (cotangent of the core's n reported scalars, total at index `at`), d[n..] = g[0] * [1, w_lang,
+// w_lcon, w_icon] (answer / caption, language, the two contrastive terms).
+extern "C" int vlp3d_loss_tail_bwd(const float *g, int n, int at, float w_lang, float w_lcon, float w_icon, float *d, void *stream) {
+  if (!g || !d || n < 1 || at < 0 || at >= n) return VLP3D_EINVAL;
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, n, at, w_lang, w_lcon, w_icon, d);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

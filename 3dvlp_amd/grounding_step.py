@@ -418,7 +418,18 @@ class GroundingStep:
                     self._check_no_stale_grads()
                     queue = qctx.__enter__()
                     # (retain_graph: without it the engine releases the saved tensors of the nodes it did NOT run as well)
-                    torch.autograd.backward([loss], inputs=head + boundary, retain_graph=True)
+                    # autograd.grad, not backward(inputs=...): the latter calls retain_grad() on the non-leaf boundary, whose
+                    # hook CLONES d(sa2_features) into a channel-major .grad here and, firing again in the second pass, adds
+                    # the cotangent onto it; the reshape in front of SA2's backward then copies it back to point-major rows:
+                    # three 8 MB element-wise launches (13 + 6 + 19 us in the kernel trace) for nothing.  The captured
+                    # gradient is the engine's own buffer — point-major like its producers (SA3 / FP2 input gradients).
+                    # The head parameters' gradients come back as tensors and are attached by hand (no AccumulateGrad clone
+                    # of the shared zero gradients of biases in front of a train-mode BatchNorm either).
+                    grads = torch.autograd.grad([loss], head + boundary, retain_graph=True, allow_unused=True)
+                    for p_, g_ in zip(head, grads[:len(head)]):
+                        p_.grad = g_
+                    bgrads = list(grads[len(head):])
+                    del grads
                 head_ids = {id(p) for p in head}
                 tail = [p for p in self.model.parameters() if id(p) not in head_ids]
                 rh, rt = self.bucket.param_range(head), self.bucket.param_range([p for p in tail if p.requires_grad])
@@ -432,10 +443,9 @@ class GroundingStep:
                     # not run on the main stream beside this graph (it would read buffers the flush is still filling)
                     self.bucket.collect_subset(head)
                 with torch.cuda.graph(self._gM2):
-                    torch.autograd.backward(boundary, [t.grad for t in boundary])
+                    torch.autograd.backward(boundary, bgrads)
                     qctx.__exit__(None, None, None)
-                    for t in boundary:
-                        t.grad = None
+                    del bgrads
                     self._static_out = _detached(out)
                     self.bucket.collect_subset(tail)
                     add_norm.advance(self.device)

@@ -264,16 +264,54 @@ class _JointLossCore(Function):
         ctx.save_for_backward(*diff, *fixed, sums, assign, objlab, rowinfo)
         ctx.dims, ctx.cfg = dims, cfg
         ctx.mark_non_differentiable(assign, objlab, rowinfo)
+        ctx.set_materialize_grads(False)   # no zero-filled cotangents for the three index outputs (three fill launches)
         return out, assign, objlab, rowinfo
 
     @staticmethod
     def backward(ctx, gout, _a, _b, _c):
         sv = ctx.saved_tensors
         diff, fixed, (sums, assign, objlab, rowinfo) = sv[:10], sv[10:25], sv[25:]
+        if gout is None:
+            return (None,) * 12
         g = gout[9:10].contiguous()  # only the total is differentiable (the components are reporting values)
         grads = [torch.empty_like(t) for t in diff]
         _ext.call("vlp3d_joint_loss_bwd", *diff, *fixed, *ctx.dims, *ctx.cfg, sums, assign, objlab, rowinfo, g, *grads)
         return (*grads, None, None)
+
+
+class _LossTail(Function):
+    """loss_joint.py:204-223 in one launch each way (csrc/glue.hip loss_tail): total = ((core[9] + 0.3 lang) + (0.5 lang_con +
+    2.5 iou_con)) + answer + caption, in the reference's fp32 order; returns (total, con_loss).  Replaces select / mul / mul /
+    add / add forward and ones-like / mul / mul / zeros / copy backward (SelectBackward of the core's total included).  Absent
+    terms are None.  con_loss is a reporting value: a cotangent on it is not supported (raises)."""
+
+    W_LANG, W_LCON, W_ICON = 0.3, 0.5, 2.5
+
+    @staticmethod
+    def forward(ctx, core, lang, lcon, icon, ans, cap):
+        f = lambda t: None if t is None else t.reshape(1).float()   # views: 0-dim / (1,) fp32 scalars on the device
+        total = torch.empty((2,), dtype=torch.float32, device=core.device)
+        _ext.call("vlp3d_loss_tail_fwd", core[9:10], f(lang), f(lcon), f(icon), f(ans), f(cap), _LossTail.W_LANG,
+                  _LossTail.W_LCON, _LossTail.W_ICON, total)
+        ctx.shapes = [None if t is None else (t.shape, t.dtype) for t in (lang, lcon, icon, ans, cap)]
+        ctx.ncore = core.shape[0]
+        ctx.set_materialize_grads(False)
+        return total[0], total[1]
+
+    @staticmethod
+    def backward(ctx, g, g_con):
+        if g_con is not None:
+            raise RuntimeError("_LossTail: con_loss is a reporting value (take 0.5 * lang_con_loss + 2.5 * iou_con_loss instead)")
+        if g is None:
+            return (None,) * 6
+        n = ctx.ncore
+        d = torch.empty((n + 4,), dtype=torch.float32, device=g.device)
+        _ext.call("vlp3d_loss_tail_bwd", g.reshape(1).contiguous().float(), n, 9, _LossTail.W_LANG, _LossTail.W_LCON,
+                  _LossTail.W_ICON, d)
+        outs = [d[:n]]   # d(core) = g e_9
+        for sh, k in zip(ctx.shapes, (1, 2, 3, 0, 0)):
+            outs.append(None if sh is None else d[n + k].reshape(sh[0]).to(sh[1]))
+        return tuple(outs)
 
 
 def _labels(data_dict, config, device):
@@ -375,7 +413,8 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
         cl = torch.empty((B, L, K), dtype=torch.float32, device=dev)
         _ext.call("vlp3d_joint_loss_report", assign, objlab, rowinfo, B, K, L, a64, l64, msk, cl)
         d["object_assignment"], d["objectness_label"], d["objectness_mask"], d["cluster_labels"] = a64, l64, msk, cl
-        loss = out[9]
+        loss = None   # the total is formed by _LossTail below, from the core's vector and the optional terms
+        core_out = out
     elif impl == "torch":
         vote_loss = compute_vote_loss(d)
         obj_loss, label, mask, assign = compute_objectness_loss(d)
@@ -394,28 +433,44 @@ def get_joint_loss(args, data_dict, device=None, config=None, weights=None, pad_
         loss = 10 * (vote_loss + 0.1 * obj_loss + box_loss) + w_ref * ref_loss + w_diou * d["diou_loss"]
     else:
         raise ValueError(impl)
+    fused_tail = impl == "hip"
+    terms = dict(lang=None, lcon=None, icon=None, ans=None, cap=None)
     if use_lang_classifier and "lang_scores" in d and "object_cat_list" in d:
         d["lang_loss"] = compute_lang_classification_loss(d)
-        loss = loss + 0.3 * d["lang_loss"]
+        terms["lang"] = d["lang_loss"]
     else:
         d["lang_loss"] = _const("zero", lambda: torch.zeros(()), dev)
     if getattr(args, "use_con", False):
         if d["epoch"] >= 50:
-            d["con_loss"] = 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]   # loss_joint.py:208
-            loss = loss + d["con_loss"]
+            terms["lcon"], terms["icon"] = d["lang_con_loss"], d["iou_con_loss"]
+            if not fused_tail:
+                d["con_loss"] = 0.5 * d["lang_con_loss"] + 2.5 * d["iou_con_loss"]   # loss_joint.py:208
     else:
         d["con_loss"] = torch.zeros(1)
     if getattr(args, "use_answer", False):  # loss_joint.py:118-119, 219-220 (the ScanQA + grounding joint task, cfg5)
         d["answer_loss"] = compute_answer_classification_loss(d)
-        loss = loss + d["answer_loss"]
+        terms["ans"] = d["answer_loss"]
     zero_keys = ["ori_loss", "ori_acc", "dist_loss", "mlm_loss"]
     if caption:  # loss_joint.py:122-127, 222-223 (Scan2Cap head on the shared proposal features, BASELINE cfg4)
         from .caption import compute_cap_loss
         d["cap_loss"], d["cap_acc"] = compute_cap_loss(d, pad_token_id=0 if pad_token_id is None else pad_token_id)
-        loss = loss + d["cap_loss"]
+        terms["cap"] = d["cap_loss"]
     else:
         zero_keys += ["cap_loss", "cap_acc"]
     for k in zero_keys:
         d[k] = _const("zero", lambda: torch.zeros(()), dev)
+    if fused_tail:   # one launch each way for the sum (and its backward, SelectBackward of the core's total included)
+        loss, con = _LossTail.apply(core_out, terms["lang"], terms["lcon"], terms["icon"], terms["ans"], terms["cap"])
+        if terms["lcon"] is not None:
+            d["con_loss"] = con.detach()
+    else:       # loss_joint.py:204-223, op by op
+        if terms["lang"] is not None:
+            loss = loss + 0.3 * terms["lang"]
+        if terms["lcon"] is not None:
+            loss = loss + d["con_loss"]
+        if terms["ans"] is not None:
+            loss = loss + terms["ans"]
+        if terms["cap"] is not None:
+            loss = loss + terms["cap"]
     d["loss"] = loss
     return d

@@ -714,6 +714,14 @@ int vlp3d_bce_logits_fwd(const float *x, const float *t, long long rows, long lo
 int vlp3d_bce_logits_bwd(const float *x, const float *t, long long rows, long long cols, const float *g, float *dx,
                          void *stream);
 
+/* Tail of get_joint_loss (lib/loss_helper/loss_joint.py:204-223) in one launch, the reference's fp32 order:
+ * total[0] = ((core[0] + w_lang lang[0]) + (w_lcon lcon[0] + w_icon icon[0])) + ans[0] + cap[0]; total[1] = the contrastive sum
+ * (data_dict["con_loss"]); `core` points at the core's total.  lang / (lcon and icon) / ans / cap may be NULL.
+ * bwd: d (n + 4): d[0..n) = g[0] e_at (the core's n reported scalars, total at index at), d[n..] = g[0] [1, w_lang, w_lcon, w_icon]. */
+int vlp3d_loss_tail_fwd(const float *core, const float *lang, const float *lcon, const float *icon, const float *ans,
+                        const float *cap, float w_lang, float w_lcon, float w_icon, float *total, void *stream);
+int vlp3d_loss_tail_bwd(const float *g, int n, int at, float w_lang, float w_lcon, float w_icon, float *d, void *stream);
+
 /* Training-time scene augmentation on the device (csrc/augment.hip) — lib/joint/dataset.py:653-690 with
  * utils/utils_fn.py:28-142 (flip_augment, rotate_augment, scale_augment, translate) and
  * data/scannet/model_util_scannet.py:48-80 (rotate_aligned_boxes_along_axis); votes recomputed AFTER augmentation.

@@ -226,3 +226,41 @@ def test_fused_joint_loss_equals_torch_form(shape, epoch, coin, NH):
                                         use_con=True)["loss"]
             fd, an = (lp - lm) / (2 * h), float((g * u).sum())
             assert abs(fd - an) <= 2e-4 * n + 1e-7, (k, fd, an, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("present", [(1, 1, 1, 1), (0, 1, 0, 0), (1, 0, 0, 1), (0, 0, 1, 0), (0, 0, 0, 0)])
+def test_loss_tail_is_the_op_by_op_sum(present):
+    """csrc/glue.hip loss_tail (one launch each way) vs loss_joint.py:204-223 written out with framework ops: the total and the
+    reported contrastive sum bit for bit (same fp32 order), the cotangents of every term, absent terms left out."""
+    L = importlib.import_module("3dvlp_amd.losses")
+    g = torch.Generator().manual_seed(sum(present))
+    core = (torch.randn(15, generator=g) * 7).cuda().requires_grad_(True)
+    mk = lambda on: (torch.randn((), generator=g) * 3).cuda().requires_grad_(True) if on else None
+    lang, con, ans, cap = mk(present[0]), present[1], mk(present[2]), mk(present[3])
+    lcon, icon = (mk(1), mk(1)) if con else (None, None)
+    total, csum = L._LossTail.apply(core, lang, lcon, icon, ans, cap)
+    ref = core[9]
+    if lang is not None:
+        ref = ref + 0.3 * lang
+    if con:
+        rc = 0.5 * lcon + 2.5 * icon
+        ref = ref + rc
+        assert torch.equal(csum.detach(), rc.detach())
+    if ans is not None:
+        ref = ref + ans
+    if cap is not None:
+        ref = ref + cap
+    assert torch.equal(total.detach(), ref.detach())
+    leaves = [t for t in (core, lang, lcon, icon, ans, cap) if t is not None]
+    up = torch.tensor(1.7, device="cuda")
+    ga = torch.autograd.grad(total, leaves, up)
+    gb = torch.autograd.grad(ref, leaves, up)
+    for a, b in zip(ga, gb):
+        assert a.shape == b.shape and torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        if con:
+            t2, c2 = L._LossTail.apply(core, lang, lcon, icon, ans, cap)
+            c2.backward()
+        else:
+            raise RuntimeError("no contrastive term in this case")

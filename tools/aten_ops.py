@@ -1,55 +1,63 @@
-"""Which aten ops (= framework kernels) does one step issue, and from which source line of the package?  A TorchDispatchMode
-logs every non-view aten call of one eager bf16 step with the innermost 3dvlp_amd frame (autograd-engine ops have no Python
-frame: they are attributed to the backward Function that is running, when there is one).
-    python tools/aten_ops.py"""
-import collections
+"""List the framework (ATen / runtime-copy) launches of ONE eager training step with the operator and the autograd node that
+issued each: the launches the step driver's graphs replay besides this library's own kernels.  Usage (GPU box):
+python tools/aten_ops.py > gpurun_out/aten_ops.txt"""
 import importlib
 import os
 import sys
-import traceback
 
 import torch
-from torch.utils._python_dispatch import TorchDispatchMode
+from torch.profiler import ProfilerActivity, profile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gs = importlib.import_module("3dvlp_amd.grounding_step")
 synth = importlib.import_module("3dvlp_amd.synth")
 
-VIEWS = {"view", "reshape", "_unsafe_view", "t", "transpose", "permute", "expand", "slice", "select", "unsqueeze", "squeeze",
-         "as_strided", "detach", "alias", "split", "split_with_sizes", "unbind", "_reshape_alias", "empty", "empty_like",
-         "empty_strided", "new_empty", "new_empty_strided", "set_", "is_pinned", "_local_scalar_dense", "lift_fresh", "unfold",
-         "narrow", "chunk", "stride", "sym_size", "sym_stride", "sym_numel", "is_contiguous", "dim", "size", "storage_offset"}
-
-
-class Log(TorchDispatchMode):
-    def __init__(self):
-        super().__init__()
-        self.cnt = collections.Counter()
-
-    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-        name = func.overloadpacket.__name__
-        if name not in VIEWS:
-            where = "(autograd engine)"
-            for fr in reversed(traceback.extract_stack()):
-                if "3dvlp_amd/" in fr.filename and "tools/" not in fr.filename:
-                    where = f"{fr.filename.split('3dvlp_amd/')[-1]}:{fr.lineno} {fr.name}"
-                    break
-            shapes = [tuple(a.shape) for a in args if torch.is_tensor(a)][:2]
-            self.cnt[(where, name, str(shapes))] += 1
-        return func(*args, **(kwargs or {}))
-
-
 dev = torch.device("cuda:0")
-step = gs.GroundingStep(dev, sa_dtype=torch.bfloat16, use_graph=False, pipeline=True)
+step = gs.GroundingStep(dev, epoch=50, lr=1e-3, sa_dtype=torch.bfloat16, use_graph=False, pipeline=True, seed=0)
 batch = gs.batch_to_device(synth.make_batch(0, 8, 40000, 8), dev)
-for _ in range(3):
-    step.run(batch)
+for _ in range(2):
+    step.run(batch, batch)
 torch.cuda.synchronize()
-log = Log()
-with log:
-    step.run(batch)
-torch.cuda.synchronize()
-print("aten calls (non-view):", sum(log.cnt.values()))
-for (where, name, shapes), n in sorted(log.cnt.items()):
-    print(f"{n:3d}x  {where:60s} {name:28s} {shapes}")
+split = len(sys.argv) > 1 and sys.argv[1] == "split"   # the second pass of the step driver's split backward only
+if split:
+    _ext = importlib.import_module("3dvlp_amd._lib")
+    step.bucket.zero()
+    loss, out = step.forward_loss(batch, step.model.backbone_net.compute_geometry(step._coords(batch)))
+    boundary = [out["sa2_features"]]
+    head = [p for n, p in step.model.named_parameters()
+            if p.requires_grad and not n.startswith(("backbone_net.sa1.", "backbone_net.sa2."))]
+    with _ext.deferred_slab_reduce():
+        torch.autograd.backward([loss], inputs=head + boundary, retain_graph=True)
+        g = boundary[0].grad
+        print("sa2_features", tuple(boundary[0].shape), boundary[0].stride(), "grad", tuple(g.shape), g.stride())
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            torch.autograd.backward(boundary, [g])
+            torch.cuda.synchronize()
+else:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        step.run(batch, batch)
+        torch.cuda.synchronize()
+
+
+def chain(e):
+    names = []
+    while e is not None:
+        names.append(e.name)
+        e = e.cpu_parent
+    return names
+
+
+n = 0
+for e in sorted(prof.events(), key=lambda e: e.time_range.start):
+    if not e.kernels:
+        continue
+    ks = [k.name for k in e.kernels]
+    if not any(("at::native" in k or "rocclr" in k or "Memcpy" in k or "Memset" in k) for k in ks):
+        continue
+    if any(c.kernels for c in e.cpu_children):   # report the innermost operator only
+        continue
+    ch = chain(e)
+    node = next((c for c in ch if "evaluate_function" in c or c.endswith("Backward") or "Function" in c), "")
+    n += 1
+    print(f"{n:3d} {e.name:28s} shapes={str(e.input_shapes)[:70]:70s} <- {' < '.join(ch[1:4])[:110]}  [{node[:60]}]")

@@ -25,3 +25,20 @@ print(f"step wall {1e-6 * (t1 - t0):.3f} ms, kernel busy {1e-6 * busy:.3f} ms, {
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"{1e-6 * d:8.3f} ms {n:5d}x  {k[:120]}")
+
+# per-queue view of the same step: span and busy time of every HIP queue, and (with a third argument) the launches in order
+qs = defaultdict(list)
+for r in win:
+    qs[r["Queue_Id"]].append(r)
+print("\nqueues of this step (offsets from the step's first launch):")
+for q, rs in sorted(qs.items(), key=lambda kv: -len(kv[1])):
+    s = min(int(r["Start_Timestamp"]) for r in rs) - t0
+    e = max(int(r["End_Timestamp"]) for r in rs) - t0
+    bz = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)
+    print(f"  queue {q}: {len(rs):4d} launches, first start {1e-6 * s:.3f} ms, last end {1e-6 * e:.3f} ms, busy {1e-6 * bz:.3f} ms")
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as out:
+        for r in win:
+            s = int(r["Start_Timestamp"]) - t0
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            out.write(f"{1e-3 * s:9.1f} us  +{1e-3 * d:7.1f} us  q{r['Queue_Id']}  {r['Kernel_Name'][:110]}\n")
