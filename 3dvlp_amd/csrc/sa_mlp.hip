@@ -223,6 +223,22 @@ struct Mma<bf16, NCT> {
 // Per-column reductions of a workgroup -> its own slab [blockIdx.x][2][COUT] (fp64).  Thousands of waves adding
 // atomically into the same 2*COUT addresses serialise at the memory side (that alone cost ~0.4 ms per launch at
 // R = 1 M); the consumers (bn_fold / bn_bwd_consts) sum the slabs instead.
+// slabs the consumers of a statistics buffer sum for R rows = the UNCAPPED grid of the row kernels (vlp3d_sa_stat_slabs)
+__host__ __device__ inline unsigned stat_slabs_of(long long R) {
+  const long long blocks = (R / 32 + 3) / 4;
+  const long long cap = 256 * 4;  // a few persistent workgroups per CU; each wave walks tiles with a grid stride
+  return (unsigned)(blocks < cap ? blocks : cap);
+}
+// A launch with FEWER workgroups than slabs (launch_lds_c caps the grid at one workgroup per CU when only one fits): the
+// slabs nobody owns are zeroed by the workgroups that run, slab s by workgroup s mod gridDim.x.
+template <int COUT>
+__device__ __forceinline__ void zero_unowned_slabs(double *__restrict__ slabs, long long R) {
+  const unsigned want = stat_slabs_of(R);
+  for (unsigned sl = blockIdx.x + gridDim.x; sl < want; sl += gridDim.x) {
+    double *slab = slabs + (size_t)sl * 2 * COUT;
+    for (int i = threadIdx.x; i < 2 * COUT; i += 256) slab[i] = 0.0;
+  }
+}
 template <int COUT>
 __device__ __forceinline__ void block_stats_to_slab(const double (&s1)[COUT / 32], const double (&s2)[COUT / 32],
                                                     double *__restrict__ slabs, int r, int half, int wave) {
@@ -666,7 +682,9 @@ __device__ __forceinline__ uint4 finish8(const RowGemmArgs &a, int2 meta, const 
 
 // second launch bound: at least two waves per SIMD for outputs up to 160 columns (the register allocator otherwise
 // settles just above 256 registers for <128, BNBWD, MASK>: one wave per SIMD on a latency-bound kernel)
-template <int COUT, int LOADER, int EPI>
+// WIDE (GATHER only): the instantiation for 160 < K <= 288 — its own kernel so that the 144 operand registers of the wide
+// loader and the prefetch registers of the narrow one never meet in one allocation (together: 315 spilled VGPRs)
+template <int COUT, int LOADER, int EPI, bool WIDE = false>
 __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kernel(RowGemmArgs a) {
   typedef bf16 T;
   constexpr int NCT = COUT / 32;
@@ -689,6 +707,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
     if (EPI == STORE || EPI == MASK) {
       double *slab = ((EPI == STORE) ? a.stats : a.tstats) + (size_t)blockIdx.x * 2 * COUT;
       for (int i = threadIdx.x; i < 2 * COUT; i += 256) slab[i] = 0.0;
+      zero_unowned_slabs<COUT>((EPI == STORE) ? a.stats : a.tstats, a.R);
     }
     return;
   }
@@ -716,9 +735,11 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   // is a per-tile scalar and the ball-query indices of the NEXT tile are fetched while this one is computed.  The
   // generic path below spends three integer divisions per chunk (27 per lane and tile at SA1 — more VALU work than
   // the tile's matrix products) and waits for idx before it can ask for a feature row.
-  constexpr int MAXCH = 10;  // chunks per lane: 32 * (K/8) / 64, K <= 160
+  constexpr int MAXCH = WIDE ? 1 : 10;  // chunks per lane: 32 * (K/8) / 64, K <= 160
   constexpr bool GATHER_PREFETCH = VLP3D_GATHER_PREFETCH != 0;
-  const bool fastg = LOADER == GATHER && (a.tile_scene || compact) && nch <= 64 * MAXCH;
+  const bool fastg = !WIDE && LOADER == GATHER && (a.tile_scene || compact) && nch <= 64 * MAXCH;
+  constexpr int WIDECH = WIDE ? 18 : 1;  // K <= 288
+  const bool wideg = WIDE;               // launch_lds_c checked the shape
   int crow[MAXCH], ccol[MAXCH], pidx[MAXCH];
   const long long tile_step = (long long)gridDim.x * 4;
   // The gathered rows of tile t+1 are requested BEFORE tile t goes to the matrix cores and stay in registers (gv0 / gv1)
@@ -869,10 +890,56 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         }
       }
     }
+    // WIDE gather (160 < K <= 288: the 256-channel levels SA3 / SA4 / vote aggregation, 17 chunks per lane): these layers have
+    // one or two tiles per wave, so there is no steady state to prefetch into — what counts is the number of dependent round
+    // trips inside ONE tile.  The generic loop below takes the chunks four at a time, each batch waiting for its row-map word
+    // and then for its feature row: ten round trips, ~25 us per tile in the step.  Here all row-map words are requested first,
+    // then all feature rows (144 registers — the accumulators are not live yet): two round trips.
+    if constexpr (LOADER == GATHER && WIDE) {
+      const int scene = compact ? 0 : row0 / (a.M * a.S);
+      const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
+      int wp[WIDECH];
+#pragma unroll
+      for (int u = 0; u < WIDECH; ++u) {
+        const int c = min(64 * u + lane, nch - 1);
+        wp[u] = src_index((long long)row0 + (int)(((unsigned)c * kc_inv) >> 20));
+      }
+      const int wprow = src_index((long long)row0 + (lane & 31));
+      float4 w0[WIDECH], w1[WIDECH];
+#pragma unroll
+      for (int u = 0; u < WIDECH; ++u) {
+        const int c = min(64 * u + lane, nch - 1);
+        const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
+        const float *fr = fbase + (long long)wp[u] * a.C;
+        w0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w1[u] = w0[u];
+        if (64 * u < nch) {  // uniform
+          if (col < a.C) w0[u] = ld4(fr + col);
+          if (col + 4 < a.C) w1[u] = ld4(fr + col + 4);
+        }
+      }
+      const float *wq = a.xyz + ((long long)scene * a.N + wprow) * 3;
+      const float wx = wq[0], wy = wq[1], wz = wq[2];
+#pragma unroll
+      for (int u = 0; u < WIDECH; ++u) {
+        const int c = 64 * u + lane;
+        if (c < nch) {
+          const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
+          *reinterpret_cast<uint4 *>(sA + rw * ldw + col) = pack8(w0[u], w1[u]);
+        }
+      }
+      if (lane < 32) {  // [dx, dy, dz, 0] columns: same wave, later instruction — lands after the chunk writes above
+        const int rr = row0 + lane;
+        const int bm = compact ? (sMeta[lane].x >> 8) : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
+        const float *cc3 = a.new_xyz + (long long)bm * 3;
+        *reinterpret_cast<uint2 *>(sA + lane * ldw + a.C) =
+            pack4(make_float4((wx - cc3[0]) * inv_radius, (wy - cc3[1]) * inv_radius, (wz - cc3[2]) * inv_radius, 0.f));
+      }
+    }
     // chunks in flight per lane: four, two for the wide BN-backward kernels (their raw operands — y, g or the pooled
     // triple — at four in flight pushed the kernel over 256 registers: one wave per SIMD)
     constexpr int UB = (LOADER == BNBWD && COUT >= 128) ? 2 : 4;
-    for (int c0 = 0; !fastg && !(PF && hoist_pf) && c0 < nch; c0 += (HOIST ? 64 * UB : 256)) {
+    for (int c0 = 0; !fastg && !wideg && !(PF && hoist_pf) && c0 < nch; c0 += (HOIST ? 64 * UB : 256)) {
       if (HOIST) {
         Raw8 raw[UB];
         const int kshift = __builtin_ctz(kc);  // kc | 64: a power of two (shifts instead of eight divisions per batch)
@@ -984,6 +1051,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
   }
 
   if (EPI == STORE || EPI == MASK) block_stats_to_slab<COUT>(s1, s2, (EPI == STORE) ? a.stats : a.tstats, r, half, wave);
+  if (EPI == STORE || EPI == MASK) zero_unowned_slabs<COUT>((EPI == STORE) ? a.stats : a.tstats, a.R);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1860,11 +1928,7 @@ void set_pool(RowGemmArgs &a, const float *pool_g, const unsigned char *pool_sel
     if ((1 << sh) == pool_S) a.pool_shift = sh;
 }
 
-unsigned grid_tiles(long long R) {
-  const long long blocks = (R / 32 + 3) / 4;
-  const long long cap = 256 * 4;  // a few persistent workgroups per CU; each wave walks tiles with a grid stride
-  return (unsigned)(blocks < cap ? blocks : cap);
-}
+unsigned grid_tiles(long long R) { return stat_slabs_of(R); }
 
 template <typename T, int LOADER, int EPI>
 int launch_row_gemm_t(int cout, const RowGemmArgs &a, hipStream_t s) {
@@ -1889,12 +1953,23 @@ int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
   const size_t lds_static = (EPI == SCATTER) ? 0 : sizeof(double) * 4 * 2 * COUT;  // block_stats_to_slab
   if (lds + lds_static > 160 * 1024) return VLP3D_EINVAL;
   auto kern = row_gemm_lds_kernel<COUT, LOADER, EPI>;
+  if constexpr (LOADER == GATHER && EPI == STORE && COUT == 128) {
+    // the 256-channel levels (K = 272): all row-map words, then all feature rows of a tile in flight at once
+    const int kc = a.K / 8;
+    if (32 * kc > 64 * 10 && 32 * kc <= 64 * 18 && kc <= 36 && a.C % 8 == 0 && (a.tile_scene || a.crow != nullptr))
+      kern = row_gemm_lds_kernel<COUT, LOADER, EPI, true>;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid_tiles(a.R)), dim3(256), lds, s, a);
+  // more than half a CU's LDS: ONE workgroup per CU is resident, and a second wave of workgroups would stage the weight again
+  // behind the first (SA3's gather layer, K = 272: 512 workgroups of one tile per wave took two rounds of ~25 us) — cap the grid
+  // at the CU count and let the waves stride over the tiles instead
+  unsigned grid = grid_tiles(a.R);
+  if (lds + lds_static > 80 * 1024 && grid > 256) grid = 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
