@@ -273,7 +273,7 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     sdpa_name = ("sdpa_fwd_lds_kernel (bf16 MFMA)" if bf else "sdpa_fwd_kernel<fp32 MFMA>")
     cands = [
         entry(gname + " SA1 layer 1 (gather + 135->64 GEMM + BN sums)",
-              "row_gemm_lds_kernel<64, 0, 0>" if bf else "row_gemm_kernel<float, 64, 0, 0>", "hbm", g_bytes,
+              "row_gemm_lds_kernel<64, 0, 0" if bf else "row_gemm_kernel<float, 64, 0, 0>", "hbm", g_bytes,
               PEAK_HBM_GBS, "GB/s", g_ms, in_step("vlp3d_sa_fwd_gather", is_sa1),
               mfma_TFLOPs=round(g_flops / (g_ms * 1e-3) / 1e12, 2), algorithmic_bytes=g_bytes, rows_evaluated=rows, rows_padded=R,
               padded_form_bytes=g_bytes_dense,
@@ -283,12 +283,12 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
               PEAK_HBM_GBS, "GB/s", None, in_step("vlp3d_sa_wgrad", is_sa1), algorithmic_bytes=wg_bytes),
         entry("sa_last_dgrad_kernel<64,128> SA1 layer 3 input gradient WITHOUT the layer's pre-activation (csrc/sa_last.hip: "
               "(k1 G) W3 - w (W3^T alpha + a2 Q), ReLU mask + BN-backward sums; round 3: row_gemm_lds_kernel<64,BNBWD,MASK> read Y3)",
-              "sa_last_dgrad", "hbm", dg_bytes, PEAK_HBM_GBS, "GB/s", None,
+              "sa_last_dgrad_kernel<64, 128>", "hbm", dg_bytes, PEAK_HBM_GBS, "GB/s", None,
               in_step("vlp3d_sa_last_dgrad", lambda a: a[0] == B * m and a[2] == 64), algorithmic_bytes=dg_bytes,
               note="Y2 rows once, G2 written, the row map, the balls' pooled gradient / arg-max rows; runs beside the side stream's "
                    "deferred weight-gradient graph"),
         entry("sa_last_wgrad_kernel<64,128> SA1 layer 3 weight gradient WITHOUT Y3 ((k1 G)^T a2 - alpha (x) s - diag(beta) W3 M)",
-              "sa_last_wgrad", "hbm", wg3_bytes, PEAK_HBM_GBS, "GB/s", None,
+              "sa_last_wgrad_kernel<64, 128>", "hbm", wg3_bytes, PEAK_HBM_GBS, "GB/s", None,
               in_step("vlp3d_sa_last_wgrad", lambda a: a[0] == B * m and a[2] == 64), algorithmic_bytes=wg3_bytes),
     ]
     cands = [c for c in cands if c["ms"] is not None]

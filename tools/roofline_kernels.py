@@ -57,6 +57,13 @@ for _ in range(3):
     ext.call("vlp3d_sa_bwd_layer", None, Y3, R, 128, c5_3, WT3, 64, Y2, vec2, G2, t2, gsel, sel, 64, 1, *cm)
     ext.call("vlp3d_sa_wgrad", G1, Y1, R, 64, c5_1, 1, None, 144, None, None, xyz, new_xyz, idx, feat_pm, n, m, 64, 132, 0.2,
              dW, part, nblk, None, None, 0, 1, 0, *cm)
+# round 4: the same layer's input / weight gradient WITHOUT its pre-activation (csrc/sa_last.hip): what the step runs at SA1
+W3 = (torch.randn(128, 64, device=dev) * 0.05).to(torch.bfloat16)
+nb3 = 512
+part3 = torch.empty((nb3, 128, 64), device=dev)
+for _ in range(3):
+    ext.call("vlp3d_sa_last_dgrad", Y2, vec2, c5_3, WT3, gsel, sel, B * m, 64, 64, 128, G2, t2, nslab, *cm)
+    ext.call("vlp3d_sa_last_wgrad", Y2, vec2, c5_3, W3, gsel, sel, B * m, 64, 64, 128, part3, nb3, *cm)
 q = torch.randn(64, 256, 128, device=dev)
 kc = torch.randn(64, 49, 128, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
