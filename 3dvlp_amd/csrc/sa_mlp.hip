@@ -69,6 +69,10 @@ struct RowGemmArgs {
   const int *idx;
   int N, M, S, C;
   float radius;
+  // GATHER, bf16 feature rows (the loader's / the previous level's bf16 copy): (B*N x ldf) bf16, ldf % 8 == 0, columns
+  // [C, ldf) zero; NULL = fp32 rows in feat_pm.  The LDS kernels then copy 16-byte chunks without a conversion.
+  const void *feat_bf;
+  int ldf;
   // BNRELU / BNBWD / PLAIN: source matrices (R x ldin)
   const void *Yin, *Gin;
   int ldin;
@@ -759,15 +763,24 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
     const int scene = compact ? 0 : row0 / (a.M * a.S);  // wave-uniform (R < 2^31); compact rows carry global point rows
     const float *fbase = a.feat_pm + (long long)scene * a.N * a.C;
     const float *xbase = a.xyz + (long long)scene * a.N * 3;
+    if (a.feat_bf != nullptr) {  // kernel-uniform: one 16-byte load per chunk, already bf16
+      const bf16 *bbase = reinterpret_cast<const bf16 *>(a.feat_bf) + (long long)scene * a.N * a.ldf;
 #pragma unroll
-    for (int u = 0; u < MAXCH; ++u) {
-      const float *fr = fbase + (long long)pidx[u] * a.C;
-      const int col = ccol[u];
-      gv0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      gv1[u] = gv0[u];
-      if (64 * u < nch) {  // uniform
-        if (col < a.C) gv0[u] = ld4(fr + col);
-        if (col + 4 < a.C) gv1[u] = ld4(fr + col + 4);
+      for (int u = 0; u < MAXCH; ++u) {
+        gv0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (64 * u < nch && ccol[u] < a.C) gv0[u] = *reinterpret_cast<const float4 *>(bbase + (long long)pidx[u] * a.ldf + ccol[u]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < MAXCH; ++u) {
+        const float *fr = fbase + (long long)pidx[u] * a.C;
+        const int col = ccol[u];
+        gv0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gv1[u] = gv0[u];
+        if (64 * u < nch) {  // uniform
+          if (col < a.C) gv0[u] = ld4(fr + col);
+          if (col + 4 < a.C) gv1[u] = ld4(fr + col + 4);
+        }
       }
     }
     const float *q = xbase + (long long)prow * 3;
@@ -777,7 +790,9 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
     const int row0 = (int)(tile * 32);
 #pragma unroll
     for (int u = 0; u < MAXCH; ++u)
-      if (64 * u + lane < nch) *reinterpret_cast<uint4 *>(sA + crow[u] * ldw + ccol[u]) = pack8(gv0[u], gv1[u]);
+      if (64 * u + lane < nch)
+        *reinterpret_cast<uint4 *>(sA + crow[u] * ldw + ccol[u]) =
+            a.feat_bf != nullptr ? *reinterpret_cast<const uint4 *>(&gv0[u]) : pack8(gv0[u], gv1[u]);
     if (lane < 32) {  // same wave, later instruction: lands after the chunk writes above
       const int rr = row0 + lane;
       const int bm = compact ? (sMeta[lane].x >> 8) : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
@@ -2073,6 +2088,11 @@ extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const
   RowGemmArgs a = {};
   a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feat_pm = feat_pm;
   a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
+  if (bf16_io & 2) {  // EXPERIMENT: feat_pm holds bf16 rows of (C + 7) & ~7 columns
+    a.feat_bf = feat_pm;
+    a.ldf = (C + 7) & ~7;
+    bf16_io = 1;
+  }
   a.W = W; a.K = K; a.R = (long long)B * M * S; a.Yout = Y; a.ldout = cout; a.stats = stats;
   a.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   if (crow) {

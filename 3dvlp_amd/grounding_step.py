@@ -91,6 +91,9 @@ def grounding_loss(d, config, args=None, impl=None, caption=False):
     return d["loss"]
 
 
+_MEAN_SIZE_CACHE = {}
+
+
 def prepare_batch(out, mean_size_arr=None):
     """Device batch (the reference's keys and dtypes) -> the same dict plus the KERNEL-READY forms of pure input data
     that the step would otherwise re-derive with a dozen small launches every iteration (loader work: it depends on the
@@ -100,17 +103,30 @@ def prepare_batch(out, mean_size_arr=None):
       (class2size, model_util_scannet.py:183-185; consumed by the DIoU loss and the contrast module);
       k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134);
       k/xyz, k/feat_pm — the cloud split into coordinates and point-major features (backbone_module.py:73-80 slices
-      and copies them inside forward: 173 MB per step at cfg2)."""
-    device = out["point_clouds"].device
+      and copies them inside forward: 173 MB per step at cfg2).  A batch that arrives as (k/xyz, k/feat_bf) —
+      input_pipeline.compress_cloud on the host — has no point_clouds: its features are expanded to fp32 here."""
+    device = (out["point_clouds"] if "point_clouds" in out else out["k/xyz"]).device
     out.setdefault("istrain", [1])
-    mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32,
-                           device=device)
+    # (cached per device: a pageable host -> device copy is SYNCHRONOUS — issued on the copy stream behind a batch's upload it
+    # blocked the host for the whole upload, 2.8 ms per step: tools/host_feed_timeline.py)
+    key = (str(device), None if mean_size_arr is None else id(mean_size_arr))
+    mean = _MEAN_SIZE_CACHE.get(key)
+    if mean is None:
+        mean = torch.as_tensor(synth.mean_size_arr() if mean_size_arr is None else mean_size_arr, dtype=torch.float32,
+                               device=device)
+        if mean_size_arr is None:
+            _MEAN_SIZE_CACHE[key] = mean
     out["k/vote_label_mask"] = out["vote_label_mask"].float()
     for k in ("heading_class_label", "size_class_label", "sem_cls_label", "lang_num"):
         if k in out:
             out["k/" + k] = out[k].to(torch.int32)
     out["k/ref_size"] = (mean[out["ref_size_class_label_list"]] + out["ref_size_residual_label_list"]).float().contiguous()
     out["k/lang_kv"] = out["lang_fea"][:, 1:].contiguous()
+    if "k/feat_bf" in out and "k/xyz" in out:
+        # the loader sent the cloud already split, its feature channels as bf16 (input_pipeline.compress_cloud: half the
+        # PCIe bytes of the step's largest input); expanded here, on the copy stream
+        out["k/feat_pm"] = out.pop("k/feat_bf").float()
+        return out
     pc = out["point_clouds"]
     if pc.size(-1) > 3:
         out["k/xyz"], out["k/feat_pm"] = pc[..., :3].contiguous(), pc[..., 3:].contiguous()
@@ -496,10 +512,20 @@ class GroundingStep:
 
     @staticmethod
     def _refill(static, batch):
+        """New values into the captured graphs' static inputs: ONE launch for all tensors that are plain device copies (~40
+        per batch: 40 `copy_` launches cost the host-fed step 0.1 ms of launch stream and 0.2 ms of host time)."""
+        dst, src = [], []
         for k, sv in static.items():
             v = batch[k]
             if torch.is_tensor(v) and sv.data_ptr() != v.data_ptr():
-                sv.copy_(v, non_blocking=True)
+                if (v.is_cuda and sv.is_cuda and v.dtype == sv.dtype and v.shape == sv.shape and v.is_contiguous()
+                        and sv.is_contiguous() and v.numel() > 0):
+                    dst.append(sv)
+                    src.append(v)
+                else:
+                    sv.copy_(v, non_blocking=True)
+        if dst:
+            _ext.copy_batch(dst, src)
 
     @staticmethod
     def _coords(batch):

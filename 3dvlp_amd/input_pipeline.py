@@ -13,6 +13,8 @@
 A 40 000-point cfg2 batch is 8 x 40 000 x 135 fp32 = 173 MB: ~3.5 ms of PCIe gen5 per step if not overlapped, against a
 ~9 ms step — overlapped it is free; bench.py --host-batches measures exactly that.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -60,6 +62,36 @@ class Prefetcher:
         buf.copy_(t)
         return buf
 
+    PACK_BELOW = 1 << 20   # bytes: tensors smaller than this travel in one packed upload
+
+    def _stage_all(self, host):
+        """-> ({key: pinned tensor or plain value} for the large tensors, (pinned byte buffer, layout) for the small ones).
+        A batch has ~45 tensors of which 3 carry 99 % of the bytes; 45 separate copies kept the command processor busy for
+        ~0.15 ms per step that the launch stream's dispatches waited for (tools/host_feed_timeline.py)."""
+        small, staged = [], {}
+        for k, v in host.items():
+            t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+            if torch.is_tensor(t) and not t.is_cuda and t.numel() > 0 and t.numel() * t.element_size() < self.PACK_BELOW \
+                    and os.environ.get("VLP3D_PREFETCH_PACK", "1") != "0":
+                small.append((k, t.contiguous()))
+            else:
+                staged[k] = self._stage(k, v)
+        if not small:
+            return staged, None
+        layout, total = [], 0
+        for k, t in small:
+            n = t.numel() * t.element_size()
+            layout.append((k, total, n, t.dtype, tuple(t.shape)))
+            total += (n + 255) & ~255
+        pool = self._pinned[self._flip]
+        buf = pool.get("__packed__")
+        if buf is None or buf.numel() < total:
+            buf = torch.empty((total,), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            pool["__packed__"] = buf
+        for (k, t), (_, off, n, _, _) in zip(small, layout):
+            buf[off:off + n].copy_(t.reshape(-1).view(torch.uint8))
+        return staged, (buf[:total], layout)
+
     def preload(self):
         try:
             host = next(self.loader)
@@ -69,20 +101,32 @@ class Prefetcher:
         used = self._flip
         if self._uploaded[used] is not None:
             self._uploaded[used].synchronize()  # the copies that read this staging set two batches ago have finished
-        staged = {k: self._stage(k, v) for k, v in host.items()}
+        staged, packed = self._stage_all(host)
         self._flip ^= 1
         with torch.cuda.stream(self.stream):
             dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in staged.items()}
+            if packed is not None:   # the small tensors: ONE upload, carved into views on the device
+                buf, layout = packed
+                dbuf = buf.to(self.device, non_blocking=True)
+                for k, off, n, dtype, shape in layout:
+                    dev[k] = dbuf[off:off + n].view(dtype).view(shape)
             ev = torch.cuda.Event()
             ev.record(self.stream)
             self._uploaded[used] = ev
             if self.prepare is not None:
                 dev = self.prepare(dev)
+            self._ready = torch.cuda.Event()
+            self._ready.record(self.stream)
         self.data_dict = dev
 
     def next(self):
         """The prefetched batch (device tensors, safe to use on the current stream), or None when the loader is exhausted."""
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        # order the consumer's stream behind the upload + prepare — unless they have already finished (no packet at all then)
+        ready = getattr(self, "_ready", None)
+        if ready is None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        elif not ready.query():
+            torch.cuda.current_stream(self.device).wait_event(ready)
         data_dict = self.data_dict
         if data_dict is not None:
             for v in data_dict.values():
@@ -90,6 +134,24 @@ class Prefetcher:
                     v.record_stream(torch.cuda.current_stream(self.device))
         self.preload()
         return data_dict
+
+
+def compress_cloud(host_batch):
+    """Host batch -> the same batch with `point_clouds` (B,N,3+C) fp32 replaced by `k/xyz` (B,N,3) fp32 and `k/feat_bf` (B,N,C)
+    bf16: loader-side work (a DataLoader worker / collate_fn) that halves the bytes of the step's largest input on the PCIe
+    link — at cfg2 the cloud is 173 MB of a batch's 176 MB, and the host-fed step is bound by that copy (bench.py
+    ms_per_step_host_batches).  ONLY for the bf16 configuration: its first grouped-MLP layer rounds the gathered features to
+    bf16 (round to nearest even, as here) before the matrix product, so the step computes the same bits; the exact-fp32
+    parity configuration and the device-side augmentation (which rewrites the cloud) need the fp32 cloud.
+    grounding_step.prepare_batch expands k/feat_bf on the device."""
+    pc = host_batch["point_clouds"]
+    pc = torch.from_numpy(np.ascontiguousarray(pc)) if isinstance(pc, np.ndarray) else pc
+    if pc.shape[-1] <= 3:
+        return host_batch
+    out = {k: v for k, v in host_batch.items() if k != "point_clouds"}
+    out["k/xyz"] = pc[..., :3].contiguous()
+    out["k/feat_bf"] = pc[..., 3:].to(torch.bfloat16).contiguous()
+    return out
 
 
 # ---- training-time augmentation (lib/joint/dataset.py:653-690, utils/utils_fn.py:28-142) --------------------------------

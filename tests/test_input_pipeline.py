@@ -43,6 +43,63 @@ def test_prefetcher_uploads_in_order_and_prepares_on_copy_stream():
     assert pf.next() is None
 
 
+def test_packed_staging_and_compressed_cloud_on_the_host():
+    """Host logic of the uploader (no device needed): tensors below Prefetcher.PACK_BELOW bytes travel in ONE byte buffer and
+    come back as views of the right dtype / shape; compress_cloud replaces the cloud by (k/xyz fp32, k/feat_bf bf16 = the
+    round-to-nearest-even values of the feature channels) and leaves everything else alone."""
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    pf = ip.Prefetcher.__new__(ip.Prefetcher)      # the staging helpers only (no stream, no upload)
+    pf._pinned, pf._flip = [{}, {}], 0
+    pf._stage = lambda k, v: v
+    host = {"a": np.arange(10, dtype=np.int64).reshape(2, 5), "b": torch.randn(3, 4), "empty": torch.zeros(0),
+            "big": torch.zeros(600000), "flag": [1], "h": torch.randn(7).half(), "u": torch.arange(5, dtype=torch.uint8)}
+    staged, (buf, layout) = pf._stage_all(host)
+    assert sorted(staged) == ["big", "empty", "flag"] and [l[0] for l in layout] == ["a", "b", "h", "u"]
+    for k, off, n, dt, sh in layout:
+        assert off % 256 == 0
+        ref = torch.from_numpy(host[k]) if isinstance(host[k], np.ndarray) else host[k]
+        assert torch.equal(buf[off:off + n].view(dt).view(sh), ref), k
+    b = {k: torch.from_numpy(v) for k, v in synth.make_batch(0, 2, 4096, 2).items()}
+    c = ip.compress_cloud(b)
+    assert "point_clouds" not in c and c["k/xyz"].dtype == torch.float32 and c["k/feat_bf"].dtype == torch.bfloat16
+    assert torch.equal(c["k/xyz"], b["point_clouds"][..., :3])
+    assert torch.equal(c["k/feat_bf"].float(), b["point_clouds"][..., 3:].to(torch.bfloat16).float())
+    assert c["k/feat_bf"].shape == b["point_clouds"][..., 3:].shape
+    assert all(torch.equal(c[k], b[k]) for k in b if k != "point_clouds")
+    xyz_only = {"point_clouds": torch.zeros(2, 16, 3)}
+    assert ip.compress_cloud(xyz_only) is xyz_only
+
+
+@pytest.mark.gpu
+def test_compressed_cloud_gives_the_same_bf16_step():
+    """A batch uploaded through compress_cloud (features as bf16 on the link, expanded by prepare_batch) and the same batch
+    uploaded as the fp32 cloud: the bf16 configuration rounds the gathered features to bf16 in front of the first product, so
+    forward, loss and gradients are the same numbers (the loss to the bit: tools/determinism_probe.py)."""
+    ip = importlib.import_module("3dvlp_amd.input_pipeline")
+    gs = importlib.import_module("3dvlp_amd.grounding_step")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    hb = {k: torch.from_numpy(v) for k, v in synth.make_batch(0, 2, 20000, 4).items()}
+    feeds = [ip.Prefetcher(iter([hb]), device="cuda", prepare=gs.prepare_batch),
+             ip.Prefetcher(iter([ip.compress_cloud(hb)]), device="cuda", prepare=gs.prepare_batch)]
+    a, c = feeds[0].next(), feeds[1].next()
+    assert "point_clouds" not in c and torch.equal(c["k/xyz"], a["k/xyz"])
+    assert torch.equal(c["k/feat_pm"], a["k/feat_pm"].to(torch.bfloat16).float())
+    for k in a:   # every other prepared tensor arrives unchanged through the packed upload
+        if torch.is_tensor(a[k]) and k not in ("point_clouds", "k/feat_pm"):
+            assert a[k].dtype == c[k].dtype and torch.equal(a[k], c[k]), k
+    res = []
+    for batch in (a, c):
+        torch.manual_seed(0)
+        step = gs.GroundingStep(torch.device("cuda:0"), epoch=50, sa_dtype=torch.bfloat16, lr=0.0, seed=0)
+        loss = step.run(batch)
+        torch.cuda.synchronize()
+        res.append((float(loss), step.bucket.flat.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+    d = (res[0][1] - res[1][1]).abs().max().item()
+    assert d <= 2e-2 * res[0][1].abs().max().item(), d     # (backbone gradients carry the run-to-run noise of DESIGN.md 4.20)
+
+
 # ---- training-time augmentation (SURVEY.md §8f-4; lib/joint/dataset.py:653-690, utils/utils_fn.py:28-142) -------------
 def test_augment_oracle_invariants():
     """The numpy restatement: identity parameters change nothing except that votes point to the instance's POINT box

@@ -24,7 +24,7 @@ def t(fn, n=20):
     return s.elapsed_time(e) / (5 * n) * 1e3
 
 
-def case(name, B, N, M, S, C, cout, idx_mode):
+def case(name, B, N, M, S, C, cout, idx_mode, bf=False):
     g = torch.Generator(device="cpu").manual_seed(0)
     xyz = torch.rand(B, N, 3, generator=g).to(dev)
     new_xyz = xyz[:, :M].contiguous()
@@ -41,22 +41,19 @@ def case(name, B, N, M, S, C, cout, idx_mode):
     Y = torch.empty((R, cout), dtype=torch.bfloat16, device=dev)
     ns = int(ext.load().vlp3d_sa_stat_slabs(R))
     st = torch.empty((ns, 2, cout), dtype=torch.float64, device=dev)
-    us = t(lambda: ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat, B, N, M, S, C, 0.3, W, K1, cout, Y, st, 1, None, None, 0))
+    if bf:
+        Cp = (C + 7) // 8 * 8
+        fb = torch.zeros(B, N, Cp, device=dev, dtype=torch.bfloat16)
+        fb[..., :C] = feat.to(torch.bfloat16)
+        feat = fb
+    us = t(lambda: ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat, B, N, M, S, C, 0.3, W, K1, cout, Y, st, 3 if bf else 1, None, None, 0))
     gb = R * C * 4 / 1e9
     print(f"{name:44s} R={R:7d} K={K1:3d}  {us:7.1f} us   gathered {gb / (us * 1e-6) / 1e3:5.2f} TB/s")
 
 
-case("SA4 shape, random idx", 8, 512, 256, 16, 256, 128, "random")
-case("SA4 shape, local idx", 8, 512, 256, 16, 256, 128, "local")
-case("SA4 shape, same row", 8, 512, 256, 16, 256, 128, "same")
-case("SA3 shape, random idx", 8, 1024, 512, 16, 256, 128, "random")
-case("2x SA3 rows", 8, 1024, 1024, 16, 256, 128, "random")
-case("4x SA3 rows", 8, 1024, 2048, 16, 256, 128, "random")
-case("SA2 shape (K = 144)", 8, 2048, 1024, 32, 128, 128, "random")
-case("K = 144 at SA4's rows", 8, 512, 256, 16, 128, 128, "random")
-case("K = 144 at SA3's rows", 8, 1024, 512, 16, 128, 128, "random")
-case("K = 16 at SA4's rows, cout 128", 8, 512, 256, 16, 12, 128, "random")
-case("K = 16 at SA4's rows, cout 64", 8, 512, 256, 16, 12, 64, "random")
-case("K = 80 at SA4's rows, cout 128", 8, 512, 256, 16, 76, 128, "random")
-case("K = 16, 8 tiles per wave, cout 128", 8, 2048, 1024, 32, 12, 128, "random")
-case("K = 16, 16 tiles per wave, cout 128", 8, 2048, 2048, 32, 12, 128, "random")
+case("SA1 shape fp32 features", 8, 40000, 2048, 64, 132, 64, "random")
+case("SA1 shape bf16 features", 8, 40000, 2048, 64, 132, 64, "random", True)
+case("SA1 shape fp32 features, local", 8, 40000, 2048, 64, 132, 64, "local")
+case("SA1 shape bf16 features, local", 8, 40000, 2048, 64, 132, 64, "local", True)
+case("SA2 shape fp32 features", 8, 2048, 1024, 32, 128, 128, "random")
+case("SA2 shape bf16 features", 8, 2048, 1024, 32, 128, 128, "random", True)
