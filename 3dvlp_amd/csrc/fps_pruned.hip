@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256) void fps_cell_kernel(const float *__restrict__
   const int cell = vlp3d_cells::cell_code((unsigned)vlp3d_cells::axis_cell(p[0], bb[0], bb[3]),
                                           (unsigned)vlp3d_cells::axis_cell(p[1], bb[1], bb[4]),
                                           (unsigned)vlp3d_cells::axis_cell(p[2], bb[2], bb[5]));
-  cellid[(size_t)b * N + k] = cell;
-  atomicAdd(hist + (size_t)b * NCELL + cell, 1);
+  // the point's RANK inside its cell comes back with the histogram update and travels with the cell code (15 + 17 bits, N <=
+  // 131 072): the scatter below then needs no second round of 320 000 memory-side atomics (27 -> see DESIGN.md 4.1)
+  const int rank = atomicAdd(hist + (size_t)b * NCELL + cell, 1);
+  cellid[(size_t)b * N + k] = (int)((unsigned)cell | ((unsigned)rank << 15));
 }
 
-// ---- pre-pass 3: exclusive scan of the 32768 bins of a scene (in place) --------------------------------------
+// ---- pre-pass 3: INCLUSIVE scan of the 32768 bins of a scene (in place): hist[c] = end of cell c's run -------
 __global__ __launch_bounds__(1024) void fps_scan_kernel(int *__restrict__ hist) {
   __shared__ int part[1024];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(1024) void fps_scan_kernel(int *__restrict__ hist) 
   int loc[32], s = 0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    loc[i] = s;
     s += h[i];
+    loc[i] = s;
   }
   // inclusive scan of the 1024 thread sums: shuffles inside a wave, the 16 wave totals through LDS (the Hillis-Steele form
   // over LDS took 20 barriers: 11.9 us for the 8 scenes, in front of the longest dependent chain of the step)
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256) void fps_scatter_kernel(const float *__restric
   if (k >= N) return;
   const float *p = xyz + ((size_t)b * N + k) * 3;
   const float x = p[0], y = p[1], z = p[2];
-  const int pos = atomicAdd(hist + (size_t)b * NCELL + cellid[(size_t)b * N + k], 1);
+  const unsigned v = (unsigned)cellid[(size_t)b * N + k];
+  const int cell = (int)(v & (NCELL - 1)), rank = (int)(v >> 15);
+  const int pos = (cell > 0 ? hist[(size_t)b * NCELL + cell - 1] : 0) + rank;
   pts[(size_t)b * N + pos] = make_float4(x, y, z, vlp3d_fps_skipped(x, y, z) ? -1.f : 1e10f);
   perm[(size_t)b * N + pos] = k;
 }

@@ -279,7 +279,7 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
               padded_form_bytes=g_bytes_dense,
               note=("distinct rows of every ball only (ball-query padding removed, DESIGN.md §4.6): %.1f %% of the padded "
                     "rows; `achieved` counts the bytes of the rows evaluated" % (100.0 * rows / R)) if compact else "padded rows"),
-        entry("wgrad_kernel<bf16,...,GATHER> SA1 layer 1 weight gradient (dY1^T x gathered rows)", "wgrad_kernel", "hbm", wg_bytes,
+        entry("wgrad_kernel<bf16,...,GATHER> SA1 layer 1 weight gradient (dY1^T x gathered rows)", "::wgrad_kernel<__hip_bfloat16, 64, 0,", "hbm", wg_bytes,
               PEAK_HBM_GBS, "GB/s", None, in_step("vlp3d_sa_wgrad", is_sa1), algorithmic_bytes=wg_bytes),
         entry("sa_last_dgrad_kernel<64,128> SA1 layer 3 input gradient WITHOUT the layer's pre-activation (csrc/sa_last.hip: "
               "(k1 G) W3 - w (W3^T alpha + a2 Q), ReLU mask + BN-backward sums; round 3: row_gemm_lds_kernel<64,BNBWD,MASK> read Y3)",
