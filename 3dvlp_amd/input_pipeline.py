@@ -35,9 +35,15 @@ class Prefetcher:
     """Iterates `loader` (an iterable of dicts of numpy arrays / CPU tensors / plain Python values), keeping ONE batch in
     flight on a copy stream.  `prepare(batch_dict_on_device) -> batch_dict` runs on that stream after the upload."""
 
-    def __init__(self, loader, device="cuda", prepare=None, stream=None):
+    def __init__(self, loader, device="cuda", prepare=None, stream=None, max_ahead=3):
         self.loader = iter(loader)
         self.device = torch.device(device)
+        # The uploads never run more than `max_ahead` next() calls ahead of the consumer's STREAM: an asynchronous consumer (a
+        # captured step: ~0.5 ms of host time per 4 ms of device time) otherwise lets the host race ahead until the launch queues
+        # push back — ~60 batches of 176 MB in flight at cfg2, 11 GB of device memory that the allocator cannot reuse
+        # (tools/soak_host_feed.py).  The wait is on the host, for the consumer's position `max_ahead` calls ago.
+        self.max_ahead = max_ahead
+        self._marks = []
         # (stream: reuse a copy stream created earlier — every new HIP stream takes one of the few hardware queues, and a
         # stream created late in a process can land on the queue of the step's main or side stream and serialise with it)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
@@ -128,10 +134,17 @@ class Prefetcher:
         elif not ready.query():
             torch.cuda.current_stream(self.device).wait_event(ready)
         data_dict = self.data_dict
+        cur = torch.cuda.current_stream(self.device)
         if data_dict is not None:
             for v in data_dict.values():
                 if torch.is_tensor(v):
-                    v.record_stream(torch.cuda.current_stream(self.device))
+                    v.record_stream(cur)
+        if self.max_ahead:
+            mark = torch.cuda.Event()
+            mark.record(cur)           # everything the consumer has enqueued before asking for this batch
+            self._marks.append(mark)
+            if len(self._marks) > self.max_ahead:
+                self._marks.pop(0).synchronize()
         self.preload()
         return data_dict
 
