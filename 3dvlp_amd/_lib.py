@@ -108,6 +108,7 @@ SIGNATURES = {
     "vlp3d_l2norm_rows": [_vp, ctypes.c_longlong, _i, _f, _vp, _vp, _vp],
     "vlp3d_l2norm_rows_bwd": [_vp, _vp, _vp, ctypes.c_longlong, _i, _f, _vp, _vp],
     "vlp3d_relation_inputs": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "vlp3d_relation_inputs_bf16": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "vlp3d_copy_paste_map": [_vp, _i, _i, _vp, _vp, _vp],
     "vlp3d_gather_rows": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],
     "vlp3d_scatter_rows_add": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp],

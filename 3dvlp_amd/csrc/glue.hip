@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__res
 // (src + 128 b) * 128, src = seed_inds[b][vote_inds[b][k]] (relation_module.py:98-113: ids offset by b*128, rows taken
 // from the channel-major reshape) read from the point-major point cloud pc (B,N,3+3+128..): element e of that block ->
 // batch e / (128 N), channel (e % (128 N)) / N, point e % N, stored at pc[batch][point][6 + channel].
-__global__ __launch_bounds__(256) void relation_inputs_kernel(const float *__restrict__ pc, int Cpc, int col0, int N,
+// (PB: pc holds bf16 rows — the loader's bf16 copy of the cloud's feature channels — widened on the way out)
+template <bool PB>
+__global__ __launch_bounds__(256) void relation_inputs_kernel(const void *__restrict__ pc_, int Cpc, int col0, int N,
                                                               const int *__restrict__ seed_inds, int S,
                                                               const int *__restrict__ vote_inds, const float *__restrict__ corners,
                                                               int B, int K, float *__restrict__ obj_feat,
@@ -159,7 +161,13 @@ __global__ __launch_bounds__(256) void relation_inputs_kernel(const float *__res
     const long long flat = row_id * 128 + c;
     const long long fb = flat / (128ll * N), rem = flat - fb * 128ll * N;
     const long long ch = rem / N, pt = rem - ch * N;
-    obj_feat[t * 128 + c] = fb < B ? pc[(fb * N + pt) * Cpc + col0 + ch] : 0.f;
+    float v = 0.f;
+    if (fb < B) {
+      const long long o = (fb * N + pt) * Cpc + col0 + ch;
+      if (PB) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(pc_)[o] << 16);
+      else v = reinterpret_cast<const float *>(pc_)[o];
+    }
+    obj_feat[t * 128 + c] = v;
   }
   if (lane < 3) {  // per coordinate: min / max / mean over the 8 corners
     const float *cr = corners + t * 24 + lane;
@@ -390,8 +398,20 @@ extern "C" int vlp3d_relation_inputs(const float *pc, int Cpc, int col0, int N, 
   if (!pc || !seed_inds || !vote_inds || !corners || !obj_feat || !bbox_feat || !centre || B < 1 || K < 1 || N < 1 || S < 1 ||
       col0 < 0 || Cpc < col0 + 128)
     return VLP3D_EINVAL;
-  hipLaunchKernelGGL(relation_inputs_kernel, dim3(blocks_of((long long)B * K, 4)), dim3(256), 0, (hipStream_t)stream, pc, Cpc, col0, N,
-                     seed_inds, S, vote_inds, corners, B, K, obj_feat, bbox_feat, centre);
+  hipLaunchKernelGGL(relation_inputs_kernel<false>, dim3(blocks_of((long long)B * K, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const void *)pc, Cpc, col0, N, seed_inds, S, vote_inds, corners, B, K, obj_feat, bbox_feat, centre);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
+}
+// the same with pc as bf16 rows (Cpc = their row stride in elements): obj_feat = the widened values
+extern "C" int vlp3d_relation_inputs_bf16(const void *pc, int Cpc, int col0, int N, const int *seed_inds, int S,
+                                          const int *vote_inds, const float *corners, int B, int K, float *obj_feat,
+                                          float *bbox_feat, float *centre, void *stream) {
+  if (!pc || !seed_inds || !vote_inds || !corners || !obj_feat || !bbox_feat || !centre || B < 1 || K < 1 || N < 1 || S < 1 ||
+      col0 < 0 || Cpc < col0 + 128)
+    return VLP3D_EINVAL;
+  hipLaunchKernelGGL(relation_inputs_kernel<true>, dim3(blocks_of((long long)B * K, 4)), dim3(256), 0, (hipStream_t)stream, pc, Cpc,
+                     col0, N, seed_inds, S, vote_inds, corners, B, K, obj_feat, bbox_feat, centre);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }

@@ -1358,6 +1358,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   float4 rgf[(RAWF && DYL == BNBWD) ? NE_DY : 1];  // RAWF: vdy holds the raw pre-activation, rgf the raw gradient
   constexpr int MAXE_A8 = (MAXE_A + 1) / 2;
   uint4 pa8[A8 ? MAXE_A8 : 1];         // bf16 storage: RAW operands of the next tile (arithmetic at the LDS store)
+  // GATHER from bf16 feature rows (w.src.feat_bf, kernel-uniform): 8-column (16-byte) elements like the A8 operands — with 4-column
+  // elements the loads shrink to 8 bytes each and the kernel, bound by its load instructions, got SLOWER (126 -> 176 us at SA1)
+  constexpr bool G8 = ST16 && LOADER == GATHER;
+  const bool gbf = G8 && w.src.feat_bf != nullptr;
+  const int kg8 = (KF + 7) / 8, neg8 = 32 * kg8;          // 16-byte chunks per feature row (the last one may be half padding)
+  const unsigned kg8_inv = ((1u << 20) + kg8 - 1) / max(kg8, 1);  // e / kg8 == (e * kg8_inv) >> 20 for e < 32 * kg8, kg8 <= 36
+  uint4 pg8[G8 ? MAXE_A8 : 1];
+  int pidx8[G8 ? MAXE_A8 : 1];
   DyRaw8 rdy[ST16 ? NE_DY8 : 1];
   int2 mc[ST16 ? NE_DY8 : 1], mn[ST16 ? NE_DY8 : 1];  // compact-map words of the rows in rdy / of the tile after it
   const int kf8 = KF / 8, nef8 = 32 * kf8, kfs8 = A8 ? __builtin_ctz(kf8 > 0 ? kf8 : 1) : 0;
@@ -1391,10 +1399,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
   auto fetch_idx = [&](long long tile) {
     if (LOADER != GATHER) return;
     const int row0 = (int)(tile * 32);
+    if (gbf) {
+      if constexpr (G8) {
 #pragma unroll
-    for (int j = 0; j < MAXE_A; ++j) {
-      const int e = min((int)threadIdx.x + 256 * j, nef - 1);
-      pidx[j] = compact ? w.src.crow[row0 + row_of(e)].x : w.src.idx[row0 + row_of(e)];
+        for (int j = 0; j < MAXE_A8; ++j) {
+          const int e = min((int)threadIdx.x + 256 * j, neg8 - 1);
+          const int row = (int)(((unsigned)e * kg8_inv) >> 20);
+          pidx8[j] = compact ? w.src.crow[row0 + row].x : w.src.idx[row0 + row];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MAXE_A; ++j) {
+        const int e = min((int)threadIdx.x + 256 * j, nef - 1);
+        pidx[j] = compact ? w.src.crow[row0 + row_of(e)].x : w.src.idx[row0 + row_of(e)];
+      }
     }
     const int te = min((int)threadIdx.x, max(net, 1) - 1);
     const int trow = row0 + te / max(tc, 1);
@@ -1449,8 +1468,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
                                                   (long long)(row0 + row) * w.src.ldin + k0);
       }
     }
+    if constexpr (G8) {
+      if (gbf) {
 #pragma unroll
-    for (int j = 0; j < (A8 ? 0 : MAXE_A); ++j) {
+        for (int j = 0; j < MAXE_A8; ++j) {
+          const int e = min((int)threadIdx.x + 256 * j, neg8 - 1);
+          const int row = (int)(((unsigned)e * kg8_inv) >> 20), k0 = (e - row * kg8) * 8;
+          pg8[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16 *>(w.src.feat_bf) +
+                                                    (pbase + pidx8[j]) * w.src.ldf + k0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < ((A8 || gbf) ? 0 : MAXE_A); ++j) {
       const int e = min((int)threadIdx.x + 256 * j, nef - 1);
       const int row = row_of(e), k0 = (e - row * kf4) * 4;
       const int rr = row0 + row;
@@ -1571,8 +1601,23 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
           }
         }
       }
+      if constexpr (G8) {
+        if (gbf) {
 #pragma unroll
-      for (int j = 0; j < (A8 ? 0 : MAXE_A); ++j) {
+          for (int j = 0; j < MAXE_A8; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            if (e < neg8) {
+              const int row = (int)(((unsigned)e * kg8_inv) >> 20), k0 = (e - row * kg8) * 8;
+              short *q = ldb_a + row * RSA + k0;
+              *reinterpret_cast<uint2 *>(q) = make_uint2(pg8[j].x, pg8[j].y);
+              // the second half of a row's last chunk is the tail's [dx, dy, dz, 0] (written below by another thread)
+              if (k0 + 4 < KF) *reinterpret_cast<uint2 *>(q + 4) = make_uint2(pg8[j].z, pg8[j].w);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < ((A8 || gbf) ? 0 : MAXE_A); ++j) {
         const int e = threadIdx.x + 256 * j;
         if (e < nef) {
           const int row = row_of(e);
@@ -2088,7 +2133,8 @@ extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const
   RowGemmArgs a = {};
   a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feat_pm = feat_pm;
   a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
-  if (bf16_io & 2) {  // EXPERIMENT: feat_pm holds bf16 rows of (C + 7) & ~7 columns
+  if (bf16_io & 2) {  // feat_pm holds bf16 rows of (C + 7) & ~7 columns (zero padded): the gather fast path of the LDS kernels only
+    if (!(bf16_io & 1) || (K % 16) || 32 * (K / 8) > 64 * 10 || !(crow || (((long long)M * S) & 31) == 0)) return VLP3D_EINVAL;
     a.feat_bf = feat_pm;
     a.ldf = (C + 7) & ~7;
     bf16_io = 1;
@@ -2226,6 +2272,11 @@ extern "C" int vlp3d_sa_wgrad(const void *G, const void *Y, long long R, int cou
     if (!xyz || !new_xyz || !idx || !feat_pm || M < 1 || S < 1 || (((long long)M * S) & 31)) return VLP3D_EINVAL;
     w.src.xyz = xyz; w.src.new_xyz = new_xyz; w.src.idx = idx; w.src.feat_pm = feat_pm;
     w.src.N = N; w.src.M = M; w.src.S = S; w.src.C = C; w.src.radius = radius;
+    if (bf16_io & 2) {  // bf16 feature rows, as in vlp3d_sa_fwd_gather
+      if (!(bf16_io & 1)) return VLP3D_EINVAL;
+      w.src.feat_bf = feat_pm;
+      w.src.ldf = (C + 7) & ~7;
+    }
     w.src.S_shift = (S & (S - 1)) ? -1 : __builtin_ctz(S);
   } else {
     if (!Yprev || !scale || !shift || (256 % (K / 4)) || ((K / 4) & (K / 4 - 1))) return VLP3D_EINVAL;  // fixed staging columns per thread, shift-indexed rows

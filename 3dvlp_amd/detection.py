@@ -75,13 +75,17 @@ class Pointnet2Backbone(nn.Module):
         return g
 
     def forward(self, data_dict):
-        if "k/xyz" in data_dict and "k/feat_pm" in data_dict:
+        rows_bf16 = None
+        if "k/xyz" in data_dict and "k/feat_bf" in data_dict:
+            # ... and handed the feature channels over as bf16 rows (input_pipeline.compress_cloud / prepare_batch(feat_bf16=True))
+            xyz, features, rows_bf16 = data_dict["k/xyz"], None, (data_dict["k/feat_bf"], int(data_dict["k/feat_c"]))
+        elif "k/xyz" in data_dict and "k/feat_pm" in data_dict:
             # the loader already split the cloud (grounding_step.prepare_batch): no 173 MB copy inside the step
             xyz, features = data_dict["k/xyz"], data_dict["k/feat_pm"].transpose(1, 2)
         else:
             xyz, features = self._break_up_pc(data_dict["point_clouds"])
         geo = data_dict.get("backbone_geometry") or {}
-        xyz, features, fps_inds = self.sa1(xyz, features, geometry=geo.get("sa1"))
+        xyz, features, fps_inds = self.sa1(xyz, features, geometry=geo.get("sa1"), feat_rows_bf16=rows_bf16)
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
         xyz, features, fps_inds = self.sa2(xyz, features, geometry=geo.get("sa2"))
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
@@ -448,7 +452,10 @@ class RelationModule(nn.Module):
         corners = data_dict["pred_bbox_corner"]
 
         # the multiview channels: columns 6.. of the raw cloud, or 3.. of the loader's point-major feature split
-        src_pc, col0 = (data_dict["k/feat_pm"], 3) if "k/feat_pm" in data_dict else (data_dict.get("point_clouds"), 6)
+        if "k/feat_bf" in data_dict:
+            src_pc, col0 = data_dict["k/feat_bf"], 3
+        else:
+            src_pc, col0 = (data_dict["k/feat_pm"], 3) if "k/feat_pm" in data_dict else (data_dict.get("point_clouds"), 6)
         fused_inputs = self.fused_bias and corners.is_cuda and src_pc is not None and src_pc.shape[-1] >= col0 + 128
         if fused_inputs:  # obj_feat, manual_bbox_feat and the corner mean in ONE launch (csrc/glue.hip), no gradient
             obj_feat, manual_bbox_feat, centre = glue.relation_inputs(

@@ -108,14 +108,16 @@ def l2norm_rows(x, eps=1e-12):
 @torch.no_grad()
 def relation_inputs(pc, seed_inds, vote_inds, corners, col0=6):
     """-> obj_feat (B,K,128), manual_bbox_feat (B,K,27), centre (B,K,3); no gradient (all inputs are detached data).
-    pc: point-major rows holding the 128 multiview channels in columns col0..col0+127 (raw cloud: 6; k/feat_pm: 3)."""
+    pc: point-major rows holding the 128 multiview channels in columns col0..col0+127 (raw cloud: 6; k/feat_pm: 3), fp32 or
+    bf16 (k/feat_bf: the loader's bf16 copy, any row stride)."""
     B, N, Cpc = pc.shape
     K = corners.shape[1]
     dev = pc.device
     obj_feat = torch.empty((B, K, 128), dtype=torch.float32, device=dev)
     bbox = torch.empty((B, K, 27), dtype=torch.float32, device=dev)
     centre = torch.empty((B, K, 3), dtype=torch.float32, device=dev)
-    _ext.call("vlp3d_relation_inputs", pc.contiguous(), Cpc, int(col0), N, seed_inds.contiguous().int(), seed_inds.shape[1],
+    entry = "vlp3d_relation_inputs_bf16" if pc.dtype == torch.bfloat16 else "vlp3d_relation_inputs"
+    _ext.call(entry, pc.contiguous(), Cpc, int(col0), N, seed_inds.contiguous().int(), seed_inds.shape[1],
               vote_inds.contiguous().int(), corners.contiguous().float(), B, K, obj_feat, bbox, centre)
     return obj_feat, bbox, centre
 

@@ -94,7 +94,7 @@ def grounding_loss(d, config, args=None, impl=None, caption=False):
 _MEAN_SIZE_CACHE = {}
 
 
-def prepare_batch(out, mean_size_arr=None):
+def prepare_batch(out, mean_size_arr=None, feat_bf16=False):
     """Device batch (the reference's keys and dtypes) -> the same dict plus the KERNEL-READY forms of pure input data
     that the step would otherwise re-derive with a dozen small launches every iteration (loader work: it depends on the
     batch only, never on the model; input_pipeline.Prefetcher runs it on the copy stream):
@@ -103,8 +103,10 @@ def prepare_batch(out, mean_size_arr=None):
       (class2size, model_util_scannet.py:183-185; consumed by the DIoU loss and the contrast module);
       k/lang_kv — lang_fea[:, 1:] contiguous (the K/V tokens of match_module.py:134);
       k/xyz, k/feat_pm — the cloud split into coordinates and point-major features (backbone_module.py:73-80 slices
-      and copies them inside forward: 173 MB per step at cfg2).  A batch that arrives as (k/xyz, k/feat_bf) —
-      input_pipeline.compress_cloud on the host — has no point_clouds: its features are expanded to fp32 here."""
+      and copies them inside forward: 173 MB per step at cfg2).  feat_bf16 (bf16 configuration only): the features as BF16
+      rows instead — k/feat_bf (B,N,round_up(C,8)) zero padded + k/feat_c = C — which the first grouped-MLP layer and its
+      weight gradient read directly (the fp32 rows are rounded to exactly these values on their way into LDS).  A batch that
+      arrives as (k/xyz, k/feat_bf, k/feat_c) — input_pipeline.compress_cloud on the host — is left as it is."""
     device = (out["point_clouds"] if "point_clouds" in out else out["k/xyz"]).device
     out.setdefault("istrain", [1])
     # (cached per device: a pageable host -> device copy is SYNCHRONOUS — issued on the copy stream behind a batch's upload it
@@ -123,19 +125,25 @@ def prepare_batch(out, mean_size_arr=None):
     out["k/ref_size"] = (mean[out["ref_size_class_label_list"]] + out["ref_size_residual_label_list"]).float().contiguous()
     out["k/lang_kv"] = out["lang_fea"][:, 1:].contiguous()
     if "k/feat_bf" in out and "k/xyz" in out:
-        # the loader sent the cloud already split, its feature channels as bf16 (input_pipeline.compress_cloud: half the
-        # PCIe bytes of the step's largest input); expanded here, on the copy stream
-        out["k/feat_pm"] = out.pop("k/feat_bf").float()
+        # the loader sent the cloud already split, its feature channels as bf16 rows (input_pipeline.compress_cloud: half the
+        # PCIe bytes of the step's largest input): the bf16 kernels read them as they are
         return out
     pc = out["point_clouds"]
     if pc.size(-1) > 3:
-        out["k/xyz"], out["k/feat_pm"] = pc[..., :3].contiguous(), pc[..., 3:].contiguous()
+        out["k/xyz"] = pc[..., :3].contiguous()
+        if feat_bf16:   # the same split made on the device (resident batches, or behind the device-side augmentation)
+            C = pc.size(-1) - 3
+            rows = torch.zeros(pc.shape[:-1] + ((C + 7) // 8 * 8,), dtype=torch.bfloat16, device=pc.device)
+            rows[..., :C] = pc[..., 3:]
+            out["k/feat_bf"], out["k/feat_c"] = rows, C
+        else:
+            out["k/feat_pm"] = pc[..., 3:].contiguous()
     return out
 
 
-def batch_to_device(batch, device, mean_size_arr=None):
+def batch_to_device(batch, device, mean_size_arr=None, feat_bf16=False):
     """Host batch (numpy) -> device tensors + prepare_batch (synchronous form; see input_pipeline.Prefetcher)."""
-    return prepare_batch({k: torch.from_numpy(v).to(device) for k, v in batch.items()}, mean_size_arr)
+    return prepare_batch({k: torch.from_numpy(v).to(device) for k, v in batch.items()}, mean_size_arr, feat_bf16)
 
 
 def _detached(out):

@@ -150,20 +150,23 @@ class Prefetcher:
 
 
 def compress_cloud(host_batch):
-    """Host batch -> the same batch with `point_clouds` (B,N,3+C) fp32 replaced by `k/xyz` (B,N,3) fp32 and `k/feat_bf` (B,N,C)
-    bf16: loader-side work (a DataLoader worker / collate_fn) that halves the bytes of the step's largest input on the PCIe
+    """Host batch -> the same batch with `point_clouds` (B,N,3+C) fp32 replaced by `k/xyz` (B,N,3) fp32, `k/feat_bf`
+    (B,N,round_up(C,8)) bf16 (zero padded) and `k/feat_c` = C: loader-side work (a DataLoader worker / collate_fn) that halves the bytes of the step's largest input on the PCIe
     link — at cfg2 the cloud is 173 MB of a batch's 176 MB, and the host-fed step is bound by that copy (bench.py
     ms_per_step_host_batches).  ONLY for the bf16 configuration: its first grouped-MLP layer rounds the gathered features to
     bf16 (round to nearest even, as here) before the matrix product, so the step computes the same bits; the exact-fp32
     parity configuration and the device-side augmentation (which rewrites the cloud) need the fp32 cloud.
-    grounding_step.prepare_batch expands k/feat_bf on the device."""
+    The bf16 kernels read k/feat_bf as it is (grounding_step.prepare_batch leaves it alone)."""
     pc = host_batch["point_clouds"]
     pc = torch.from_numpy(np.ascontiguousarray(pc)) if isinstance(pc, np.ndarray) else pc
     if pc.shape[-1] <= 3:
         return host_batch
     out = {k: v for k, v in host_batch.items() if k != "point_clouds"}
+    C = pc.shape[-1] - 3
     out["k/xyz"] = pc[..., :3].contiguous()
-    out["k/feat_bf"] = pc[..., 3:].to(torch.bfloat16).contiguous()
+    rows = torch.zeros(pc.shape[:-1] + ((C + 7) // 8 * 8,), dtype=torch.bfloat16)   # 16-byte rows for the gather kernels
+    rows[..., :C] = pc[..., 3:]
+    out["k/feat_bf"], out["k/feat_c"] = rows, C
     return out
 
 

@@ -96,7 +96,7 @@ class PointnetSAModuleVotes(nn.Module):
         return (self.compact and self.fused == "mfma" and xyz.is_cuda and self.mlp_dtype == torch.bfloat16
                 and self.nsample >= int(os.environ.get("VLP3D_SA_COMPACT_MIN_S", 16)))
 
-    def _forward_rows(self, xyz, features, inds, geometry=None):
+    def _forward_rows(self, xyz, features, inds, geometry=None, feat_rows_bf16=None):
         """Same math as the reference sequence, on GEMM-ready rows: group_rows -> (linear, BN, ReLU) x L ->
         max over nsample.  BatchNorm over the (B*npoint*nsample) rows of a channel is exactly BatchNorm2d over
         (B, npoint, nsample); the first layer's weight columns are permuted to [features | xyz | 0]."""
@@ -110,18 +110,31 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             new_xyz = pointnet2_utils.gather_xyz(xyz, inds)  # gather_operation on the transposed cloud, without the transposes
             idx = pointnet2_utils.ball_query(self.radius, S, xyz, new_xyz)
-        feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
         dtype = self.mlp_dtype or (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
                                    else torch.float32)
         mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
-        if self.fused == "mfma" and sa_fused.supported(feat_pm.shape[2], mlp_out, S, B * M * S, M):
+        feat_c = None
+        if feat_rows_bf16 is not None:
+            # the loader's bf16 copy of the input channels (B, N, round_up(C, 8)): read as it is by the bf16 kernels (K <= 160);
+            # every other configuration widens it first
+            rows, feat_c = feat_rows_bf16
+            direct = (self.fused == "mfma" and dtype == torch.bfloat16 and feat_c + 4 <= 160
+                      and sa_fused.supported(feat_c, mlp_out, S, B * M * S, M))   # (supported: M * S % 32 == 0)
+            if direct:
+                feat_pm = rows
+            else:
+                feat_pm, feat_c = rows[..., :feat_c].float().contiguous(), None
+        else:
+            feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
+        if self.fused == "mfma" and sa_fused.supported(feat_c or feat_pm.shape[2], mlp_out, S, B * M * S, M):
             if cmap is None and geometry is None and self._use_compact(xyz):
                 cmap = sa_fused_ext.sa_compact(idx, N)
                 if self.csr_backward and os.environ.get("VLP3D_SA_CSR", "1") != "0" and torch.is_grad_enabled():
                     inv = sa_fused_ext.sa_inverse(idx, N, cmap)
             bf = dtype == torch.bfloat16
-            pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm.float(), self.radius if self.normalize_xyz else 1.0,
-                                          self.mlp_module, bf, cmap if bf else None, inv if bf else None)
+            pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm if feat_c is not None else feat_pm.float(),
+                                          self.radius if self.normalize_xyz else 1.0, self.mlp_module, bf, cmap if bf else None,
+                                          inv if bf else None, feat_c)
             return new_xyz, pooled.transpose(1, 2), inds
         x = pointnet2_utils.group_rows(xyz, new_xyz, idx, feat_pm, self.radius if self.normalize_xyz else 1.0, dtype)
         for i, layer in enumerate(self.mlp_module):
@@ -144,10 +157,17 @@ class PointnetSAModuleVotes(nn.Module):
         pooled = x.view(B * M, S, x.shape[-1]).max(dim=1)[0]
         return new_xyz, pooled.view(B, M, -1).transpose(1, 2), inds  # (B,C,npoint) view of point-major data
 
-    def forward(self, xyz, features=None, inds=None, geometry=None):
+    def forward(self, xyz, features=None, inds=None, geometry=None, feat_rows_bf16=None):
         # geometry and the gather kernels are fp32-only (like the reference's CHECK_IS_FLOAT); under
         # autocast the previous layer hands over bf16 activations
         xyz = xyz.float()
+        if feat_rows_bf16 is not None:   # (bf16 rows (B, N, round_up(C, 8)), C) instead of `features`
+            rows, c = feat_rows_bf16
+            if self.fused and c % 4 == 0 and xyz.is_cuda:
+                if geometry is None and inds is None:
+                    inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+                return self._forward_rows(xyz, None, inds, geometry, feat_rows_bf16)
+            features = rows[..., :c].float().transpose(1, 2)
         features = features.float() if features is not None else None
         use_rows = self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda
         if geometry is not None:

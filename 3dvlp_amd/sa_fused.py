@@ -55,7 +55,7 @@ class FusedSAMLP(Function):
     """(xyz, new_xyz, idx, feat_pm, W1,g1,b1, W2,g2,b2, W3,g3,b3) -> pooled (B*M, C3) fp32."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, inv, *params):
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, inv, feat_c, *params):
         W, gam, bet = params[0::3], params[1::3], params[2::3]
         # inv = (inv_start, inv_rows) of _lib.sa_inverse: backward sums the gather layer's input gradient per point through
         # this map (no atomics, csrc/sa_gather_sum.hip) — bf16 rows, feature gradients only
@@ -64,7 +64,13 @@ class FusedSAMLP(Function):
         cm = (cmap[1], cmap[0], idx.shape[0] * idx.shape[1]) if (cmap is not None and use_bf16) else (None, None, 0)
         B, N, _ = xyz.shape
         _, M, S = idx.shape
-        C = feat_pm.shape[2]
+        # feat_pm as BF16 rows (the loader's bf16 copy of the cloud's channels, zero padded to a multiple of 8 columns; feat_c =
+        # the real channel count): read as they are by the gather layer and its weight gradient (include/vlp3d.h: bf16_io bit 1)
+        feat_bf = feat_pm.dtype == torch.bfloat16
+        C = int(feat_c) if feat_bf else feat_pm.shape[2]
+        if feat_bf and not (use_bf16 and feat_pm.shape[2] == _round_up(C, 8) and feat_pm.is_contiguous()):
+            raise RuntimeError("FusedSAMLP: bf16 feature rows need the bf16 configuration and (B, N, round_up(C, 8)) contiguous rows")
+        fbit = 2 if feat_bf else 0
         R = B * M * S
         dt = torch.bfloat16 if use_bf16 else torch.float32
         bf = int(use_bf16)
@@ -88,7 +94,7 @@ class FusedSAMLP(Function):
             st = torch.empty((nslab, 2, cout[l]), dtype=torch.float64, device=dev)
             if l == 0:
                 _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
-                          cout[0], y, st, bf, *cm)
+                          cout[0], y, st, bf | fbit, *cm)
             else:
                 _ext.call("vlp3d_sa_fwd_layer", Y[l - 1], R, Ks[l], vecs[l - 1][0], vecs[l - 1][1], Wd[l], cout[l], y,
                           st, bf, *cm)
@@ -112,6 +118,7 @@ class FusedSAMLP(Function):
         ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet, Wd[2])
         ctx.cm = cm
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
+        ctx.fbit = fbit
         return out
 
     @staticmethod
@@ -196,7 +203,7 @@ class FusedSAMLP(Function):
                 G = Gp
             if l == 0:
                 _ext.call("vlp3d_sa_wgrad", G, Y[0], R, cout[0], c5, 1, None, Ks[0], None, None, xyz, new_xyz, idx,
-                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf, int(q is not None), *cm)
+                          feat_pm, N, M, S, C, radius, dW, part, nblk, None, None, 0, bf | ctx.fbit, int(q is not None), *cm)
                 if q is not None:  # the batched slab sum writes [xyz | features] columns directly
                     q.add(part, _ext.wgrad_slabs(R, nblk), dW, cout[0] * Ks[0], Ks[0], C + 3, ncol_out=C + 3, rot=3)
                     dparams[0] = dW.view(cout[0], C + 3, 1, 1)
@@ -215,17 +222,18 @@ class FusedSAMLP(Function):
                     dnew = arena[o + n_df + n_dx:].view(B, M, 3) if need[1] else None
                     _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
                               dxyz, dnew, bf, *cm)
-        return (dxyz, dnew, None, dfeat, None, None, None, None, None, None, *dparams)
+        return (dxyz, dnew, None, dfeat, None, None, None, None, None, None, None, *dparams)
 
 
-def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None, inv=None):
+def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None, inv=None, feat_c=None):
     """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32.
     cmap: (rowptr, crow) of _lib.sa_compact(idx, N) — evaluate the stack on the distinct rows only (bf16 configuration);
-    inv: (inv_start, inv_rows) of _lib.sa_inverse(idx, N, cmap) — atomic-free backward of the gather (bf16 configuration)."""
+    inv: (inv_start, inv_rows) of _lib.sa_inverse(idx, N, cmap) — atomic-free backward of the gather (bf16 configuration).
+    feat_pm may be BF16 rows (B, N, round_up(feat_c, 8)), columns beyond feat_c zero (bf16 configuration, no gradient to them)."""
     bns = [layer.bn.bn for layer in mlp_module]
     params = []
     for layer in mlp_module:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
     B, M = new_xyz.shape[:2]
-    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, inv, *params)
+    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, inv, feat_c, *params)
     return out.view(B, M, -1)

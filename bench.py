@@ -239,8 +239,11 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
         rowptr, crow = ext.sa_compact(idx, n)
         cm = (crow, rowptr, B * m)
         rows = (int(rowptr[-1]) + 31) // 32 * 32
+    fbit = 0
+    if bf and "k/feat_bf" in batch:   # what the step's SA1 reads: the loader's bf16 rows
+        feat_pm, fbit = batch["k/feat_bf"], 2
     g_ms = time_kernel(lambda: ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1,
-                                        cout, Y, stats, int(bf), *cm), reps)
+                                        cout, Y, stats, int(bf) | fbit, *cm), reps)
 
     # match-module attention cores: (B*L = 64, 256 queries, 4 heads x 32): self 256 keys, cross 49 keys
     BL = B * LANG_NUM
@@ -255,14 +258,15 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     fps_peak = PEAK_FP32_VECTOR_TFLOPS * B / NUM_CUS  # one workgroup (CU) per scene
     bq_bytes = B * (12 * n + 12 * m + 4 * m * 64)
     # features once + row map (idx, or the 16-byte compact entries) + Y + xyz, for the rows the kernel evaluates
-    g_bytes = B * n * C * 4 + (rows * 16 if compact else B * m * 64 * 4) + rows * cout * esz + B * n * 12
-    g_bytes_dense = B * n * C * 4 + B * m * 64 * 4 + R * cout * esz + B * n * 12
+    fsz = 2 if fbit else 4   # the feature rows as the step reads them (bf16 rows from the loader in the bf16 configuration)
+    g_bytes = B * n * C * fsz + (rows * 16 if compact else B * m * 64 * 4) + rows * cout * esz + B * n * 12
+    g_bytes_dense = B * n * C * fsz + B * m * 64 * 4 + R * cout * esz + B * n * 12
     g_flops = 2.0 * rows * (C + 3) * cout
     # Q, K, V, O touched once in bf16 = the ALGORITHMIC bytes; the kernels' I/O is fp32 (moved bytes)
     att_alg, att_moved = 4 * q.numel() * 2, 4 * q.numel() * 4
     xat_alg, xat_moved = (2 * q.numel() + 2 * kc.numel()) * 2, (2 * q.numel() + 2 * kc.numel()) * 4
     # SA1 layer-1 weight gradient: dW1 = dY1^T A0 over the evaluated rows: features once, G1 and Y1 rows once, the row map
-    wg_bytes = B * n * C * 4 + rows * (2 * cout * esz + 16)
+    wg_bytes = B * n * C * fsz + rows * (2 * cout * esz + 16)
     # SA1 layer-3 input gradient (vlp3d_sa_bwd_layer, pooled-gradient loader + mask epilogue): Y3 and Y2 rows once, G2 written,
     # the row map, the pooled gradient / arg-max tensors of the balls
     dg_bytes = rows * (2 * 64 * esz + 16) + B * m * 128 * 5          # since round 4: Y2 in, G2 out, row map, pooled rows (no Y3)
@@ -369,7 +373,7 @@ def host_feed(args, gs, first, world, rank, device, augment=False, stream=None):
         hb = {k: torch.from_numpy(v) for k, v in hb.items()}
         if compress:
             hb = ip.compress_cloud(hb)
-        host.append({k: v.pin_memory() for k, v in hb.items()})
+        host.append({k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in hb.items()})
 
     def endless():
         i = 0
@@ -389,6 +393,8 @@ def extra_config_ms(args, batch, gs, side_stream, dtype=None, padded=False, feed
     rows (VLP3D_SA_COMPACT=0: what the step costs when the distinct-row evaluation gains nothing — the synthetic scenes have
     39 % / 18 % distinct rows at SA1 / SA2, ScanNet-like density 65 % / 43 %); feed = every batch starts in pinned host memory."""
     dtype = dtype or args.dtype
+    if dtype != "bf16" and "k/feat_bf" in batch:   # the parity configuration reads the fp32 cloud
+        batch = gs.prepare_batch({k: v for k, v in batch.items() if not k.startswith("k/")})
     old = os.environ.get("VLP3D_SA_COMPACT")
     if padded:
         os.environ["VLP3D_SA_COMPACT"] = "0"
@@ -476,7 +482,10 @@ def main():
 
     first, _ = ddp.shard_range(B_PER_GPU * world, rank, world)
     batch_np = synth.make_batch(first, B_PER_GPU, NUM_POINTS, LANG_NUM, caption_tokens=32 if args.caption else 0)
-    batch = gs.batch_to_device(batch_np, device)
+    # bf16 configuration: the loader hands the cloud's feature channels over as bf16 rows (prepare_batch(feat_bf16=True): the values
+    # the first grouped-MLP layer rounds them to anyway) — read directly by the gather layer and its weight gradient
+    feat_bf16 = args.dtype == "bf16" and os.environ.get("VLP3D_FEAT_BF16", "1") != "0"
+    batch = gs.batch_to_device(batch_np, device, feat_bf16=feat_bf16)
     step = gs.GroundingStep(device, epoch=50, sa_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
                             use_graph=not args.no_graph, pipeline=not args.no_pipeline, use_caption=args.caption)
     ddp.broadcast_parameters(step.model, layout=step.layout)

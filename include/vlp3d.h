@@ -156,6 +156,10 @@ int vlp3d_sa_compact(const int *idx, int B, int N, int M, int S, int *rowptr, vo
  * [features(C) | xyz(3) | 0], K >= C+4, K % 8 (fp32) / 16 (bf16) == 0.
  * stats: (vlp3d_sa_stat_slabs(R) x 2 x cout) f64 — one [sum | sumsq] slab per workgroup, fully written (no atomics;
  * vlp3d_sa_bn_fold sums the slabs).  The same convention holds for `tstats` of vlp3d_sa_bwd_layer. */
+/* bf16_io of vlp3d_sa_fwd_gather and of vlp3d_sa_wgrad (gather != 0): bit 0 = bf16 storage / MFMA as everywhere; bit 1 (with
+ * bit 0, K <= 160, M*S % 32 == 0 or a compact row map) = feat_pm points at BF16 feature rows of (C + 7) & ~7 columns, columns
+ * [C, ..) zero — the loader's bf16 copy of the cloud's channels (input_pipeline.compress_cloud / prepare_batch): half the
+ * gathered bytes, the same numbers (the fp32 rows are rounded to bf16 on their way into LDS anyway). */
 int vlp3d_sa_stat_slabs(long long R);
 int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
                         int M, int S, int C, float radius, const void *W, int K, int cout, void *Y, double *stats,
@@ -509,6 +513,10 @@ int vlp3d_l2norm_rows_bwd(const float *g, const float *y, const float *norm, lon
  * col0 = 6) or the loader's feature split k/feat_pm (Cpc = 132, col0 = 3). */
 int vlp3d_relation_inputs(const float *pc, int Cpc, int col0, int N, const int *seed_inds, int S, const int *vote_inds,
                           const float *corners, int B, int K, float *obj_feat, float *bbox_feat, float *centre, void *stream);
+/* the same from bf16 rows (the loader's bf16 copy of the feature channels, Cpc = its row stride): values widened */
+int vlp3d_relation_inputs_bf16(const void *pc, int Cpc, int col0, int N, const int *seed_inds, int S, const int *vote_inds,
+                               const float *corners, int B, int K, float *obj_feat, float *bbox_feat, float *centre,
+                               void *stream);
 int vlp3d_copy_paste_map(const long long *obj_mask, int B, int K, const float *coin, int *src, void *stream);
 int vlp3d_gather_rows(const float *x, const int *src, long long R, int D, float *out, void *stream);
 int vlp3d_scatter_rows_add(const float *g, const int *src, long long R, int D, float *dx, void *stream);

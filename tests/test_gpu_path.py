@@ -1520,6 +1520,47 @@ def test_sa_last_layer_backward_without_its_preactivation(mlp, S, compact):
           f"new vs old: parameters {diff:.2e}, d(features) {_rel(runs['new']['df'], runs['old']['df']):.2e}")
 
 
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("C", [132, 128, 12])
+def test_sa_gather_layer_reads_bf16_feature_rows(C, compact):
+    """include/vlp3d.h bf16_io bit 1 (round 4): the first grouped-MLP layer and its weight gradient read the loader's BF16 copy
+    of the feature channels ((B, N, round_up(C, 8)) zero-padded rows) instead of the fp32 rows.  The fp32 rows are rounded to
+    bf16 (nearest even) on their way into LDS, so with features that ARE bf16 values both forms must agree to the bit: pooled
+    output and every parameter gradient (the weight-gradient slabs are summed in the same order)."""
+    pm = importlib.import_module("3dvlp_amd.pointnet2_modules")
+    synth = importlib.import_module("3dvlp_amd.synth")
+    B, N = 2, 8192
+    xyz = torch.from_numpy(np.stack([synth.make_scene(60 + i, N)["xyz"] for i in range(B)]).astype(np.float32)).cuda()
+    torch.manual_seed(C)
+    feats = torch.randn(B, N, C, device="cuda").to(torch.bfloat16)          # representable: the rounding is the identity
+    rows = torch.zeros(B, N, (C + 7) // 8 * 8, dtype=torch.bfloat16, device="cuda")
+    rows[..., :C] = feats
+    res, g = [], None
+    for form in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=32, mlp=[C, 64, 64, 128], use_xyz=True, normalize_xyz=True).cuda().train()
+        m.mlp_dtype, m.compact = torch.bfloat16, compact
+        if form == "fp32":
+            _, out, _ = m(xyz, feats.float().transpose(1, 2))
+        else:
+            _, out, _ = m(xyz, None, feat_rows_bf16=(rows, C))
+        if g is None:
+            g = torch.randn_like(out)
+        out.backward(g)
+        res.append((out.detach().clone(), [p.grad.clone() for p in m.parameters()], [n for n, _ in m.named_parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for n, a, b in zip(res[0][2], res[0][1], res[1][1]):
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
+    # the exact-fp32 configuration takes the same rows through the widening fall-back
+    m = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=32, mlp=[C, 64, 64, 128], use_xyz=True, normalize_xyz=True).cuda().train()
+    torch.manual_seed(11)
+    m2 = pm.PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=32, mlp=[C, 64, 64, 128], use_xyz=True, normalize_xyz=True).cuda().train()
+    m2.load_state_dict(m.state_dict())
+    _, o1, _ = m(xyz, feats.float().transpose(1, 2))
+    _, o2, _ = m2(xyz, None, feat_rows_bf16=(rows, C))
+    assert torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize("name,B,N", [("cfg3: 32 scenes per GPU", 32, 40000), ("cfg5: 80 000-point scenes", 4, 80000)])
 def test_step_runs_at_other_baseline_shapes(name, B, N):
     """BASELINE.json cfg3 (batch 32 per GPU, epoch >= 50: OCC/OSC active) and cfg5 (80k-point scenes: pruned FPS with two slot

@@ -64,8 +64,10 @@ def test_packed_staging_and_compressed_cloud_on_the_host():
     c = ip.compress_cloud(b)
     assert "point_clouds" not in c and c["k/xyz"].dtype == torch.float32 and c["k/feat_bf"].dtype == torch.bfloat16
     assert torch.equal(c["k/xyz"], b["point_clouds"][..., :3])
-    assert torch.equal(c["k/feat_bf"].float(), b["point_clouds"][..., 3:].to(torch.bfloat16).float())
-    assert c["k/feat_bf"].shape == b["point_clouds"][..., 3:].shape
+    C = b["point_clouds"].shape[-1] - 3
+    assert c["k/feat_c"] == C and c["k/feat_bf"].shape[-1] == (C + 7) // 8 * 8 and c["k/feat_bf"].is_contiguous()
+    assert torch.equal(c["k/feat_bf"][..., :C].float(), b["point_clouds"][..., 3:].to(torch.bfloat16).float())
+    assert not c["k/feat_bf"][..., C:].float().any()          # 16-byte rows: the padding columns are zero
     assert all(torch.equal(c[k], b[k]) for k in b if k != "point_clouds")
     xyz_only = {"point_clouds": torch.zeros(2, 16, 3)}
     assert ip.compress_cloud(xyz_only) is xyz_only
@@ -73,31 +75,37 @@ def test_packed_staging_and_compressed_cloud_on_the_host():
 
 @pytest.mark.gpu
 def test_compressed_cloud_gives_the_same_bf16_step():
-    """A batch uploaded through compress_cloud (features as bf16 on the link, expanded by prepare_batch) and the same batch
-    uploaded as the fp32 cloud: the bf16 configuration rounds the gathered features to bf16 in front of the first product, so
-    forward, loss and gradients are the same numbers (the loss to the bit: tools/determinism_probe.py)."""
+    """A batch uploaded through compress_cloud (the feature channels as bf16 rows on the link AND in the step: the gather
+    layer of SA1, its weight gradient and the relation module read them directly), the same batch with the bf16 rows made on
+    the device (prepare_batch(feat_bf16=True)) and the same batch as the fp32 cloud: the bf16 configuration rounds the gathered
+    features to bf16 in front of the first product, so forward, loss and gradients are the same numbers (the loss to the bit:
+    tools/determinism_probe.py)."""
     ip = importlib.import_module("3dvlp_amd.input_pipeline")
     gs = importlib.import_module("3dvlp_amd.grounding_step")
     synth = importlib.import_module("3dvlp_amd.synth")
     hb = {k: torch.from_numpy(v) for k, v in synth.make_batch(0, 2, 20000, 4).items()}
     feeds = [ip.Prefetcher(iter([hb]), device="cuda", prepare=gs.prepare_batch),
-             ip.Prefetcher(iter([ip.compress_cloud(hb)]), device="cuda", prepare=gs.prepare_batch)]
-    a, c = feeds[0].next(), feeds[1].next()
-    assert "point_clouds" not in c and torch.equal(c["k/xyz"], a["k/xyz"])
-    assert torch.equal(c["k/feat_pm"], a["k/feat_pm"].to(torch.bfloat16).float())
+             ip.Prefetcher(iter([ip.compress_cloud(hb)]), device="cuda", prepare=gs.prepare_batch),
+             ip.Prefetcher(iter([hb]), device="cuda", prepare=lambda d: gs.prepare_batch(d, feat_bf16=True))]
+    a, c, e = feeds[0].next(), feeds[1].next(), feeds[2].next()
+    assert "point_clouds" not in c and "k/feat_pm" not in c and "k/feat_pm" not in e and torch.equal(c["k/xyz"], a["k/xyz"])
+    C = a["k/feat_pm"].shape[-1]
+    assert c["k/feat_c"] == C == e["k/feat_c"] and torch.equal(c["k/feat_bf"], e["k/feat_bf"])
+    assert torch.equal(c["k/feat_bf"][..., :C].float(), a["k/feat_pm"].to(torch.bfloat16).float())
     for k in a:   # every other prepared tensor arrives unchanged through the packed upload
         if torch.is_tensor(a[k]) and k not in ("point_clouds", "k/feat_pm"):
             assert a[k].dtype == c[k].dtype and torch.equal(a[k], c[k]), k
     res = []
-    for batch in (a, c):
+    for batch in (a, c, e):
         torch.manual_seed(0)
         step = gs.GroundingStep(torch.device("cuda:0"), epoch=50, sa_dtype=torch.bfloat16, lr=0.0, seed=0)
         loss = step.run(batch)
         torch.cuda.synchronize()
         res.append((float(loss), step.bucket.flat.clone()))
-    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]), (res[0][0], res[1][0])
-    d = (res[0][1] - res[1][1]).abs().max().item()
-    assert d <= 2e-2 * res[0][1].abs().max().item(), d     # (backbone gradients carry the run-to-run noise of DESIGN.md 4.20)
+    for other in res[1:]:
+        assert abs(res[0][0] - other[0]) <= 1e-6 * abs(res[0][0]), (res[0][0], other[0])
+        d = (res[0][1] - other[1]).abs().max().item()
+        assert d <= 2e-2 * res[0][1].abs().max().item(), d     # (backbone gradients carry the run-to-run noise of DESIGN.md 4.20)
 
 
 # ---- training-time augmentation (SURVEY.md §8f-4; lib/joint/dataset.py:653-690, utils/utils_fn.py:28-142) -------------

@@ -24,7 +24,7 @@ for j in range(3):
     hb = {k: torch.from_numpy(v) for k, v in synth.make_batch(8 * j, 8, 40000, 8).items()}
     if "nocompress" not in sys.argv:
         hb = ip.compress_cloud(hb)
-    host.append({k: v.pin_memory() for k, v in hb.items()})
+    host.append({k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in hb.items()})
 
 
 def endless():

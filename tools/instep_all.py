@@ -21,7 +21,7 @@ names = [n for n, a in ext.SIGNATURES.items() if a and a[-1] is ext._vp and not 
 only = [a[5:].split(",") for a in sys.argv[1:] if a.startswith("only=")]   # only=copy_batch,adamw_flat: few stamps = the step's
 if only:                                                                    # real timeline (every stamp pair costs ~3.5 us)
     names = [n for n in names if n[6:] in only[0]] + ["vlp3d_sa_fwd_gather"]
-batch = gs.batch_to_device(synth.make_batch(0, 8, num_points=40000, lang_num_max=8), dev)
+batch = gs.batch_to_device(synth.make_batch(0, 8, num_points=40000, lang_num_max=8), dev, feat_bf16=os.environ.get("VLP3D_FEAT_BF16", "1") != "0" and "fp32" not in sys.argv)
 step = gs.GroundingStep(dev, epoch=50, sa_dtype=None if "fp32" in sys.argv else torch.bfloat16, use_graph=True, pipeline=True)
 with ext.Stamps(names + ["vlp3d_probe_empty"], dev, capacity=4096) as st:
     def begin():

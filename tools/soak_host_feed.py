@@ -10,7 +10,7 @@ with torch.cuda.stream(cs): torch.zeros(1, device=dev)
 host = []
 for j in range(3):
     hb = ip.compress_cloud({k: torch.from_numpy(v) for k, v in synth.make_batch(8 * j, 8, 40000, 8).items()})
-    host.append({k: v.pin_memory() for k, v in hb.items()})
+    host.append({k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in hb.items()})
 def endless():
     i = 0
     while True:

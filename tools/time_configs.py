@@ -20,7 +20,7 @@ for name, B, npts, kw in (("cfg2  8 x 40k", 8, 40000, {}), ("cfg3  4 x 40k (32 s
                           ("cfg5  4 x 80k, QA + grounding", 4, 80000, dict(use_answer=True, num_answers=512)),
                           ("cfg5  8 x 80k, QA + grounding", 8, 80000, dict(use_answer=True, num_answers=512))):
     batch = gs.batch_to_device(synth.make_batch(0, B, npts, 8, num_answers=kw.get("num_answers", 0),
-                                                caption_tokens=32 if kw.get("use_caption") else 0), dev)
+                                                caption_tokens=32 if kw.get("use_caption") else 0), dev, feat_bf16=True)
     step = gs.GroundingStep(dev, epoch=50, sa_dtype=torch.bfloat16, use_graph=True, pipeline=True, side_stream=side, **kw)
     side = step._side
     for _ in range(12):
