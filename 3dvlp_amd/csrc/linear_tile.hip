@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restric
 int vlp3d_internal_linear_tile(const float *X, int ldx, const float *W, int ldw, int kdim, int ncols, const float *bias,
                                const float *base, long long R, float *Y, int ldy, int transposed_weight, hipStream_t stream) {
   if (kdim % 16 || ncols % 4 || R < 1) return -22;
-  static const int tr = getenv("VLP3D_LINEAR_TILE_ROWS") ? atoi(getenv("VLP3D_LINEAR_TILE_ROWS")) : 64;
+  static const int tr = getenv("VLP3D_LINEAR_TILE_ROWS") ? atoi(getenv("VLP3D_LINEAR_TILE_ROWS")) : 32;  // (round 4 sweep: 64 -> 32)
   const int TRr = tr == 32 ? 32 : 64;
   const long long nblk = (R + TRr - 1) / TRr;
   const dim3 grid((unsigned)(nblk < 4096 ? nblk : 4096), (unsigned)((ncols + TC - 1) / TC));

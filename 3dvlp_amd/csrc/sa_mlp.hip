@@ -2016,7 +2016,8 @@ int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
   if constexpr (LOADER == GATHER && EPI == STORE && COUT == 128) {
     // the 256-channel levels (K = 272): all row-map words, then all feature rows of a tile in flight at once
     const int kc = a.K / 8;
-    if (32 * kc > 64 * 10 && 32 * kc <= 64 * 18 && kc <= 36 && a.C % 8 == 0 && (a.tile_scene || a.crow != nullptr))
+    static const bool wide_on = !(getenv("VLP3D_SA_WIDE") && atoi(getenv("VLP3D_SA_WIDE")) == 0);
+    if (wide_on && 32 * kc > 64 * 10 && 32 * kc <= 64 * 18 && kc <= 36 && a.C % 8 == 0 && (a.tile_scene || a.crow != nullptr))
       kern = row_gemm_lds_kernel<COUT, LOADER, EPI, true>;
   }
   if (lds > 64 * 1024) {
@@ -2028,7 +2029,8 @@ int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
   // behind the first (SA3's gather layer, K = 272: 512 workgroups of one tile per wave took two rounds of ~25 us) — cap the grid
   // at the CU count and let the waves stride over the tiles instead
   unsigned grid = grid_tiles(a.R);
-  if (lds + lds_static > 80 * 1024 && grid > 256) grid = 256;
+  static const bool cap_on = !(getenv("VLP3D_SA_GRIDCAP") && atoi(getenv("VLP3D_SA_GRIDCAP")) == 0);
+  if (cap_on && lds + lds_static > 80 * 1024 && grid > 256) grid = 256;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;

@@ -809,7 +809,7 @@ int sdpa_lds_min_bh() {
 int dkv_wpb(long long key_tile_waves) {
   static const int v = getenv("VLP3D_SDPA_DKV_WPB") ? atoi(getenv("VLP3D_SDPA_DKV_WPB")) : 0;
   if (v > 0) return v > 4 ? 4 : v;
-  return key_tile_waves >= 2048 ? 4 : 1;
+  return 2;  // (round-4 sweep inside the step: 2 key tiles x up to 4 query splits for every shape of the path; round 3: 4 / 1)
 }
 int dkv_qsplit(long long key_tile_waves) {  // power of two
   static const int v = getenv("VLP3D_SDPA_DKV_QSPLIT") ? atoi(getenv("VLP3D_SDPA_DKV_QSPLIT")) : 0;

@@ -19,7 +19,7 @@ _ext.load()
 # small dW (SA1: 16-36 KB) get up to 2048 workgroups (their tiles are staging-latency bound: 4.5 us per 32-row tile at two
 # workgroups per CU), layers with a large dW (131-147 KB) fewer than before; 5.34 -> 5.30 ms per step
 WGRAD_BLOCKS = int(os.environ.get("VLP3D_WGRAD_BLOCKS", 2048))
-WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 4))    # 32-row tiles a workgroup accumulates before writing its slab
+WGRAD_TILES = int(os.environ.get("VLP3D_WGRAD_TILES", 8))    # 32-row tiles a workgroup accumulates before writing its slab (round 4: 4 -> 8)
 
 
 WGRAD_SLAB_MB = float(os.environ.get("VLP3D_WGRAD_SLAB_MB", 16))  # cap on the partial-dW slabs of one launch
