@@ -947,8 +947,10 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         const int rr = row0 + lane;
         const int bm = compact ? (sMeta[lane].x >> 8) : (a.S_shift >= 0 ? (rr >> a.S_shift) : rr / a.S);
         const float *cc3 = a.new_xyz + (long long)bm * 3;
+        // (a division like the loader this path replaces and the reference's `grouped_xyz /= radius`: the reciprocal form moved
+        // the step's first loss from 30.08 to 32.06 — one ulp in three layers' offsets changes which votes the proposal FPS picks)
         *reinterpret_cast<uint2 *>(sA + lane * ldw + a.C) =
-            pack4(make_float4((wx - cc3[0]) * inv_radius, (wy - cc3[1]) * inv_radius, (wz - cc3[2]) * inv_radius, 0.f));
+            pack4(make_float4((wx - cc3[0]) / a.radius, (wy - cc3[1]) / a.radius, (wz - cc3[2]) / a.radius, 0.f));
       }
     }
     // chunks in flight per lane: four, two for the wide BN-backward kernels (their raw operands — y, g or the pooled
