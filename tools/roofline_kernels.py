@@ -33,8 +33,13 @@ for bf in (1, 0):
     W = (torch.randn(cout, K1, device=dev) * 0.05).to(dt)
     Y = torch.empty((R, cout), dtype=dt, device=dev)
     stats = torch.empty((int(ext.load().vlp3d_sa_stat_slabs(R)), 2, cout), dtype=torch.float64, device=dev)
+    rows = feat_pm
+    if bf:   # what the bf16 step reads: the loader's bf16 copy of the channels (prepare_batch(feat_bf16=True))
+        rows = torch.zeros(B, n, (C + 7) // 8 * 8, dtype=torch.bfloat16, device=dev)
+        rows[..., :C] = feat_pm
+        rows_bf = rows
     for _ in range(3):
-        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, bf, *(cm if bf else (None, None, 0)))
+        ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, rows, B, n, m, 64, C, 0.2, W, K1, cout, Y, stats, 3 if bf else 0, *(cm if bf else (None, None, 0)))
 # SA1 layer-3 input gradient (pooled-gradient loader, 128 -> 64, mask epilogue) and the gather layer's weight gradient on the
 # compact rows, bf16: the two largest main-stream kernels of the backward pass (bench.py roofline candidates)
 R = B * m * 64
@@ -55,8 +60,8 @@ nblk = 1024
 part = torch.empty((nblk, 64, 144), device=dev)
 for _ in range(3):
     ext.call("vlp3d_sa_bwd_layer", None, Y3, R, 128, c5_3, WT3, 64, Y2, vec2, G2, t2, gsel, sel, 64, 1, *cm)
-    ext.call("vlp3d_sa_wgrad", G1, Y1, R, 64, c5_1, 1, None, 144, None, None, xyz, new_xyz, idx, feat_pm, n, m, 64, 132, 0.2,
-             dW, part, nblk, None, None, 0, 1, 0, *cm)
+    ext.call("vlp3d_sa_wgrad", G1, Y1, R, 64, c5_1, 1, None, 144, None, None, xyz, new_xyz, idx, rows_bf, n, m, 64, 132, 0.2,
+             dW, part, nblk, None, None, 0, 3, 0, *cm)
 # round 4: the same layer's input / weight gradient WITHOUT its pre-activation (csrc/sa_last.hip): what the step runs at SA1
 W3 = (torch.randn(128, 64, device=dev) * 0.05).to(torch.bfloat16)
 nb3 = 512
