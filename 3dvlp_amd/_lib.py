@@ -45,6 +45,7 @@ SIGNATURES = {
     "vlp3d_sa_fwd_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_fwd_layer": [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_pool": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "vlp3d_sa_pool_rows": [_vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "vlp3d_sa_pool_grad": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _vp],
     "vlp3d_sa_bwd_layer": [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     "vlp3d_sa_bwd_gather": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],

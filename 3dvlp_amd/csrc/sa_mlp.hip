@@ -921,16 +921,28 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
       }
       const int wprow = src_index((long long)row0 + (lane & 31));
       float4 w0[WIDECH], w1[WIDECH];
+      const bool wbf = a.feat_bf != nullptr;  // kernel-uniform: bf16 feature rows — one 16-byte load per chunk, stored as it is
+      if (wbf) {
+        const bf16 *bbase = reinterpret_cast<const bf16 *>(a.feat_bf) + (long long)scene * a.N * a.ldf;
 #pragma unroll
-      for (int u = 0; u < WIDECH; ++u) {
-        const int c = min(64 * u + lane, nch - 1);
-        const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
-        const float *fr = fbase + (long long)wp[u] * a.C;
-        w0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        w1[u] = w0[u];
-        if (64 * u < nch) {  // uniform
-          if (col < a.C) w0[u] = ld4(fr + col);
-          if (col + 4 < a.C) w1[u] = ld4(fr + col + 4);
+        for (int u = 0; u < WIDECH; ++u) {
+          const int c = min(64 * u + lane, nch - 1);
+          const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
+          w0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (64 * u < nch && col < a.C) w0[u] = *reinterpret_cast<const float4 *>(bbase + (long long)wp[u] * a.ldf + col);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < WIDECH; ++u) {
+          const int c = min(64 * u + lane, nch - 1);
+          const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
+          const float *fr = fbase + (long long)wp[u] * a.C;
+          w0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          w1[u] = w0[u];
+          if (64 * u < nch) {  // uniform
+            if (col < a.C) w0[u] = ld4(fr + col);
+            if (col + 4 < a.C) w1[u] = ld4(fr + col + 4);
+          }
         }
       }
       const float *wq = a.xyz + ((long long)scene * a.N + wprow) * 3;
@@ -940,7 +952,7 @@ __global__ __launch_bounds__(256, (COUT <= 256 ? 2 : 1)) void row_gemm_lds_kerne
         const int c = 64 * u + lane;
         if (c < nch) {
           const int rw = (int)(((unsigned)c * kc_inv) >> 20), col = (c - rw * kc) * 8;
-          *reinterpret_cast<uint4 *>(sA + rw * ldw + col) = pack8(w0[u], w1[u]);
+          *reinterpret_cast<uint4 *>(sA + rw * ldw + col) = wbf ? *reinterpret_cast<const uint4 *>(&w0[u]) : pack8(w0[u], w1[u]);
         }
       }
       if (lane < 32) {  // [dx, dy, dz, 0] columns: same wave, later instruction — lands after the chunk writes above
@@ -1101,7 +1113,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int S_dense, int C, long long BM,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                                     float *__restrict__ out, unsigned char *__restrict__ sel_idx,
-                                                    const int *__restrict__ rowptr) {
+                                                    const int *__restrict__ rowptr, bf16 *__restrict__ out_bf) {
   const int c8n = C / 8;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= BM * c8n) return;
@@ -1154,6 +1166,9 @@ __global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int
   o1.z = fmaxf(0.f, best[6] * sc[6] + shift[c0 + 6]); o1.w = fmaxf(0.f, best[7] * sc[7] + shift[c0 + 7]);
   *reinterpret_cast<float4 *>(o) = o0;
   *reinterpret_cast<float4 *>(o + 4) = o1;
+  // the same row as bf16 (optional): what the NEXT level's gather layer rounds it to on its way into LDS — handed over so that
+  // it can read 16-byte chunks of it instead (vlp3d_sa_pool_rows)
+  if (out_bf != nullptr) *reinterpret_cast<uint4 *>(out_bf + bm * C + c0) = pack8(o0, o1);
   uint2 sb;
   sb.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
   sb.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
@@ -2015,13 +2030,18 @@ int launch_lds_c(const RowGemmArgs &a, hipStream_t s) {
   const size_t lds_static = (EPI == SCATTER) ? 0 : sizeof(double) * 4 * 2 * COUT;  // block_stats_to_slab
   if (lds + lds_static > 160 * 1024) return VLP3D_EINVAL;
   auto kern = row_gemm_lds_kernel<COUT, LOADER, EPI>;
+  bool wide = false;
   if constexpr (LOADER == GATHER && EPI == STORE && COUT == 128) {
     // the 256-channel levels (K = 272): all row-map words, then all feature rows of a tile in flight at once
     const int kc = a.K / 8;
     static const bool wide_on = !(getenv("VLP3D_SA_WIDE") && atoi(getenv("VLP3D_SA_WIDE")) == 0);
-    if (wide_on && 32 * kc > 64 * 10 && 32 * kc <= 64 * 18 && kc <= 36 && a.C % 8 == 0 && (a.tile_scene || a.crow != nullptr))
+    if (wide_on && 32 * kc > 64 * 10 && 32 * kc <= 64 * 18 && kc <= 36 && a.C % 8 == 0 && (a.tile_scene || a.crow != nullptr)) {
       kern = row_gemm_lds_kernel<COUT, LOADER, EPI, true>;
+      wide = true;
+    }
   }
+  // bf16 feature rows are read by the gather fast path (32 K/8 <= 640 chunks per tile) and by the WIDE instantiation only
+  if (LOADER == GATHER && a.feat_bf != nullptr && !wide && 32 * (a.K / 8) > 64 * 10) return VLP3D_EINVAL;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -2138,7 +2158,9 @@ extern "C" int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const
   a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.feat_pm = feat_pm;
   a.N = N; a.M = M; a.S = S; a.C = C; a.radius = radius;
   if (bf16_io & 2) {  // feat_pm holds bf16 rows of (C + 7) & ~7 columns (zero padded): the gather fast path of the LDS kernels only
-    if (!(bf16_io & 1) || (K % 16) || 32 * (K / 8) > 64 * 10 || !(crow || (((long long)M * S) & 31) == 0)) return VLP3D_EINVAL;
+    const int kc8 = K / 8;   // the fast path (K <= 160) or the WIDE instantiation (cout 128, K <= 288, C % 8 == 0)
+    const bool wide_ok = cout == 128 && 32 * kc8 <= 64 * 18 && kc8 <= 36 && C % 8 == 0;
+    if (!(bf16_io & 1) || (K % 16) || !(32 * kc8 <= 64 * 10 || wide_ok) || !(crow || (((long long)M * S) & 31) == 0)) return VLP3D_EINVAL;
     a.feat_bf = feat_pm;
     a.ldf = (C + 7) & ~7;
     bf16_io = 1;
@@ -2169,18 +2191,32 @@ extern "C" int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const flo
                  : launch_row_gemm<float>(BNRELU, STORE, cout, a, (hipStream_t)stream);
 }
 
+static int sa_pool_impl(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
+                        void *out_bf16, unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream);
 extern "C" int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift,
                              float *out, unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream) {
+  return sa_pool_impl(Y, BM, S, C, scale, shift, out, nullptr, sel_idx, bf16_io, rowptr, stream);
+}
+// vlp3d_sa_pool that also writes the pooled rows as bf16 (out_bf16 (BM x C), C % 8 == 0): the next level's gather layer reads them
+// through bf16_io bit 1 (include/vlp3d.h)
+extern "C" int vlp3d_sa_pool_rows(const void *Y, long long BM, int S, int C, const float *scale, const float *shift,
+                                  float *out, void *out_bf16, unsigned char *sel_idx, int bf16_io, const int *rowptr,
+                                  void *stream) {
+  if (!out_bf16 || (C % 8)) return VLP3D_EINVAL;
+  return sa_pool_impl(Y, BM, S, C, scale, shift, out, out_bf16, sel_idx, bf16_io, rowptr, stream);
+}
+static int sa_pool_impl(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
+                        void *out_bf16, unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream) {
   if (!Y || !scale || !shift || !out || !sel_idx || BM < 1 || S < 1 || S > 255 || C < 1) return VLP3D_EINVAL;
   if (rowptr && (C % 8)) return VLP3D_EINVAL;  // compact row map: the 8-channel kernel only
   if (C % 8 == 0) {
     const dim3 grid8((unsigned)((BM * (C / 8) + 255) / 256));
     if (bf16_io)
       hipLaunchKernelGGL((pool8_kernel<bf16>), grid8, dim3(256), 0, (hipStream_t)stream, (const bf16 *)Y, S, C, BM, scale,
-                         shift, out, sel_idx, rowptr);
+                         shift, out, sel_idx, rowptr, (bf16 *)out_bf16);
     else
       hipLaunchKernelGGL((pool8_kernel<float>), grid8, dim3(256), 0, (hipStream_t)stream, (const float *)Y, S, C, BM,
-                         scale, shift, out, sel_idx, rowptr);
+                         scale, shift, out, sel_idx, rowptr, (bf16 *)out_bf16);
     VLP3D_LAUNCH_CHECK();
     return VLP3D_OK;
   }

@@ -63,6 +63,10 @@ class PointnetSAModuleVotes(nn.Module):
         # True (set by the backbone for sa2..sa4): also build the point -> rows map, and sum the gather layer's input
         # gradient per point through it instead of scattering it with float atomics (csrc/sa_gather_sum.hip)
         self.csr_backward = False
+        # bf16 configuration: also emit the pooled output as bf16 rows (an attribute of the returned feature tensor) and read
+        # such rows when the incoming feature tensor carries them (vlp3d_sa_pool_rows / bf16_io bit 1): the next level's gather
+        # layer and its weight gradient then read 16-byte chunks of rows that are already what they would round them to
+        self.pass_rows_bf16 = os.environ.get("VLP3D_SA_ROWS_BF16", "1") != "0"
 
     @torch.no_grad()
     def compute_geometry(self, xyz, fps_ordered=False):
@@ -113,29 +117,47 @@ class PointnetSAModuleVotes(nn.Module):
         dtype = self.mlp_dtype or (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda")
                                    else torch.float32)
         mlp_out = [layer.conv.weight.shape[0] for layer in self.mlp_module]
-        feat_c = None
-        if feat_rows_bf16 is not None:
-            # the loader's bf16 copy of the input channels (B, N, round_up(C, 8)): read as it is by the bf16 kernels (K <= 160);
-            # every other configuration widens it first
+        feat_c = feat_rows = None
+
+        def rows_readable(c):
+            """bf16 rows of c channels can be read directly: the bf16 kernels' gather fast path (K <= 160) or its wide form
+            (128 output channels, K <= 288, c % 8 == 0) — include/vlp3d.h, bf16_io bit 1."""
+            K1 = (c + 4 + 15) // 16 * 16
+            return (self.fused == "mfma" and dtype == torch.bfloat16 and sa_fused.supported(c, mlp_out, S, B * M * S, M)
+                    and (K1 <= 160 or (mlp_out[0] == 128 and K1 <= 288 and c % 8 == 0)))
+
+        if feat_rows_bf16 is not None and features is None:
+            # the loader's bf16 copy of the input channels (B, N, round_up(C, 8)), no fp32 form: read as it is by the bf16
+            # kernels; every other configuration widens it first
             rows, feat_c = feat_rows_bf16
-            direct = (self.fused == "mfma" and dtype == torch.bfloat16 and feat_c + 4 <= 160
-                      and sa_fused.supported(feat_c, mlp_out, S, B * M * S, M))   # (supported: M * S % 32 == 0)
-            if direct:
+            if rows_readable(feat_c):
                 feat_pm = rows
             else:
                 feat_pm, feat_c = rows[..., :feat_c].float().contiguous(), None
         else:
             feat_pm = features.transpose(1, 2).contiguous()  # (B,N,C): no copy when features is a point-major view
+            if feat_rows_bf16 is not None and rows_readable(feat_rows_bf16[1]):
+                # the previous level's pooled output as bf16 rows beside the fp32 tensor that carries the gradient
+                feat_rows, feat_c = feat_rows_bf16
         if self.fused == "mfma" and sa_fused.supported(feat_c or feat_pm.shape[2], mlp_out, S, B * M * S, M):
             if cmap is None and geometry is None and self._use_compact(xyz):
                 cmap = sa_fused_ext.sa_compact(idx, N)
                 if self.csr_backward and os.environ.get("VLP3D_SA_CSR", "1") != "0" and torch.is_grad_enabled():
                     inv = sa_fused_ext.sa_inverse(idx, N, cmap)
             bf = dtype == torch.bfloat16
-            pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm if feat_c is not None else feat_pm.float(),
+            want = bf and self.pass_rows_bf16 and mlp_out[2] % 8 == 0
+            pooled = sa_fused.sa_mlp_pool(xyz, new_xyz, idx, feat_pm if feat_pm.dtype == torch.bfloat16 else feat_pm.float(),
                                           self.radius if self.normalize_xyz else 1.0, self.mlp_module, bf, cmap if bf else None,
-                                          inv if bf else None, feat_c)
-            return new_xyz, pooled.transpose(1, 2), inds
+                                          inv if bf else None, feat_c, feat_rows, want)
+            rows_out = None
+            if want:
+                pooled, rows_out = pooled
+            feats = pooled.transpose(1, 2)
+            if rows_out is not None:
+                # travels with the tensor OBJECT to the next level (Pointnet2Backbone hands `features` on unchanged): the same
+                # values as bf16 rows (B, npoint, C) for its gather layer
+                feats._vlp3d_rows_bf16 = rows_out
+            return new_xyz, feats, inds
         x = pointnet2_utils.group_rows(xyz, new_xyz, idx, feat_pm, self.radius if self.normalize_xyz else 1.0, dtype)
         for i, layer in enumerate(self.mlp_module):
             w = layer.conv.weight[:, :, 0, 0]
@@ -168,17 +190,21 @@ class PointnetSAModuleVotes(nn.Module):
                     inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
                 return self._forward_rows(xyz, None, inds, geometry, feat_rows_bf16)
             features = rows[..., :c].float().transpose(1, 2)
+        carried = getattr(features, "_vlp3d_rows_bf16", None) if features is not None else None
         features = features.float() if features is not None else None
         use_rows = self.fused and features is not None and features.shape[1] % 4 == 0 and xyz.is_cuda
+        if (carried is not None and self.pass_rows_bf16 and use_rows and carried.is_contiguous()
+                and tuple(carried.shape) == (features.shape[0], features.shape[2], features.shape[1]) and carried.shape[2] % 8 == 0):
+            feat_rows_bf16 = (carried, carried.shape[2])
         if geometry is not None:
             assert use_rows, "precomputed geometry needs the fused path"
-            return self._forward_rows(xyz, features, None, geometry)
+            return self._forward_rows(xyz, features, None, geometry, feat_rows_bf16)
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
         if use_rows:
-            return self._forward_rows(xyz, features, inds)
+            return self._forward_rows(xyz, features, inds, None, feat_rows_bf16)
         features = features.contiguous() if features is not None else None
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = (pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()

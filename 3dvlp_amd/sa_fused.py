@@ -55,7 +55,8 @@ class FusedSAMLP(Function):
     """(xyz, new_xyz, idx, feat_pm, W1,g1,b1, W2,g2,b2, W3,g3,b3) -> pooled (B*M, C3) fp32."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, inv, feat_c, *params):
+    def forward(ctx, xyz, new_xyz, idx, feat_pm, radius, bns, training, use_bf16, cmap, inv, feat_c, feat_rows, want_rows,
+                *params):
         W, gam, bet = params[0::3], params[1::3], params[2::3]
         # inv = (inv_start, inv_rows) of _lib.sa_inverse: backward sums the gather layer's input gradient per point through
         # this map (no atomics, csrc/sa_gather_sum.hip) — bf16 rows, feature gradients only
@@ -66,9 +67,13 @@ class FusedSAMLP(Function):
         _, M, S = idx.shape
         # feat_pm as BF16 rows (the loader's bf16 copy of the cloud's channels, zero padded to a multiple of 8 columns; feat_c =
         # the real channel count): read as they are by the gather layer and its weight gradient (include/vlp3d.h: bf16_io bit 1)
-        feat_bf = feat_pm.dtype == torch.bfloat16
+        # feat_rows: the SAME values as bf16 rows beside an fp32 feat_pm that carries the gradient (the previous level's pooled
+        # output, vlp3d_sa_pool_rows): the kernels read the rows, autograd sees feat_pm.  want_rows: also return this level's
+        # pooled output as bf16 rows for the next level.
+        src = feat_rows if feat_rows is not None else feat_pm
+        feat_bf = src.dtype == torch.bfloat16
         C = int(feat_c) if feat_bf else feat_pm.shape[2]
-        if feat_bf and not (use_bf16 and feat_pm.shape[2] == _round_up(C, 8) and feat_pm.is_contiguous()):
+        if feat_bf and not (use_bf16 and src.shape[2] == _round_up(C, 8) and src.is_contiguous()):
             raise RuntimeError("FusedSAMLP: bf16 feature rows need the bf16 configuration and (B, N, round_up(C, 8)) contiguous rows")
         fbit = 2 if feat_bf else 0
         R = B * M * S
@@ -93,7 +98,7 @@ class FusedSAMLP(Function):
             y = torch.empty((R, cout[l]), dtype=dt, device=dev)
             st = torch.empty((nslab, 2, cout[l]), dtype=torch.float64, device=dev)
             if l == 0:
-                _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, feat_pm, B, N, M, S, C, float(radius), Wd[0], K1,
+                _ext.call("vlp3d_sa_fwd_gather", xyz, new_xyz, idx, src, B, N, M, S, C, float(radius), Wd[0], K1,
                           cout[0], y, st, bf | fbit, *cm)
             else:
                 _ext.call("vlp3d_sa_fwd_layer", Y[l - 1], R, Ks[l], vecs[l - 1][0], vecs[l - 1][1], Wd[l], cout[l], y,
@@ -114,15 +119,27 @@ class FusedSAMLP(Function):
             vecs.append(vec)
         out = torch.empty((B * M, cout[2]), dtype=torch.float32, device=dev)
         sel = torch.empty((B * M, cout[2]), dtype=torch.uint8, device=dev)
-        _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf, cm[1])
-        ctx.save_for_backward(xyz, new_xyz, idx, feat_pm, out, sel, *Y, *vecs, *WTs, *gam, *bet, Wd[2])
+        out_rows = None
+        if want_rows and bf and cout[2] % 8 == 0:
+            out_rows = torch.empty((B * M, cout[2]), dtype=torch.bfloat16, device=dev)
+            _ext.call("vlp3d_sa_pool_rows", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, out_rows, sel, bf, cm[1])
+        else:
+            _ext.call("vlp3d_sa_pool", Y[2], B * M, S, cout[2], vecs[2][0], vecs[2][1], out, sel, bf, cm[1])
+        # (backward reads the gathered operand again for the first layer's weight gradient: the rows the forward read)
+        ctx.save_for_backward(xyz, new_xyz, idx, src, out, sel, *Y, *vecs, *WTs, *gam, *bet, Wd[2])
+        ctx.feat_shape = (B, N, C)
         ctx.cm = cm
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
         ctx.fbit = fbit
+        if want_rows:
+            if out_rows is None:   # configuration without the bf16 copy: an empty tensor keeps the output arity fixed
+                out_rows = torch.empty((0,), dtype=torch.bfloat16, device=dev)
+            ctx.mark_non_differentiable(out_rows)
+            return out, out_rows
         return out
 
     @staticmethod
-    def backward(ctx, dP):
+    def backward(ctx, dP, _drows=None):
         B, N, M, S, C, R, radius, bf, dt, cout, Ks, training = ctx.cfg
         cm = ctx.cm
         sv = ctx.saved_tensors
@@ -222,18 +239,25 @@ class FusedSAMLP(Function):
                     dnew = arena[o + n_df + n_dx:].view(B, M, 3) if need[1] else None
                     _ext.call("vlp3d_sa_bwd_gather", G, Y[0], cout[0], c5, WTs[0], kpad, idx, B, N, M, S, C, radius, dfeat,
                               dxyz, dnew, bf, *cm)
-        return (dxyz, dnew, None, dfeat, None, None, None, None, None, None, None, *dparams)
+        return (dxyz, dnew, None, dfeat, None, None, None, None, None, None, None, None, None, *dparams)
 
 
-def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None, inv=None, feat_c=None):
+def sa_mlp_pool(xyz, new_xyz, idx, feat_pm, radius, mlp_module, use_bf16, cmap=None, inv=None, feat_c=None, feat_rows=None,
+                want_rows=False):
     """Run the 3-layer SharedMLP + max-pool of an SA layer fused.  Returns pooled (B, npoint, C3) fp32.
     cmap: (rowptr, crow) of _lib.sa_compact(idx, N) — evaluate the stack on the distinct rows only (bf16 configuration);
     inv: (inv_start, inv_rows) of _lib.sa_inverse(idx, N, cmap) — atomic-free backward of the gather (bf16 configuration).
-    feat_pm may be BF16 rows (B, N, round_up(feat_c, 8)), columns beyond feat_c zero (bf16 configuration, no gradient to them)."""
+    feat_pm may be BF16 rows (B, N, round_up(feat_c, 8)), columns beyond feat_c zero (bf16 configuration, no gradient to them);
+    or fp32 rows with feat_rows = their bf16 copy (what the kernels then read; the gradient goes to feat_pm).  want_rows: also
+    return this level's pooled output as bf16 rows — the next level's feat_rows."""
     bns = [layer.bn.bn for layer in mlp_module]
     params = []
     for layer in mlp_module:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
     B, M = new_xyz.shape[:2]
-    out = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, inv, feat_c, *params)
-    return out.view(B, M, -1)
+    res = FusedSAMLP.apply(xyz, new_xyz, idx, feat_pm, radius, bns, bns[0].training, use_bf16, cmap, inv, feat_c, feat_rows,
+                           want_rows, *params)
+    if want_rows:   # -> (pooled (B, M, C3) fp32, the same as bf16 rows (B, M, C3) or None)
+        out, rows = res
+        return out.view(B, M, -1), (rows.view(B, M, -1) if rows.numel() else None)
+    return res.view(B, M, -1)

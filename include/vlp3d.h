@@ -157,9 +157,10 @@ int vlp3d_sa_compact(const int *idx, int B, int N, int M, int S, int *rowptr, vo
  * stats: (vlp3d_sa_stat_slabs(R) x 2 x cout) f64 — one [sum | sumsq] slab per workgroup, fully written (no atomics;
  * vlp3d_sa_bn_fold sums the slabs).  The same convention holds for `tstats` of vlp3d_sa_bwd_layer. */
 /* bf16_io of vlp3d_sa_fwd_gather and of vlp3d_sa_wgrad (gather != 0): bit 0 = bf16 storage / MFMA as everywhere; bit 1 (with
- * bit 0, K <= 160, M*S % 32 == 0 or a compact row map) = feat_pm points at BF16 feature rows of (C + 7) & ~7 columns, columns
- * [C, ..) zero — the loader's bf16 copy of the cloud's channels (input_pipeline.compress_cloud / prepare_batch): half the
- * gathered bytes, the same numbers (the fp32 rows are rounded to bf16 on their way into LDS anyway). */
+ * bit 0; K <= 160, or cout = 128 with K <= 288 and C % 8 == 0; M*S % 32 == 0 or a compact row map) = feat_pm points at BF16
+ * feature rows of (C + 7) & ~7 columns, columns [C, ..) zero — the loader's bf16 copy of the cloud's channels
+ * (input_pipeline.compress_cloud / prepare_batch) or the previous level's vlp3d_sa_pool_rows output: half the gathered bytes, the
+ * same numbers (the fp32 rows are rounded to bf16 on their way into LDS anyway). */
 int vlp3d_sa_stat_slabs(long long R);
 int vlp3d_sa_fwd_gather(const float *xyz, const float *new_xyz, const int *idx, const float *feat_pm, int B, int N,
                         int M, int S, int C, float radius, const void *W, int K, int cout, void *Y, double *stats,
@@ -172,6 +173,10 @@ int vlp3d_sa_fwd_layer(const void *Yin, long long R, int K, const float *scale, 
  * (position inside the ball; with rowptr != NULL inside the ball's compact rows). */
 int vlp3d_sa_pool(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
                   unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream);
+/* vlp3d_sa_pool that also writes the pooled rows as bf16 (out_bf16 (BM x C), C % 8 == 0): the next level's gather layer and its
+ * weight gradient read them through bf16_io bit 1 instead of rounding the fp32 rows themselves (the same values). */
+int vlp3d_sa_pool_rows(const void *Y, long long BM, int S, int C, const float *scale, const float *shift, float *out,
+                       void *out_bf16, unsigned char *sel_idx, int bf16_io, const int *rowptr, void *stream);
 /* G (BM*S x C) = dP routed to the selected sample where out > 0 (max-pool + ReLU backward). */
 int vlp3d_sa_pool_grad(const float *dP, const float *out, const unsigned char *sel_idx, long long BM, int S, int C,
                        void *G, int bf16_io, void *stream);
