@@ -131,6 +131,7 @@ class FusedSAMLP(Function):
         ctx.cm = cm
         ctx.cfg = (B, N, M, S, C, R, float(radius), bf, dt, cout, Ks, training)
         ctx.fbit = fbit
+        ctx.set_materialize_grads(False)   # no zero-filled cotangent for the bf16 rows output (a fill launch per backward)
         if want_rows:
             if out_rows is None:   # configuration without the bf16 copy: an empty tensor keeps the output arity fixed
                 out_rows = torch.empty((0,), dtype=torch.bfloat16, device=dev)
@@ -140,6 +141,8 @@ class FusedSAMLP(Function):
 
     @staticmethod
     def backward(ctx, dP, _drows=None):
+        if dP is None:   # (set_materialize_grads(False): the pooled output took no part in the loss)
+            return (None,) * (13 + 9)
         B, N, M, S, C, R, radius, bf, dt, cout, Ks, training = ctx.cfg
         cm = ctx.cm
         sv = ctx.saved_tensors

@@ -1,5 +1,5 @@
 # Round evidence: PMC traffic of the roofline kernels, bench JSON lines, rocprofv3 kernel stats + one steady-state step.
-# Usage (on the GPU box): bash tools/evidence.sh r04_d
+# Usage (on the GPU box): bash tools/evidence.sh r04_e
 set -e
 tag=$1
 cd $GRAFT_REPO_ROOT
