@@ -586,6 +586,10 @@ def main():
                        "input": ("every step's batch starts in pinned host memory (PCIe-inclusive; 3 batches cycled, "
                                  "input_pipeline.Prefetcher" + (", device-side training augmentation" if args.augment else "") + ")"
                                  if args.host_batches else "resident in HBM before the timed region"),
+                       "input_format": ("loader-prepared (grounding_step.prepare_batch): k/xyz fp32 + the cloud's feature channels as bf16 "
+                                        "rows (k/feat_bf: the values the first grouped-MLP layer rounds them to; bit-identical step, "
+                                        "DESIGN.md 4.20) + kernel-ready label dtypes" if (bf and "k/feat_bf" in (feed.data_dict or batch if feed is not None else batch))
+                                        else "loader-prepared (grounding_step.prepare_batch): k/xyz + k/feat_pm fp32 + kernel-ready label dtypes"),
                        "loss": float(loss.detach())},
             "allreduce_exposed_ms": exposed,
             "allreduce": ("two pieces: the head parameters' slice of the flat fp32 gradient buffer is reduced beside the backward of "
