@@ -1175,6 +1175,81 @@ __global__ __launch_bounds__(256) void pool8_kernel(const T *__restrict__ Y, int
   *reinterpret_cast<uint2 *>(sel_idx + bm * C + c0) = sb;
 }
 
+// The same pooling with a WAVE per ball (bf16 storage, C in {128, 256}): Q = 64 / (C/8) lanes share a channel group and walk the
+// ball's rows Q apart, then meet through shuffles (the better value; the smaller position on a tie: the reference's arg max is
+// the first row that attains it).  A ball of the compact form has ~25 rows at SA1: the thread-per-(ball, channel group) form
+// above walks them in seven dependent trips of four loads, this one in two (50 -> see DESIGN.md 4.20).
+template <int C8N>
+__global__ __launch_bounds__(256) void pool8_wave_kernel(const bf16 *__restrict__ Y, int S_dense, long long BM,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         float *__restrict__ out, unsigned char *__restrict__ sel_idx,
+                                                         const int *__restrict__ rowptr, bf16 *__restrict__ out_bf) {
+  constexpr int C = C8N * 8, Q = 64 / C8N;
+  const int lane = threadIdx.x & 63;
+  const long long bm = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bm >= BM) return;
+  const int g = lane % C8N, q = lane / C8N, c0 = g * 8;
+  const long long r0 = rowptr ? rowptr[bm] : bm * S_dense;
+  const int S = rowptr ? rowptr[bm + 1] - (int)r0 : S_dense;
+  const bf16 *p = Y + r0 * C + c0;
+  float sc[8], best[8];
+  int bi[8];
+  auto row8 = [&](const bf16 *qp, float (&v)[8]) { unpack8(*reinterpret_cast<const uint4 *>(qp), v); };   // one 16-byte load
+  const int s0 = min(q, S - 1);   // (a lane beyond the ball's rows repeats its last row: the tie rule discards it)
+  row8(p + (long long)s0 * C, best);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = scale[c0 + i];
+    bi[i] = s0;
+  }
+  int s = q + Q;
+  for (; s + 3 * Q < S; s += 4 * Q) {
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) row8(p + (long long)(s + u * Q) * C, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool better = sc[i] >= 0.f ? (v[u][i] > best[i]) : (v[u][i] < best[i]);
+        if (better) { best[i] = v[u][i]; bi[i] = s + u * Q; }
+      }
+  }
+  for (; s < S; s += Q) {
+    float v[8];
+    row8(p + (long long)s * C, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool better = sc[i] >= 0.f ? (v[i] > best[i]) : (v[i] < best[i]);
+      if (better) { best[i] = v[i]; bi[i] = s; }
+    }
+  }
+#pragma unroll
+  for (int off = C8N; off < 64; off <<= 1) {   // the Q lanes of a channel group are C8N apart
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float ov = __shfl_xor(best[i], off);
+      const int oi = __shfl_xor(bi[i], off);
+      const bool better = sc[i] >= 0.f ? (ov > best[i]) : (ov < best[i]);
+      if (better || (ov == best[i] && oi < bi[i])) { best[i] = ov; bi[i] = oi; }
+    }
+  }
+  if (q != 0) return;
+  float *o = out + bm * C + c0;
+  float4 o0, o1;
+  o0.x = fmaxf(0.f, best[0] * sc[0] + shift[c0 + 0]); o0.y = fmaxf(0.f, best[1] * sc[1] + shift[c0 + 1]);
+  o0.z = fmaxf(0.f, best[2] * sc[2] + shift[c0 + 2]); o0.w = fmaxf(0.f, best[3] * sc[3] + shift[c0 + 3]);
+  o1.x = fmaxf(0.f, best[4] * sc[4] + shift[c0 + 4]); o1.y = fmaxf(0.f, best[5] * sc[5] + shift[c0 + 5]);
+  o1.z = fmaxf(0.f, best[6] * sc[6] + shift[c0 + 6]); o1.w = fmaxf(0.f, best[7] * sc[7] + shift[c0 + 7]);
+  *reinterpret_cast<float4 *>(o) = o0;
+  *reinterpret_cast<float4 *>(o + 4) = o1;
+  if (out_bf != nullptr) *reinterpret_cast<uint4 *>(out_bf + bm * C + c0) = pack8(o0, o1);
+  uint2 sb;
+  sb.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+  sb.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+  *reinterpret_cast<uint2 *>(sel_idx + bm * C + c0) = sb;
+}
+
 // G3[(bm*S + s)][c] = (s == sel_idx[bm][c] && out[bm][c] > 0) ? dP[bm][c] : 0   (max-pool + ReLU backward)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_grad_kernel(const float *__restrict__ dP, const float *__restrict__ out,
@@ -2211,6 +2286,18 @@ static int sa_pool_impl(const void *Y, long long BM, int S, int C, const float *
   if (rowptr && (C % 8)) return VLP3D_EINVAL;  // compact row map: the 8-channel kernel only
   if (C % 8 == 0) {
     const dim3 grid8((unsigned)((BM * (C / 8) + 255) / 256));
+    static const bool wave_form = !(getenv("VLP3D_SA_POOL_WAVE") && atoi(getenv("VLP3D_SA_POOL_WAVE")) == 0);
+    if (bf16_io && wave_form && (C == 128 || C == 256) && BM < (1ll << 31)) {
+      const dim3 gridw((unsigned)((BM + 3) / 4));
+      if (C == 128)
+        hipLaunchKernelGGL((pool8_wave_kernel<16>), gridw, dim3(256), 0, (hipStream_t)stream, (const bf16 *)Y, S, BM, scale, shift,
+                           out, sel_idx, rowptr, (bf16 *)out_bf16);
+      else
+        hipLaunchKernelGGL((pool8_wave_kernel<32>), gridw, dim3(256), 0, (hipStream_t)stream, (const bf16 *)Y, S, BM, scale, shift,
+                           out, sel_idx, rowptr, (bf16 *)out_bf16);
+      VLP3D_LAUNCH_CHECK();
+      return VLP3D_OK;
+    }
     if (bf16_io)
       hipLaunchKernelGGL((pool8_kernel<bf16>), grid8, dim3(256), 0, (hipStream_t)stream, (const bf16 *)Y, S, C, BM, scale,
                          shift, out, sel_idx, rowptr, (bf16 *)out_bf16);
