@@ -147,6 +147,11 @@ SIGNATURES = {
     "vlp3d_sdpa_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "vlp3d_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                        _i, _i, _i, _i, _vp],
+    "vlp3d_sdpa_fwd_io": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vlp3d_sdpa_bwd_io": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                          _i, _i, _i, _i, _i, _vp],
+    "vlp3d_rows_chain_io": [_vp, _i, ctypes.c_longlong, _vp, _i, _vp, _vp],
+    "vlp3d_linear_fwd_rows16": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp],
 }
 
 _lib = None
@@ -625,6 +630,79 @@ def sdpa_bwd(q, k, v, H, bias, bias_mode, mask, out, lse, dout, need_dbias, bf16
     return dq, dk, dv, dbias
 
 
+def _row_stride_bf(t, name):
+    if not (t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)):
+        raise RuntimeError("%s must be (B, n, H*32) rows with one row stride" % name)
+    if t.dtype == torch.bfloat16:
+        if t.stride(1) % 8 or t.data_ptr() % 16:
+            raise RuntimeError("%s: bf16 rows need 16-byte aligned rows" % name)
+    elif t.dtype != torch.float32 or t.stride(1) % 4 or t.data_ptr() % 16:
+        raise RuntimeError("%s must be fp32 or bf16 rows, 16-byte aligned" % name)
+    return t.stride(1)
+
+
+def _sdpa_io(q, k, v, out_bf16):
+    io = int(q.dtype == torch.bfloat16) | (int(k.dtype == torch.bfloat16) << 1) | (int(bool(out_bf16)) << 2)
+    if k.dtype != v.dtype or io not in (0, 5, 7):
+        raise RuntimeError("sdpa rows: built combinations are fp32 everywhere, bf16 q / out with fp32 k / v, all bf16")
+    return io
+
+
+def sdpa_fwd_rows(q, k, v, H, mask, out_bf16):
+    """The bf16-MFMA core on operands that are bf16 rows already (vlp3d_sdpa_fwd_io): q (B,nq,H*32) fp32 or bf16, k / v
+    (B,nk,H*32) fp32 or bf16 (column blocks of a merged buffer allowed) -> (out (B,nq,H*32) bf16 if out_bf16 else fp32, lse)."""
+    ldq, ldk, ldv = _row_stride_bf(q, "q"), _row_stride_bf(k, "k"), _row_stride_bf(v, "v")
+    _chk_dev(q, ("k", k), ("v", v))
+    io = _sdpa_io(q, k, v, out_bf16)
+    B, nq, HD = q.shape
+    nk = k.shape[1]
+    if mask is not None:
+        _chk_float(mask, "attention_mask")
+    out = torch.empty((B, nq, HD), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=q.device)
+    lse = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(load().vlp3d_sdpa_fwd_io(_p(q), _p(k), _p(v), None, 0, _opt(mask), B, H, nq, nk, HD // H, _p(out), _p(lse), 1,
+                                        ldq, ldk, ldv, io, _stream()), "sdpa_fwd_io")
+    return out, lse
+
+
+def sdpa_bwd_rows(q, k, v, H, mask, out, lse, dout):
+    """Backward of sdpa_fwd_rows: fp32 dq / dk / dv; k, v (q, k, v) adjacent column blocks of one buffer give ONE merged
+    gradient buffer, as sdpa_bwd."""
+    ldq, ldk, ldv = _row_stride_bf(q, "q"), _row_stride_bf(k, "k"), _row_stride_bf(v, "v")
+    io = _sdpa_io(q, k, v, out.dtype == torch.bfloat16)
+    B, nq, HD = q.shape
+    nk = k.shape[1]
+    _chk_float(dout, "dout")
+    new = lambda n, c: torch.empty((B, n, c), dtype=torch.float32, device=q.device)
+    if _adjacent(q, k) and _adjacent(k, v) and ldq == 3 * HD:
+        g = new(nq, 3 * HD)
+        dq, dk, dv = g[..., :HD], g[..., HD:2 * HD], g[..., 2 * HD:]
+    elif _adjacent(k, v) and ldk == 2 * HD and ldq == HD:
+        g = new(nk, 2 * HD)
+        dq, dk, dv = new(nq, HD), g[..., :HD], g[..., HD:]
+    else:
+        raise RuntimeError("sdpa_bwd_rows: q | k | v merged, or q contiguous with k | v merged")
+    delta = torch.empty((B, H, nq), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(load().vlp3d_sdpa_bwd_io(_p(q), _p(k), _p(v), None, 0, _opt(mask), _p(out), _p(lse), _p(dout), B, H, nq, nk,
+                                        HD // H, _p(dq), _p(dk), _p(dv), None, _p(delta), 1, ldq, ldk, ldv, io, _stream()),
+               "sdpa_bwd_io")
+    return dq, dk, dv
+
+
+def linear_fwd_rows16(x2, w, bias):
+    """x2 (R, K) fp32 -> (R, N) bf16 rows = x2 w^T + bias with bf16 MFMA operands (vlp3d_linear_fwd_rows16)."""
+    _chk_float(x2, "x")
+    _chk_float(w, "weight")
+    R, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty((R, N), dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device):
+        _check(load().vlp3d_linear_fwd_rows16(_p(x2), _p(w), _opt(bias), R, K, N, _p(y), _stream()), "linear_fwd_rows16")
+    return y
+
+
 def group_rows(xyz, new_xyz, idx, feat_pm, radius, out_dtype):
     """-> (B*M*S, C+4) rows [features | (xyz[idx]-new_xyz)/radius | 0] in out_dtype (float32 / bfloat16)."""
     _chk_float(xyz, "xyz")
@@ -668,7 +746,7 @@ class SlabReduceDesc(ctypes.Structure):
 class LinearWgradJob(ctypes.Structure):
     """include/vlp3d.h: vlp3d_linear_wgrad_job."""
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("partials", ctypes.c_void_p), ("R", ctypes.c_longlong),
-                ("K", _i), ("N", _i), ("max_blocks", _i), ("with_bias", _i)]
+                ("K", _i), ("N", _i), ("max_blocks", _i), ("with_bias", _i), ("x_bf16", _i)]
 
 
 class RowsWgradJob(ctypes.Structure):
@@ -676,7 +754,7 @@ class RowsWgradJob(ctypes.Structure):
     _fields_ = [("G", ctypes.c_void_p), ("Ypre", ctypes.c_void_p), ("ldg", _i), ("bn5", ctypes.c_void_p),
                 ("X", ctypes.c_void_p), ("lda", _i), ("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p),
                 ("R", ctypes.c_longlong), ("K", _i), ("N", _i), ("partials", ctypes.c_void_p), ("max_blocks", _i),
-                ("with_bias", _i)]
+                ("with_bias", _i), ("x_bf16", _i)]
 
 
 class CopyDesc(ctypes.Structure):
@@ -724,7 +802,7 @@ class ChainStage(ctypes.Structure):
                 ("v_out", ctypes.c_void_p), ("act_kind", ctypes.c_int), ("act_p", ctypes.c_float), ("act_call", ctypes.c_int),
                 ("h_out", ctypes.c_void_p), ("has_ln", ctypes.c_int), ("res", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
                 ("beta", ctypes.c_void_p), ("ln_p", ctypes.c_float), ("ln_call", ctypes.c_int), ("eps", ctypes.c_float),
-                ("ln_out", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p)]
+                ("ln_out", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("v_out_bf16", ctypes.c_int)]
 
 
 def _prod(shape):
@@ -737,8 +815,8 @@ def _prod(shape):
 def rows_chain(X, stages, seed):
     """One launch of csrc/rows_chain.hip.  X (R, K0) fp32 contiguous CUDA; stages: list of dicts with the fields of
     vlp3d_chain_stage (tensors or None for the pointers; missing keys = NULL / 0, act_kind defaults to -1)."""
-    if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2):
-        raise RuntimeError("rows_chain: X must be a contiguous fp32 CUDA matrix")
+    if not (X.is_cuda and X.dtype in (torch.float32, torch.bfloat16) and X.is_contiguous() and X.dim() == 2):
+        raise RuntimeError("rows_chain: X must be a contiguous fp32 (or bf16 rows) CUDA matrix")
     R = X.shape[0]
     arr = (ChainStage * len(stages))()
     ptrs = ("W", "bias", "v_out", "h_out", "res", "gamma", "beta", "ln_out", "xhat", "rstd")
@@ -750,7 +828,8 @@ def rows_chain(X, stages, seed):
         for name in ptrs:
             t = st.get(name)
             if t is not None:
-                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == X.device) or \
+                want = torch.bfloat16 if (name == "v_out" and st.get("v_out_bf16")) else torch.float32
+                if not (t.is_cuda and t.dtype == want and t.is_contiguous() and t.device == X.device) or \
                         t.numel() != _prod(width[name](st)):
                     raise RuntimeError("rows_chain: %s must be contiguous fp32 on X's device with %s elements"
                                        % (name, width[name](st)))
@@ -759,11 +838,13 @@ def rows_chain(X, stages, seed):
         c.act_kind, c.act_p, c.act_call = int(st.get("act_kind", -1)), float(st.get("act_p", 0.0)), int(st.get("act_call", 0))
         c.has_ln, c.ln_p, c.ln_call = int(st.get("has_ln", 0)), float(st.get("ln_p", 0.0)), int(st.get("ln_call", 0))
         c.eps = float(st.get("eps", 1e-5))
+        c.v_out_bf16 = int(bool(st.get("v_out_bf16", 0)))
     if stages[0]["K"] != X.shape[1]:
         raise RuntimeError("rows_chain: X has %d columns, stage 0 reads %d" % (X.shape[1], stages[0]["K"]))
     with torch.cuda.device(X.device):
-        _check(load().vlp3d_rows_chain(X.data_ptr(), R, ctypes.cast(arr, ctypes.c_void_p), len(stages),
-                                       None if seed is None else seed.data_ptr(), _stream()), "vlp3d_rows_chain")
+        _check(load().vlp3d_rows_chain_io(X.data_ptr(), int(X.dtype == torch.bfloat16), R, ctypes.cast(arr, ctypes.c_void_p),
+                                          len(stages), None if seed is None else seed.data_ptr(), _stream()),
+               "vlp3d_rows_chain_io")
 
 
 class ChainBwdPoint(ctypes.Structure):
@@ -895,6 +976,7 @@ class SlabReduceQueue:
             dev = dy.device
             d.G, d.X, d.partials = dy.data_ptr(), x.data_ptr(), partials.data_ptr()
             d.ldg, d.lda, d.R, d.K, d.N, d.max_blocks, d.with_bias = N, K, R, K, N, max_blocks, with_bias
+            d.x_bf16 = int(x.dtype == torch.bfloat16)  # an attention core's bf16 rows as the layer's input
         for d, (fields, _keep) in zip(arr[len(self.wjobs):], self.rjobs):
             for k, v in fields.items():
                 if isinstance(v, tuple):  # (tensor, element offset)

@@ -47,7 +47,8 @@ __device__ __forceinline__ bf16x4 pack4(const float4 &v) {
 // TR = rows per workgroup block: 64 (waves 2 x 2, two accumulators each) or 32 (waves 1 x 4, one accumulator each: twice the
 // workgroups — two per CU at 16 384 rows — for the same LDS weight traffic per workgroup)
 // WB (with WT = false only): W already holds bf16 (a prepared weight of a grouped-MLP stack): staged without conversion.
-template <bool WT, int TR, bool WB = false>
+// YB (forward only): Y receives bf16 rows (row stride ldy elements) — a projection an attention core reads next.
+template <bool WT, int TR, bool WB = false, bool YB = false>
 __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
                                                           int kdim, int ncols, const float *__restrict__ bias,
                                                           const float *__restrict__ base, long long R, float *__restrict__ Y, int ldy) {
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256) void linear_tile_kernel(const float *__restric
         const long long row = row0 + 32 * wr + acc_row(i, half);
         if (row < R) {
           const long long o = row * ldy + col;
-          Y[o] = acc[t][i] + bv + (base ? base[o] : 0.f);
+          if (YB) reinterpret_cast<short *>(Y)[o] = bf16_bits(acc[t][i] + bv);
+          else Y[o] = acc[t][i] + bv + (base ? base[o] : 0.f);
         }
       }
     }
@@ -232,4 +234,18 @@ int vlp3d_internal_linear_tile_w16(const float *X, int ldx, const void *Wbf16, i
                      (const float *)nullptr, (const float *)nullptr, R, Y, ldy);
   VLP3D_LAUNCH_CHECK();
   return 0;
+}
+
+// Y16 (R x N bf16 rows) = X (R x K fp32) W^T + bias with bf16 MFMA operands: vlp3d_linear_fwd(bf16_mma = 1) whose result is
+// stored as bf16 — the query projection in front of an attention core that takes bf16 rows (vlp3d_sdpa_fwd_io, io bit 1).
+// R % 32 == 0, K % 16 == 0, N % 64 == 0.
+extern "C" int vlp3d_linear_fwd_rows16(const float *X, const float *W, const float *bias, long long R, int K, int N, void *Y16,
+                                       void *stream) {
+  if (!X || !W || !Y16 || R < 32 || (R & 31) || K < 16 || (K & 15) || N < 64 || (N & 63)) return VLP3D_EINVAL;
+  const long long nblk = (R + 31) / 32;
+  const dim3 grid((unsigned)(nblk < 4096 ? nblk : 4096), (unsigned)((N + TC - 1) / TC));
+  hipLaunchKernelGGL((linear_tile_kernel<false, 32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, X, K, W, K, K, N, bias,
+                     (const float *)nullptr, R, reinterpret_cast<float *>(Y16), N);
+  VLP3D_LAUNCH_CHECK();
+  return VLP3D_OK;
 }

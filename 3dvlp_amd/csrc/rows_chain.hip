@@ -35,7 +35,8 @@ static_assert(64 * LDF * 4 <= SW_BYTES, "fp32 tile must fit the weight chunk it 
 constexpr int lds_bytes(int tr) { return SW_BYTES + 2 * tr * LDX * 2; }  // 102 400 (TR = 64: one workgroup per CU) / 68 608 (32: two)
 
 struct ChainArgs {
-  const float *X;
+  const void *X;
+  int x_bf16;   // X holds bf16 rows (an attention core's output written as bf16): copied to the LDS tile as they are
   long long R;
   const unsigned long long *seed;
   int nstages;
@@ -81,15 +82,33 @@ __global__ __launch_bounds__(256) void rows_chain_kernel(const ChainArgs a) {
   const long long row0 = (long long)blockIdx.x * TR;
   const long long R = a.R;
 
-  {  // the input tile: TR rows x K0 columns, coalesced 16-byte row segments, all loads in flight before the conversions
+  if (a.x_bf16) {  // (kernel-uniform) the input tile is bf16 already: 16-byte chunks of 8 columns, no conversion
+    const int K0 = a.st[0].K, qs = K0 == KC ? 4 : 5, q = 1 << qs;  // chunks per row: 16 or 32
+    const int per = TR * q / 256;                                  // 2 .. 8
+    const short *Xb = reinterpret_cast<const short *>(a.X);
+    bf16x8 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < per) {
+        const int e = threadIdx.x + 256 * j, row = e >> qs, c8 = e & (q - 1);
+        v[j] = *reinterpret_cast<const bf16x8 *>(Xb + min(row0 + row, R - 1) * K0 + 8 * c8);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < per) {
+        const int e = threadIdx.x + 256 * j, row = e >> qs, c8 = e & (q - 1);
+        *reinterpret_cast<bf16x8 *>(cur + row * LDX + 8 * c8) = v[j];
+      }
+  } else {  // the input tile: TR rows x K0 columns, coalesced 16-byte row segments, all loads in flight before the conversions
     const int K0 = a.st[0].K, qs = K0 == KC ? 5 : 6, q = 1 << qs;  // float4 per row: 32 or 64
     const int per = TR * q / 256;                                  // 8 or 16
+    const float *Xf = reinterpret_cast<const float *>(a.X);
     float4 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (j < per) {
         const int e = threadIdx.x + 256 * j, row = e >> qs, c4 = e & (q - 1);
-        v[j] = ld4(a.X + min(row0 + row, R - 1) * K0 + 4 * c4);
+        v[j] = ld4(Xf + min(row0 + row, R - 1) * K0 + 4 * c4);
       }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -233,8 +252,15 @@ __global__ __launch_bounds__(256) void rows_chain_kernel(const ChainArgs a) {
           }
         } else {
           if (S.v_out && grow < R) {
-            *reinterpret_cast<float4 *>(S.v_out + o) = y0;
-            *reinterpret_cast<float4 *>(S.v_out + o + 4) = y1;
+            if (S.v_out_bf16) {  // the projection an attention core reads next: bf16 rows, what the core rounds to anyway
+              bf16x8 vb;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) vb[j] = bf16_bits(y[j]);
+              *reinterpret_cast<bf16x8 *>(reinterpret_cast<short *>(S.v_out) + o) = vb;
+            } else {
+              *reinterpret_cast<float4 *>(S.v_out + o) = y0;
+              *reinterpret_cast<float4 *>(S.v_out + o + 4) = y1;
+            }
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -479,11 +505,12 @@ __global__ __launch_bounds__(256) void rows_chain_bwd_kernel(const ChainBwdArgs 
 
 }  // namespace
 
-extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
-                                const unsigned long long *seed, void *stream) {
+extern "C" int vlp3d_rows_chain_io(const void *X, int x_bf16, long long R, const vlp3d_chain_stage *stages, int nstages,
+                                   const unsigned long long *seed, void *stream) {
   if (!X || !stages || R < 1 || nstages < 1 || nstages > VLP3D_CHAIN_MAX_STAGES) return VLP3D_EINVAL;
   ChainArgs a;
   a.X = X;
+  a.x_bf16 = x_bf16 != 0;
   a.R = R;
   a.seed = seed;
   a.nstages = nstages;
@@ -499,6 +526,7 @@ extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_s
       if (S.act_kind > 1 || S.act_p < 0.f || S.act_p >= 1.f || (S.act_p > 0.f && !seed)) return VLP3D_EINVAL;
     }
     if (R * (long long)S.N >= (1ll << 32)) return VLP3D_EINVAL;  // the dropout hash counts elements in 32 bits
+    if (S.v_out_bf16 && (S.has_ln || S.act_kind >= 0 || !S.v_out)) return VLP3D_EINVAL;  // plain projections only
     a.st[s] = S;
   }
   static const int tr = getenv("VLP3D_CHAIN_TILE_ROWS") ? atoi(getenv("VLP3D_CHAIN_TILE_ROWS")) : 32;
@@ -512,6 +540,11 @@ extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_s
     hipLaunchKernelGGL(rows_chain_kernel<32>, dim3((unsigned)((R + 31) / 32)), dim3(256), lds_bytes(32), (hipStream_t)stream, a);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
+}
+
+extern "C" int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
+                                const unsigned long long *seed, void *stream) {
+  return vlp3d_rows_chain_io(X, 0, R, stages, nstages, seed, stream);
 }
 
 extern "C" int vlp3d_rows_chain_bwd_blocks(long long R) { return (int)((R + BT - 1) / BT); }

@@ -76,6 +76,7 @@ struct RowGemmArgs {
   // BNRELU / BNBWD / PLAIN: source matrices (R x ldin)
   const void *Yin, *Gin;
   int ldin;
+  int in_bf16;                           // PLAIN operand of the batched linear weight gradients: Yin holds bf16 rows
   const float *scale, *shift;            // BNRELU: a = relu(y*scale + shift)
   const float *rstd, *nmean_rstd;        // BNBWD: yhat = y*rstd + nmean_rstd
   const float *k1, *k2, *k3;             // BNBWD: dy = k1*(g - k2 - yhat*k3)
@@ -1583,6 +1584,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         if (RAWF) va[j] = y;
         else va[j] = make_float4(fmaxf(0.f, y.x * a_sc.x + a_sh.x), fmaxf(0.f, y.y * a_sc.y + a_sh.y),
                                  fmaxf(0.f, y.z * a_sc.z + a_sh.z), fmaxf(0.f, y.w * a_sc.w + a_sh.w));
+      } else if (RAWF && LOADER == PLAIN && w.src.in_bf16) {  // (job-uniform) bf16 rows: widened here, re-rounded (exactly) at the LDS store
+        const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const short *>(w.src.Yin) + (long long)rr * w.src.ldin + k0);
+        va[j] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                            __uint_as_float(raw.y & 0xffff0000u));
       } else {
         va[j] = load_a4<T, LOADER>(w.src, rr, k0, 0, 0, 0);
       }
@@ -1826,7 +1831,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsWgradBatch t)
   const int ncb = jb.N / 64;
   if ((int)blockIdx.x >= jb.nblk || (int)blockIdx.y >= ncb) return;
   WgradArgs w = {};
-  w.colsum = jb.colsum;
+  w.colsum = jb.colsum & 1;
+  w.src.in_bf16 = jb.colsum >> 1;  // (bit 1 of the job's colsum word: X holds bf16 rows)
   w.src.K = jb.K; w.src.R = jb.R; w.src.Yin = jb.X; w.src.ldin = jb.lda; w.src.scale = jb.a_scale; w.src.shift = jb.a_shift;
   w.dy.ldin = jb.ldg;
   if (DYL == BNBWD) {
@@ -1962,10 +1968,23 @@ __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int
   const int c = blockIdx.x * SUMC + col;
   double a = 0.0, b = 0.0;
   if (c < C) {
-#pragma unroll 4
-    for (int k = grp; k < nslab; k += 64) {
-      a += slabs[(size_t)k * 2 * C + c];
-      b += slabs[(size_t)k * 2 * C + C + c];
+    // all of a thread's slabs requested before the first add (<= 16 per thread at the capped grids: one memory round
+    // trip instead of four; the adds keep their order, so the sums keep their bits)
+    for (int k0 = grp; k0 < nslab; k0 += 64 * 16) {
+      double va[16], vb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + 64 * u;
+        const bool in = k < nslab;
+        va[u] = in ? slabs[(size_t)k * 2 * C + c] : 0.0;
+        vb[u] = in ? slabs[(size_t)k * 2 * C + C + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + 64 * u < nslab) {
+          a += va[u];
+          b += vb[u];
+        }
     }
   }
   red[0][grp][col] = a;
@@ -2700,7 +2719,7 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
     const long long R = q.R;
     if (!q.G || !q.X || !q.partials || q.max_blocks < 1 || R < 32 || (R & 31) || R >= (1ll << 31) || K < 4 || (K & 3) ||
         ((K / 4) & (K / 4 - 1)) || (256 % (K / 4)) || K > 288 || N < 64 || (N & 63) || N > 512 || q.ldg < N || q.lda < K ||
-        (q.bn5 && (!q.Ypre || q.with_bias)) || (q.a_scale && !q.a_shift))
+        (q.bn5 && (!q.Ypre || q.with_bias)) || (q.a_scale && !q.a_shift) || (q.x_bf16 && (q.bn5 || q.a_scale || (q.lda & 3))))
       return VLP3D_EINVAL;
     const int KP = (K + 31) & ~31;
     const int per_wave = (2 * (KP / 32) + 3) / 4;  // output tiles per wave of a 64-column block
@@ -2728,7 +2747,7 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
       j.R = (int)q.R; j.K = q.K; j.N = q.N; j.ldg = q.ldg; j.lda = q.lda;
       j.nblk = (int)((ntiles + tpb - 1) / tpb);
       j.tpb = (int)tpb;
-      j.colsum = q.with_bias != 0;
+      j.colsum = (q.with_bias != 0 ? 1 : 0) | (q.x_bf16 ? 2 : 0);
       const int KP = (q.K + 31) & ~31;
       if (j.nblk > gx) gx = j.nblk;
       if (q.N / 64 > gy) gy = q.N / 64;
@@ -2755,7 +2774,7 @@ extern "C" int vlp3d_linear_wgrad_batch(const vlp3d_linear_wgrad_job *jobs, int 
     const vlp3d_linear_wgrad_job &q = jobs[i];
     if (q.K > 256) return VLP3D_EINVAL;
     r[i] = vlp3d_rows_wgrad_job{q.dY, nullptr, q.N, nullptr, q.X, q.K, nullptr, nullptr, q.R, q.K, q.N, q.partials,
-                                q.max_blocks, q.with_bias};
+                                q.max_blocks, q.with_bias, q.x_bf16};
   }
   return vlp3d_rows_wgrad_batch(r, count, stream);
 }

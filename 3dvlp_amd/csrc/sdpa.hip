@@ -60,6 +60,53 @@ __device__ __forceinline__ short bf16_bits(float v) {
   return *reinterpret_cast<short *>(&h);
 }
 
+// ---- operands that are ALREADY bf16 in memory (IO bits of vlp3d_sdpa_fwd_io / _bwd_io: 1 = q, 2 = k and v, 4 = out) ----
+// The bf16-MFMA kernels round q / k / v to bf16 on their way into registers / LDS; when the producer (a row chain's last
+// stage, a linear layer) stores them as bf16 rows the kernels move half the bytes and compute the same numbers.
+__device__ __forceinline__ float bf16_to_f32(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
+
+// elements [16*half, 16*half + 16) of head h of a row as the two bf16 MFMA operands of a lane
+template <bool B16>
+__device__ __forceinline__ void load_half_row_bf(const void *__restrict__ base, long long row, int ld, int h, int half,
+                                                 bf16x8 (&dst)[2]) {
+  if (B16) {
+    const bf16x8 *p = reinterpret_cast<const bf16x8 *>(reinterpret_cast<const short *>(base) + row * ld + h * D + half * 16);
+    dst[0] = p[0];
+    dst[1] = p[1];
+  } else {
+    float t[16];
+    load_half_row(reinterpret_cast<const float *>(base), row, ld, h, half, t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[u][j] = bf16_bits(t[8 * u + j]);
+  }
+}
+// the same 16 elements as floats
+template <bool B16>
+__device__ __forceinline__ void load_half_row_f(const void *__restrict__ base, long long row, int ld, int h, int half,
+                                                float (&dst)[16]) {
+  if (B16) {
+    bf16x8 t[2];
+    load_half_row_bf<true>(base, row, ld, h, half, t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[8 * u + j] = bf16_to_f32(t[u][j]);
+  } else {
+    load_half_row(reinterpret_cast<const float *>(base), row, ld, h, half, dst);
+  }
+}
+// four consecutive elements at element offset `off` as bf16 bits
+template <bool B16>
+__device__ __forceinline__ short4 load4_bf(const void *__restrict__ base, long long off) {
+  if (B16) return *reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(base) + off);
+  const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + off);
+  short4 r;
+  r.x = bf16_bits(v.x); r.y = bf16_bits(v.y); r.z = bf16_bits(v.z); r.w = bf16_bits(v.w);
+  return r;
+}
+
 template <bool BF, typename VA, typename VB>
 __device__ __forceinline__ f32x16 mfma_rows(const VA &a, const VB &b, f32x16 c) {
   if (BF) {
@@ -222,11 +269,13 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
 // K row-major [key][32 + 8] (a lane's MFMA operand = two ds_read_b128), V transposed [dim][nk + 4] (the operand of the
 // second product = four ds_read_b64 in the accumulator's row order) — six LDS reads per key tile, no conversions.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                           const float *__restrict__ v, const float *__restrict__ bias,
+template <int IO>  // bit 0: q holds bf16, bit 1: k and v hold bf16, bit 2: out is written as bf16 (row strides in elements)
+__global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const void *__restrict__ q, const void *__restrict__ k,
+                                                           const void *__restrict__ v, const float *__restrict__ bias,
                                                            int bias_mode, const float *__restrict__ mask, int H, int nq,
                                                            int nk, int nkp, int ldq, int ldk, int ldv, float scale,
-                                                           float *__restrict__ out, float *__restrict__ lse) {
+                                                           void *__restrict__ out, float *__restrict__ lse) {
+  constexpr bool Q16 = (IO & 1) != 0, KV16 = (IO & 2) != 0, O16 = (IO & 4) != 0;
   extern __shared__ __attribute__((aligned(16))) short sm_kv[];
   constexpr int KS = D + 8;        // K row stride (shorts): 80 B -> conflict-free b128 phases
   const int VS = nkp + 4;          // V^T row stride (shorts): (nkp/2 + 2) dwords -> conflict-free b64 phases
@@ -236,35 +285,29 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
   const int HD = H * D;
+  // the wave's query rows are requested first: their latency runs under the staging of K and V
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int qi = min(q0 + r, nq - 1);
+  const long long qrow = (long long)b * nq + qi;
+  bf16x8 qa[2];
+  load_half_row_bf<Q16>(q, qrow, ldq, h, half, qa);
   // ---- stage K, V of head (b,h): rows beyond nk are zero (their scores are masked out below)
   for (int c = threadIdx.x; c < nkp * (D / 4); c += 256) {
     const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    short4 kb = make_short4(0, 0, 0, 0), vb = kb;
     if (key < nk) {
       const long long krow = (long long)b * nk + key;
-      kv = *reinterpret_cast<const float4 *>(k + krow * ldk + h * D + d4);
-      vv = *reinterpret_cast<const float4 *>(v + krow * ldv + h * D + d4);
+      kb = load4_bf<KV16>(k, krow * ldk + h * D + d4);
+      vb = load4_bf<KV16>(v, krow * ldv + h * D + d4);
     }
-    short4 kb;
-    kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
     *reinterpret_cast<short4 *>(sK + key * KS + d4) = kb;
-    sV[(d4 + 0) * VS + key] = bf16_bits(vv.x);
-    sV[(d4 + 1) * VS + key] = bf16_bits(vv.y);
-    sV[(d4 + 2) * VS + key] = bf16_bits(vv.z);
-    sV[(d4 + 3) * VS + key] = bf16_bits(vv.w);
+    sV[(d4 + 0) * VS + key] = vb.x;
+    sV[(d4 + 1) * VS + key] = vb.y;
+    sV[(d4 + 2) * VS + key] = vb.z;
+    sV[(d4 + 3) * VS + key] = vb.w;
   }
   __syncthreads();
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
   if (q0 >= nq) return;  // whole wave (no barrier after this point)
-  const int qi = min(q0 + r, nq - 1);
-  const long long qrow = (long long)b * nq + qi;
-  float qreg[16];
-  load_half_row(q, qrow, ldq, h, half, qreg);
-  bf16x8 qa[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qa[t][j] = bf16_bits(qreg[8 * t + j]);
 
   f32x16 o = zero16();
   float m = -__builtin_inff(), l = 0.f;
@@ -322,12 +365,23 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const float *__restri
   l += __shfl_xor(l, 32);
   if (q0 + r < nq) {
     const float inv = 1.f / l;
-    float *__restrict__ orow = out + qrow * HD + h * D;
+    if (O16) {
+      short *__restrict__ orow = reinterpret_cast<short *>(out) + qrow * HD + h * D;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = dims 8g + 4*half + 0..3
-      float4 w;
-      w.x = o[4 * g + 0] * inv; w.y = o[4 * g + 1] * inv; w.z = o[4 * g + 2] * inv; w.w = o[4 * g + 3] * inv;
-      *reinterpret_cast<float4 *>(orow + 8 * g + 4 * half) = w;
+      for (int g = 0; g < 4; ++g) {
+        short4 w;
+        w.x = bf16_bits(o[4 * g + 0] * inv); w.y = bf16_bits(o[4 * g + 1] * inv);
+        w.z = bf16_bits(o[4 * g + 2] * inv); w.w = bf16_bits(o[4 * g + 3] * inv);
+        *reinterpret_cast<short4 *>(orow + 8 * g + 4 * half) = w;
+      }
+    } else {
+      float *__restrict__ orow = reinterpret_cast<float *>(out) + qrow * HD + h * D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = dims 8g + 4*half + 0..3
+        float4 w;
+        w.x = o[4 * g + 0] * inv; w.y = o[4 * g + 1] * inv; w.z = o[4 * g + 2] * inv; w.w = o[4 * g + 3] * inv;
+        *reinterpret_cast<float4 *>(orow + 8 * g + 4 * half) = w;
+      }
     }
     if (half == 0) lse[((long long)b * H + h) * nq + q0 + r] = m + __logf(l);
   }
@@ -430,9 +484,10 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_kernel(
 // backward 1, bf16-MFMA form with the head's K and V shared through LDS (same staging idea as sdpa_fwd_lds_kernel):
 // K row-major (S^T = K Q^T), V row-major (dP^T = V dO^T) and K transposed (dQ^T += K^T dS^T), all bf16, converted once.
 // ---------------------------------------------------------------------------------------------
+template <int IO>  // as sdpa_fwd_lds_kernel: bit 0 q, bit 1 k / v, bit 2 out hold bf16 (dout and the gradients stay fp32)
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ out,
+    const void *__restrict__ q, const void *__restrict__ k, const void *__restrict__ v,
+    const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const void *__restrict__ out,
     const float *__restrict__ lse, const float *__restrict__ dout, int H, int nq, int nk, int nkp, int ldq, int ldk,
     int ldv, float scale, float *__restrict__ dq, float *__restrict__ dbias, float *__restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) short sm_kv[];
@@ -441,21 +496,19 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   short *sK = sm_kv;                 // [nkp][KS]
   short *sV = sK + nkp * KS;         // [nkp][KS]
   short *sKt = sV + nkp * KS;        // [D][TS]
+  constexpr bool Q16 = (IO & 1) != 0, KV16 = (IO & 2) != 0, O16 = (IO & 4) != 0;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
   const int HD = H * D;
   for (int c = threadIdx.x; c < nkp * (D / 4); c += 256) {
     const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    short4 kb = make_short4(0, 0, 0, 0), vb = kb;
     if (key < nk) {
       const long long krow = (long long)b * nk + key;
-      kv = *reinterpret_cast<const float4 *>(k + krow * ldk + h * D + d4);
-      vv = *reinterpret_cast<const float4 *>(v + krow * ldv + h * D + d4);
+      kb = load4_bf<KV16>(k, krow * ldk + h * D + d4);
+      vb = load4_bf<KV16>(v, krow * ldv + h * D + d4);
     }
-    short4 kb, vb;
-    kb.x = bf16_bits(kv.x); kb.y = bf16_bits(kv.y); kb.z = bf16_bits(kv.z); kb.w = bf16_bits(kv.w);
-    vb.x = bf16_bits(vv.x); vb.y = bf16_bits(vv.y); vb.z = bf16_bits(vv.z); vb.w = bf16_bits(vv.w);
     *reinterpret_cast<short4 *>(sK + key * KS + d4) = kb;
     *reinterpret_cast<short4 *>(sV + key * KS + d4) = vb;
     sKt[(d4 + 0) * TS + key] = kb.x;
@@ -469,10 +522,11 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   const int qi = min(q0 + r, nq - 1);
   const long long qrow = (long long)b * nq + qi;
   const bool q_ok = q0 + r < nq;
-  float qreg[16], doreg[16], oreg[16];
-  load_half_row(q, qrow, ldq, h, half, qreg);
+  float doreg[16], oreg[16];
+  bf16x8 qa[2], da[2];
+  load_half_row_bf<Q16>(q, qrow, ldq, h, half, qa);
   load_half_row(dout, qrow, HD, h, half, doreg);
-  load_half_row(out, qrow, HD, h, half, oreg);
+  load_half_row_f<O16>(out, qrow, HD, h, half, oreg);
   float dl = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) dl += doreg[i] * oreg[i];
@@ -481,14 +535,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   if (q_ok && half == 0) delta[stat] = dl;
   const float lse_q = lse[stat];
   const long long bias_row = stat * nk;
-  bf16x8 qa[2], da[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      qa[t][j] = bf16_bits(qreg[8 * t + j]);
-      da[t][j] = bf16_bits(doreg[8 * t + j]);
-    }
+    for (int j = 0; j < 8; ++j) da[t][j] = bf16_bits(doreg[8 * t + j]);
   f32x16 dqa = zero16();
   for (int k0 = 0; k0 < nk; k0 += 32) {
     f32x16 s = zero16(), dp = zero16();
@@ -638,9 +688,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void sd
 // converted to bf16 ONCE while staging, row-major (S = Q K^T, dP = dO V^T: a lane's operand = two ds_read_b128) and
 // transposed (dV^T += dO^T P, dK^T += Q^T dS: four ds_read_b64 in the accumulator's row order); lse / delta as fp32.
 // ---------------------------------------------------------------------------------------------
-template <bool BIAS>  // BIAS = false: no bias registers in the match cores' instantiation (16 more cost them 12 %)
+template <bool BIAS, int IO = 0>  // BIAS = false: no bias registers in the match cores' instantiation (16 more cost them 12 %)
 __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const void *__restrict__ q, const void *__restrict__ k, const void *__restrict__ v,
     const float *__restrict__ bias, int bias_mode, const float *__restrict__ mask, const float *__restrict__ lse,
     const float *__restrict__ dout, const float *__restrict__ delta, int H, int nq, int nqp, int nk, int ldq, int ldk,
     int ldv, float scale, float *__restrict__ dk, float *__restrict__ dv, int wpb, int qsplit) {
@@ -659,14 +709,13 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
   const int HD = H * D, nthr = blockDim.x;
   for (int c = threadIdx.x; c < nqp * (D / 4); c += nthr) {
     const int qi = c / (D / 4), d4 = (c - qi * (D / 4)) * 4;
-    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv4 = qv;
+    float4 dv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    short4 qb = make_short4(0, 0, 0, 0), db;
     if (qi < nq) {
       const long long qrow = (long long)b * nq + qi;
-      qv = *reinterpret_cast<const float4 *>(q + qrow * ldq + h * D + d4);
+      qb = load4_bf<(IO & 1) != 0>(q, qrow * ldq + h * D + d4);
       dv4 = *reinterpret_cast<const float4 *>(dout + qrow * HD + h * D + d4);
     }
-    short4 qb, db;
-    qb.x = bf16_bits(qv.x); qb.y = bf16_bits(qv.y); qb.z = bf16_bits(qv.z); qb.w = bf16_bits(qv.w);
     db.x = bf16_bits(dv4.x); db.y = bf16_bits(dv4.y); db.z = bf16_bits(dv4.z); db.w = bf16_bits(dv4.w);
     *reinterpret_cast<short4 *>(sQ + qi * KS + d4) = qb;
     *reinterpret_cast<short4 *>(sDO + qi * KS + d4) = db;
@@ -690,17 +739,9 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
   const long long krow = (long long)b * nk + ki;
   const bool k_ok = k0 + r < nk;
   const bool masked = mask != nullptr && mask[(long long)b * nk + ki] == 0.f;
-  float kreg[16], vreg[16];
-  load_half_row(k, krow, ldk, h, half, kreg);
-  load_half_row(v, krow, ldv, h, half, vreg);
   bf16x8 kb[2], vb[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      kb[t][j] = bf16_bits(kreg[8 * t + j]);
-      vb[t][j] = bf16_bits(vreg[8 * t + j]);
-    }
+  load_half_row_bf<(IO & 2) != 0>(k, krow, ldk, h, half, kb);
+  load_half_row_bf<(IO & 2) != 0>(v, krow, ldv, h, half, vb);
   const long long stat0 = ((long long)b * H + h) * nq;
   f32x16 dka = zero16(), dva = zero16();
   for (int q0 = tile_ok ? 32 * qs : nq; q0 < nq; q0 += 32 * qsplit) {
@@ -827,53 +868,86 @@ bool bad(int B, int H, int nq, int nk, int Dh, int bias_mode) {
 
 }  // namespace
 
-extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
-                              const float *mask, int B, int H, int nq, int nk, int Dh, float *out, float *lse,
-                              int bf16_mma, int ldq, int ldk, int ldv, void *stream) {
+// io bits (bf16-MFMA LDS kernels only): 1 = q, 2 = k and v, 4 = out hold bf16 rows instead of fp32 (row strides in
+// elements; a bf16 operand needs 16-byte rows: stride % 8 == 0).  Combinations built: 0, 5 (cross-attention: q and out of the
+// 16 384-row side, k / v from the small fp32 projection of the tokens), 7 (self-attention on a merged bf16 q|k|v).
+static bool io_ok(int io) { return io == 0 || io == 5 || io == 7; }
+static bool bad_ld_io(int ldq, int ldk, int ldv, int io) {
+  return ((io & 1) && (ldq & 7)) || ((io & 2) && ((ldk | ldv) & 7));
+}
+
+extern "C" int vlp3d_sdpa_fwd_io(const void *q, const void *k, const void *v, const float *bias, int bias_mode,
+                                 const float *mask, int B, int H, int nq, int nk, int Dh, void *out, float *lse,
+                                 int bf16_mma, int ldq, int ldk, int ldv, int io, void *stream) {
   if (!q || !k || !v || !out || !lse || bad(B, H, nq, nk, Dh, bias_mode) || (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
-  if (bad_ld(ldq, ldk, ldv, H)) return VLP3D_EINVAL;
+  if (bad_ld(ldq, ldk, ldv, H) || !io_ok(io) || bad_ld_io(ldq, ldk, ldv, io)) return VLP3D_EINVAL;
+  if (io != 0 && !(bf16_mma && nk <= 384)) return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   const dim3 grid(vlp3d_cdiv(nq, 32), H, B);
+  const float *qf = reinterpret_cast<const float *>(q), *kf = reinterpret_cast<const float *>(k),
+              *vf = reinterpret_cast<const float *>(v);
+  float *of = reinterpret_cast<float *>(out);
   if (bf16_mma && nk <= 384) {  // K/V of a head shared by 4 waves through LDS (<= 55 KB)
     const int nkp = (nk + 31) & ~31;
     const size_t lds = ((size_t)nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
-    hipLaunchKernelGGL(sdpa_fwd_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, (hipStream_t)stream, q, k, v,
-                       bias, bias_mode, mask, H, nq, nk, nkp, ldq, ldk, ldv, scale, out, lse);
+    const dim3 g4(vlp3d_cdiv(nq, 128), H, B);
+#define VLP3D_SDPA_F(IOv) hipLaunchKernelGGL(sdpa_fwd_lds_kernel<IOv>, g4, dim3(256), lds, (hipStream_t)stream, q, k, v, \
+                                             bias, bias_mode, mask, H, nq, nk, nkp, ldq, ldk, ldv, scale, out, lse)
+    if (io == 5) VLP3D_SDPA_F(5);
+    else if (io == 7) VLP3D_SDPA_F(7);
+    else VLP3D_SDPA_F(0);
+#undef VLP3D_SDPA_F
   } else if (bf16_mma)
-    hipLaunchKernelGGL(sdpa_fwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask, H,
-                       nq, nk, ldq, ldk, ldv, scale, out, lse);
+    hipLaunchKernelGGL(sdpa_fwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, qf, kf, vf, bias, bias_mode, mask, H,
+                       nq, nk, ldq, ldk, ldv, scale, of, lse);
   else
-    hipLaunchKernelGGL(sdpa_fwd_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, q, k, v, bias, bias_mode, mask,
-                       H, nq, nk, ldq, ldk, ldv, scale, out, lse);
+    hipLaunchKernelGGL(sdpa_fwd_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, qf, kf, vf, bias, bias_mode, mask,
+                       H, nq, nk, ldq, ldk, ldv, scale, of, lse);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
 }
 
-extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
-                              const float *mask, const float *out, const float *lse, const float *dout, int B, int H,
-                              int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
+extern "C" int vlp3d_sdpa_fwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
+                              const float *mask, int B, int H, int nq, int nk, int Dh, float *out, float *lse,
                               int bf16_mma, int ldq, int ldk, int ldv, void *stream) {
+  return vlp3d_sdpa_fwd_io(q, k, v, bias, bias_mode, mask, B, H, nq, nk, Dh, out, lse, bf16_mma, ldq, ldk, ldv, 0, stream);
+}
+
+extern "C" int vlp3d_sdpa_bwd_io(const void *q, const void *k, const void *v, const float *bias, int bias_mode,
+                                 const float *mask, const void *out, const float *lse, const float *dout, int B, int H,
+                                 int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
+                                 int bf16_mma, int ldq, int ldk, int ldv, int io, void *stream) {
   if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta || bad(B, H, nq, nk, Dh, bias_mode) ||
       (bias_mode != 0 && !bias))
     return VLP3D_EINVAL;
-  if (bad_ld(ldq, ldk, ldv, H)) return VLP3D_EINVAL;
+  if (bad_ld(ldq, ldk, ldv, H) || !io_ok(io) || bad_ld_io(ldq, ldk, ldv, io)) return VLP3D_EINVAL;
   const float scale = 1.0f / sqrtf((float)Dh);
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(vlp3d_cdiv(nq, 32), H, B), gk(vlp3d_cdiv(nk, 32), H, B);
+  const float *qf = reinterpret_cast<const float *>(q), *kf = reinterpret_cast<const float *>(k),
+              *vf = reinterpret_cast<const float *>(v), *of = reinterpret_cast<const float *>(out);
+  const int nqp = (nq + 31) & ~31;
+  const size_t lds_kv = ((size_t)2 * nqp * (D + 8) + (size_t)2 * D * (nqp + 4)) * sizeof(short) + (size_t)2 * nqp * sizeof(float);
+  const bool dq_lds = nk <= 288 && (long long)B * H >= sdpa_lds_min_bh();
+  const bool dkv_lds = nq <= 512 && lds_kv <= 150 * 1024;
+  if (io != 0 && !(bf16_mma && dq_lds && dkv_lds && bias_mode == 0)) return VLP3D_EINVAL;  // bf16 rows: the LDS kernels only
   if (bf16_mma) {
-    if (nk <= 288 && (long long)B * H >= sdpa_lds_min_bh()) {  // K, V and K^T of a head staged once in LDS (<= 63 KB) and shared by
+    if (dq_lds) {  // K, V and K^T of a head staged once in LDS (<= 63 KB) and shared by
       // four query waves; with few (batch, head) pairs the one-wave form keeps more CUs busy
       const int nkp = (nk + 31) & ~31;
       const size_t lds = ((size_t)2 * nkp * (D + 8) + (size_t)D * (nkp + 4)) * sizeof(short);
-      hipLaunchKernelGGL(sdpa_bwd_dq_lds_kernel, dim3(vlp3d_cdiv(nq, 128), H, B), dim3(256), lds, s, q, k, v, bias,
-                         bias_mode, mask, out, lse, dout, H, nq, nk, nkp, ldq, ldk, ldv, scale, dq, dbias, delta);
+      const dim3 g4(vlp3d_cdiv(nq, 128), H, B);
+#define VLP3D_SDPA_DQ(IOv) hipLaunchKernelGGL(sdpa_bwd_dq_lds_kernel<IOv>, g4, dim3(256), lds, s, q, k, v, bias, \
+                                              bias_mode, mask, out, lse, dout, H, nq, nk, nkp, ldq, ldk, ldv, scale, dq, dbias, delta)
+      if (io == 5) VLP3D_SDPA_DQ(5);
+      else if (io == 7) VLP3D_SDPA_DQ(7);
+      else VLP3D_SDPA_DQ(0);
+#undef VLP3D_SDPA_DQ
     } else
-      hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
+      hipLaunchKernelGGL(sdpa_bwd_dq_kernel<true>, gq, dim3(64), 0, s, qf, kf, vf, bias, bias_mode, mask, of, lse, dout, H,
                          nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
-    const int nqp = (nq + 31) & ~31;
-    const size_t lds_kv = ((size_t)2 * nqp * (D + 8) + (size_t)2 * D * (nqp + 4)) * sizeof(short) + (size_t)2 * nqp * sizeof(float);
-    if (nq <= 512 && lds_kv <= 150 * 1024) {  // Q, dO (+ transposes) of a head staged once per workgroup of up to 4 key tiles
+    if (dkv_lds) {  // Q, dO (+ transposes) of a head staged once per workgroup of up to 4 key tiles
       // workgroup = wpb key tiles x qsplit query splits, at most 8 waves (174 registers per lane)
       const int tiles = vlp3d_cdiv(nk, 32), qtiles = nqp / 32;
       const long long ktw = (long long)B * H * tiles;
@@ -888,29 +962,39 @@ extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, co
       const size_t lds_red = (size_t)(qsplit >> 1) * wpb * 2048 * sizeof(float);
       if (lds_red > lds_all) lds_all = lds_red;
       const bool with_bias = bias_mode != 0;
+      const void *fn = with_bias ? reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<true, 0>)
+                       : io == 5 ? reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<false, 5>)
+                       : io == 7 ? reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<false, 7>)
+                                 : reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<false, 0>);
       if (lds_all > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(with_bias ? reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<true>)
-                                                     : reinterpret_cast<const void *>(sdpa_bwd_dkv_lds_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;
       }
-      if (with_bias)
-        hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel<true>, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s,
-                           q, k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
-                           qsplit);
-      else
-        hipLaunchKernelGGL(sdpa_bwd_dkv_lds_kernel<false>, dim3(vlp3d_cdiv(tiles, wpb), H, B), dim3(64 * wpb * qsplit), lds_all, s,
-                           q, k, v, bias, bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb,
-                           qsplit);
+      const dim3 gd(vlp3d_cdiv(tiles, wpb), H, B), bd(64 * wpb * qsplit);
+#define VLP3D_SDPA_DKV(BIASv, IOv) hipLaunchKernelGGL((sdpa_bwd_dkv_lds_kernel<BIASv, IOv>), gd, bd, lds_all, s, q, k, v, bias, \
+                                                      bias_mode, mask, lse, dout, delta, H, nq, nqp, nk, ldq, ldk, ldv, scale, dk, dv, wpb, qsplit)
+      if (with_bias) VLP3D_SDPA_DKV(true, 0);
+      else if (io == 5) VLP3D_SDPA_DKV(false, 5);
+      else if (io == 7) VLP3D_SDPA_DKV(false, 7);
+      else VLP3D_SDPA_DKV(false, 0);
+#undef VLP3D_SDPA_DKV
     } else
-      hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
+      hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<true>, gk, dim3(64), 0, s, qf, kf, vf, bias, bias_mode, mask, lse, dout, delta,
                          H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
   } else {
-    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<false>, gq, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, out, lse, dout, H,
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<false>, gq, dim3(64), 0, s, qf, kf, vf, bias, bias_mode, mask, of, lse, dout, H,
                        nq, nk, ldq, ldk, ldv, scale, dq, dbias, delta);
-    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<false>, gk, dim3(64), 0, s, q, k, v, bias, bias_mode, mask, lse, dout, delta,
+    hipLaunchKernelGGL(sdpa_bwd_dkv_kernel<false>, gk, dim3(64), 0, s, qf, kf, vf, bias, bias_mode, mask, lse, dout, delta,
                        H, nq, nk, ldq, ldk, ldv, scale, dk, dv);
   }
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
+}
+
+extern "C" int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *bias, int bias_mode,
+                              const float *mask, const float *out, const float *lse, const float *dout, int B, int H,
+                              int nq, int nk, int Dh, float *dq, float *dk, float *dv, float *dbias, float *delta,
+                              int bf16_mma, int ldq, int ldk, int ldv, void *stream) {
+  return vlp3d_sdpa_bwd_io(q, k, v, bias, bias_mode, mask, out, lse, dout, B, H, nq, nk, Dh, dq, dk, dv, dbias, delta,
+                           bf16_mma, ldq, ldk, ldv, 0, stream);
 }

@@ -4,6 +4,8 @@ Computes softmax(q k^T / sqrt(d) [+bias | *weights] [key mask]) v per head from 
 (b, n, h*d) tensors — the part of models/transformer/attention.py:63-75 between the fc_q/k/v and
 fc_o linears — without ever materialising the (b,h,nq,nk) attention matrix.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -95,6 +97,61 @@ class _SDPAMerged(Function):
         else:
             da, db = dq, (dk._base if dk._base is not None else torch.cat([dk, dv], -1))
         return da, db, dbias, None, None, None, None
+
+
+def rows_supported(nq, nk, batch_heads):
+    """Shapes the bf16-rows cores take (vlp3d_sdpa_fwd_io / _bwd_io: the LDS kernels of the bf16-MFMA configuration)."""
+    return nk <= 288 and nq <= 512 and batch_heads >= int(os.environ.get("VLP3D_SDPA_LDS_MIN_BH", 64))
+
+
+class _SDPARows(Function):
+    """The cores of the match decoder on bf16 ROWS (vlp3d_sdpa_fwd_io / _bwd_io): q, out (and k, v of a merged self-attention
+    projection) cross memory once, as bf16 — SURVEY.md §8(d)'s bytes.  The bf16-MFMA kernels round q / k / v to bf16 anyway, so
+    the forward numbers are those of the fp32-row cores.
+
+    Autograd sees fp32 SHELLS: `a_shell` and the returned out shell are fp32 tensors of the right shape whose storage is never
+    read or written.  (The engine converts a gradient to the dtype of the tensor it belongs to: a bf16 tensor in the graph
+    would receive its gradient through an extra conversion launch, rounded.)  The values travel beside the shells as bf16 rows:
+    `a_rows` in — q (b, nq, h*32) with `b_` = [k | v] fp32, or the merged [q | k | v] (b, n, 3*h*32) with `b_` None — and
+    `out_rows` out (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, a_shell, a_rows, b_, H, mask):
+        HD = H * 32
+        if b_ is None:
+            q, k, v = a_rows[..., :HD], a_rows[..., HD:2 * HD], a_rows[..., 2 * HD:]
+        else:
+            b_ = b_.contiguous()
+            q, k, v = a_rows, b_[..., :HD], b_[..., HD:]
+        out_rows, lse = _ext.sdpa_fwd_rows(q, k, v, H, mask, True)
+        ctx.save_for_backward(a_rows, b_, mask, out_rows, lse)
+        ctx.H = H
+        ctx.mark_non_differentiable(out_rows)
+        return torch.empty(out_rows.shape, dtype=torch.float32, device=out_rows.device), out_rows
+
+    @staticmethod
+    def backward(ctx, dout, _drows):
+        a_rows, b_, mask, out_rows, lse = ctx.saved_tensors
+        HD = ctx.H * 32
+        if b_ is None:
+            q, k, v = a_rows[..., :HD], a_rows[..., HD:2 * HD], a_rows[..., 2 * HD:]
+        else:
+            q, k, v = a_rows, b_[..., :HD], b_[..., HD:]
+        dq, dk, dv = _ext.sdpa_bwd_rows(q, k, v, ctx.H, mask, out_rows, lse, dout.contiguous())
+        if b_ is None:
+            return dq._base, None, None, None, None
+        return dq, None, dk._base, None, None
+
+
+def sdpa_rows(a_shell, a_rows, b_, h, attention_mask=None):
+    """-> (out shell fp32, out rows bf16); see _SDPARows.  Check rows_supported() first."""
+    nk = a_rows.shape[1] if b_ is None else b_.shape[1]
+    mask = _key_mask(attention_mask, a_rows.shape[0], nk)
+    if mask is False:
+        raise RuntimeError("fused sdpa: unsupported attention_mask shape")
+    if mask is not None:
+        mask = mask.to(torch.float32).contiguous()
+    return _SDPARows.apply(a_shell, a_rows, b_, h, mask)
 
 
 def sdpa_merged(a, b_, h, attention_weights=None, way="add", attention_mask=None, bf16_mma=None):

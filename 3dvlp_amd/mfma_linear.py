@@ -53,11 +53,13 @@ def weight_grad(dy2, x2, N, K, want_db, bf):
     """(dW (N, K), db (N) or None) of y = x W^T + b from dy2 (R, N), x2 (R, K): launched now, or queued when a deferred
     slab-reduce queue is open (one batched launch for all queued layers at the end of backward)."""
     R = x2.shape[0]
+    q = _ext.slab_queue()
+    batched = q is not None and bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
+    if x2.dtype == torch.bfloat16 and not batched:
+        x2 = x2.float()  # bf16 rows (an attention core's output) are an operand form of the batched kernel only
     # dW and (when asked for) the bias gradient come out of ONE kernel pair: [dW | db] contiguous
     dwb = torch.empty((N * K + (N if want_db else 0),), dtype=torch.float32, device=dy2.device)
     nblk = max(16, min(WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))  # few slabs for few rows: the slab sum reads nblk*N*K floats
-    q = _ext.slab_queue()
-    batched = q is not None and bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
     if batched:  # the batch supplies the parallelism: fewer, longer row groups per layer = a quarter of the slab traffic
         nblk = max(8, min(BATCH_WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))
     part = torch.empty((nblk, dwb.numel()), dtype=torch.float32, device=dy2.device)
@@ -119,6 +121,58 @@ class _Linear(Function):
         elif want_db:
             db = dy2.sum(0)
         return dx, dw, db, None, None
+
+
+class _LinearRows16(Function):
+    """linear(x, w, b, bf16_mma=True, with_residual=True) whose result is STORED as bf16 rows (vlp3d_linear_fwd_rows16): the
+    query projection in front of an attention core that reads bf16 rows (fused_attention.sdpa_rows).  Returns (y shell — an
+    fp32 tensor autograd routes the gradient through, storage untouched —, x_res, y rows bf16 (non-differentiable))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        R, K = x2.shape
+        N = weight.shape[0]
+        w = weight.contiguous()
+        rows = _ext.linear_fwd_rows16(x2, w, bias)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        rows = rows.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(rows)
+        return torch.empty(rows.shape, dtype=torch.float32, device=x.device), x.view_as(x), rows
+
+    @staticmethod
+    def backward(ctx, dy, dres, _drows):
+        x2, w = ctx.saved_tensors
+        R, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(R, N).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, K), dtype=torch.float32, device=dy.device)
+            base = None if dres is None else dres.reshape(R, K).contiguous()
+            _ext.call("vlp3d_linear_dgrad", dy2, w, R, N, K, dx, base, 1)
+            dx = dx.view(ctx.xshape)
+        elif dres is not None:
+            dx = dres
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw, db = weight_grad(dy2, x2, N, K, want_db, 1)
+        elif want_db:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def rows16_supported(x, weight):
+    R = x.numel() // x.shape[-1]
+    N, K = weight.shape
+    return supported(x, weight) and K % 32 == 0 and N % 64 == 0 and R % 32 == 0 and not torch.is_autocast_enabled("cuda")
+
+
+def linear_rows16(x, weight, bias=None):
+    """-> (y shell, x_res, y rows bf16); see _LinearRows16.  Check rows16_supported() first."""
+    return _LinearRows16.apply(x, weight, bias)
 
 
 class bf16_mma:

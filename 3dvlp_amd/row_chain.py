@@ -65,15 +65,24 @@ def supported(x, stages, rows=None):
     return True
 
 
+_T0 = 5  # position of the first of `tensors` among _Chain.forward's inputs
+
+
 class _Chain(Function):
     @staticmethod
-    def forward(ctx, spec, seed, X, *tensors):
+    def forward(ctx, spec, seed, X, x_rows, last_rows, *tensors):
         # spec: per stage (iW, ib, act_kind, act_p, act_call, has_ln, res, ig, ibeta, ln_p, ln_call, eps); indices into
         # `tensors`; res = ("ext", index) | ("tile", j)
+        # x_rows (bf16, or None): the VALUES of the input rows — X is then an fp32 shell autograd routes the gradient through,
+        # its storage never read (an attention core's bf16 output, fused_attention.sdpa_rows).  last_rows: the last stage (a
+        # plain projection) stores bf16 rows, returned as an extra non-differentiable output; its fp32 tile is a shell.
         R = X.shape[0]
         dev = X.device
+        if x_rows is not None:
+            X = x_rows
         tiles, zs, xhats, rstds, descs = [X], [], [], [], []
-        for (iW, ib, act_kind, act_p, act_call, has_ln, res, ig, ibeta, ln_p, ln_call, eps) in spec:
+        out_rows = None
+        for si, (iW, ib, act_kind, act_p, act_call, has_ln, res, ig, ibeta, ln_p, ln_call, eps) in enumerate(spec):
             W = tensors[iW]
             N, K = W.shape
             d = {"W": W, "bias": None if ib is None else tensors[ib], "N": N, "K": K, "act_kind": act_kind, "act_p": act_p,
@@ -88,6 +97,9 @@ class _Chain(Function):
             elif act_kind >= 0:
                 z = torch.empty((R, N), dtype=torch.float32, device=dev)
                 d.update(v_out=z, h_out=out)
+            elif last_rows and si + 1 == len(spec):
+                out_rows = torch.empty((R, N), dtype=torch.bfloat16, device=dev)
+                d.update(v_out=out_rows, v_out_bf16=1)
             else:
                 d.update(v_out=out)
             descs.append(d)
@@ -113,6 +125,9 @@ class _Chain(Function):
         ctx.layout = ([t is not None for t in zs], [t is not None for t in xhats])
         ctx.save_for_backward(*keep)
         ctx.set_materialize_grads(False)
+        if out_rows is not None:
+            ctx.mark_non_differentiable(out_rows)
+            return tuple(tiles[1:]) + (out_rows,)
         return tuple(tiles[1:])
 
     @staticmethod
@@ -130,7 +145,7 @@ class _Chain(Function):
         rstds = [next(rest) if h else None for h in has_ln]
         R = X.shape[0]
         grads = [None] * ctx.n_tensors
-        pend = [None] + [None if d is None else d.reshape(R, -1).contiguous() for d in douts]
+        pend = [None] + [None if d is None else d.reshape(R, -1).contiguous() for d in douts[:n]]
 
         def accumulate(slot, g):
             return g if slot is None else slot + g
@@ -154,8 +169,8 @@ class _Chain(Function):
                 gz = torch.empty_like(g)
                 _ext.call("vlp3d_act_dropout", zs[s], g, g.numel(), act_kind, act_p, seed, act_call, gz, None)
                 g = gz
-            want_db = ib is not None and ctx.needs_input_grad[3 + ib]
-            if ctx.needs_input_grad[3 + iW]:
+            want_db = ib is not None and ctx.needs_input_grad[_T0 + ib]
+            if ctx.needs_input_grad[_T0 + iW]:
                 dw, db = mfma_linear.weight_grad(g, tiles[s], N, K, want_db, 1)
                 grads[iW] = dw
                 if want_db:
@@ -225,8 +240,8 @@ class _Chain(Function):
             for s in range(top, -1, -1):
                 iW, ib = spec[s][0], spec[s][1]
                 N, K = tensors[iW].shape
-                want_db = ib is not None and ctx.needs_input_grad[3 + ib]
-                if ctx.needs_input_grad[3 + iW]:
+                want_db = ib is not None and ctx.needs_input_grad[_T0 + ib]
+                if ctx.needs_input_grad[_T0 + iW]:
                     dw, db = mfma_linear.weight_grad(gouts[s], tiles[s], N, K, want_db, 1)
                     grads[iW] = dw
                     if want_db:
@@ -243,13 +258,21 @@ class _Chain(Function):
         for i, t in enumerate(tensors):  # residual tensors keep the caller's shape
             if grads[i] is not None and grads[i].shape != t.shape:
                 grads[i] = grads[i].view(t.shape)
-        return (None, None, gX) + tuple(grads)
+        return (None, None, gX, None, None) + tuple(grads)
 
 
-def run(x, stages, training=True):
-    """x (..., K0) -> tuple of t_1..t_n, each (R, N_s) with R = rows of x.  Check `supported(x, stages)` first."""
+def run(x, stages, training=True, x_rows=None, last_rows=False):
+    """x (..., K0) -> tuple of t_1..t_n, each (R, N_s) with R = rows of x.  Check `supported(x, stages)` first.
+    x_rows: the input's values as bf16 rows (x is then an fp32 shell, see _Chain.forward); last_rows: t_n's values come back
+    as bf16 rows in an extra last element of the tuple (t_n itself is then a shell)."""
     X = x.reshape(-1, x.shape[-1]).contiguous()
     R = X.shape[0]
+    if x_rows is not None:
+        x_rows = x_rows.reshape(R, -1).contiguous()
+        if x_rows.dtype != torch.bfloat16 or x_rows.shape != X.shape:
+            raise RuntimeError("row_chain.run: x_rows must be the bf16 rows of x")
+    if last_rows and (stages[-1]["ln"] is not None or stages[-1]["act"] is not None):
+        raise RuntimeError("row_chain.run: last_rows needs a plain projection as the last stage")
     tensors, spec = [], []
 
     def slot(t):
@@ -271,4 +294,4 @@ def run(x, stages, training=True):
             spec.append((iW, ib, _ACTS[st["act"]], p, add_norm.next_call(), False, None, None, None, 0.0, 0, 0.0))
         else:
             spec.append((iW, ib, -1, 0.0, 0, False, None, None, None, 0.0, 0, 0.0))
-    return _Chain.apply(tuple(spec), add_norm.state(X.device), X, *tensors)
+    return _Chain.apply(tuple(spec), add_norm.state(X.device), X, x_rows, bool(last_rows), *tensors)

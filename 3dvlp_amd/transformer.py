@@ -7,6 +7,8 @@ runs in the fused HIP kernel (``impl='hip'``, the default: no (B,h,nq,nk) matrix
 ``impl='torch'`` is the unfused formulation, kept ONLY as an explicit opt-in for host-logic unit
 tests and A/B numerics — it is never selected automatically.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -16,6 +18,10 @@ from .ddp import merge_adjacent
 from .mfma_linear import linear as _linear
 
 DEFAULT_IMPL = "hip"
+# The match decoder's attention cores on bf16 ROWS (SURVEY.md §8(d)'s bytes: q, k, v, out touched once as bf16): the row chains
+# / the query projection store what the cores read as bf16 and the cores store what the chains read as bf16 — the values the
+# bf16-MFMA kernels round their operands to anyway.  "0": fp32 rows between the launches (round 3's form).
+ATTN_BF16_ROWS = os.environ.get("VLP3D_ATTN_BF16_ROWS", "1") != "0"
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -252,23 +258,40 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
     out, _, q_res = mha.attention(query, query, query, need_att=False, with_residual=True)
     x = add_norm.add_norm_rep(q_res, out, mha.layer_norm, rep, mha.dropout.p, mha.training).reshape(R, C)
     ca = l0.enc_dec_attention.attention
-    q, x = _linear(x, ca.fc_q.weight, ca.fc_q.bias, with_residual=True)
+    # bf16 rows between the chains and the cores (ATTN_BF16_ROWS): q / q|k|v / the cores' outputs exist as bf16 rows only; the
+    # fp32 tensors of the same names are shells that carry the autograd edges (fused_attention._SDPARows)
+    rows = (ATTN_BF16_ROWS and bf and h * 32 == C and fused_attention.rows_supported(K, max(K, key.shape[1]), B * rep * h)
+            and mfma_linear.rows16_supported(x, ca.fc_q.weight))
+    q_rows = None
+    if rows:
+        q, x, q_rows = mfma_linear.linear_rows16(x, ca.fc_q.weight, ca.fc_q.bias)
+    else:
+        q, x = _linear(x, ca.fc_q.weight, ca.fc_q.bias, with_residual=True)
     tail_out = None
     for i, layer in enumerate(layers):
         ca = layer.enc_dec_attention.attention
+        more = i + 1 < len(layers)
         kv = _linear(key, merge_adjacent([ca.fc_k.weight, ca.fc_v.weight]), merge_adjacent([ca.fc_k.bias, ca.fc_v.bias]))
-        a = fused_attention.sdpa_merged(q.view(B * rep, K, C), kv, h, None, "add", None, bf16_mma=bf)
         st = plan[i]
         st[0]["res"] = x
-        t = row_chain.run(a.reshape(R, C), st, layer.training)
+        if rows:
+            a, a_rows = fused_attention.sdpa_rows(q.view(B * rep, K, C), q_rows.view(B * rep, K, C), kv, h)
+            t = row_chain.run(a.reshape(R, C), st, layer.training, x_rows=a_rows, last_rows=more)
+        else:
+            a = fused_attention.sdpa_merged(q.view(B * rep, K, C), kv, h, None, "add", None, bf16_mma=bf)
+            t = row_chain.run(a.reshape(R, C), st, layer.training)
         x = t[2]
-        if i + 1 < len(layers):
+        if more:
             nl = layers[i + 1]
-            a = fused_attention.sdpa_merged(t[3].view(B * rep, K, 3 * C), None, h, None, "add", None, bf16_mma=bf)
             sa, nca = nl.self_attention, nl.enc_dec_attention.attention
-            x, q = row_chain.run(a.reshape(R, C), [
-                row_chain.linear_add_norm(sa.attention.fc_o.weight, sa.attention.fc_o.bias, sa.layer_norm, x, sa.dropout.p),
-                row_chain.linear(nca.fc_q.weight, nca.fc_q.bias)], nl.training)
+            head = [row_chain.linear_add_norm(sa.attention.fc_o.weight, sa.attention.fc_o.bias, sa.layer_norm, x, sa.dropout.p),
+                    row_chain.linear(nca.fc_q.weight, nca.fc_q.bias)]
+            if rows:
+                a, a_rows = fused_attention.sdpa_rows(t[3].view(B * rep, K, 3 * C), t[4].view(B * rep, K, 3 * C), None, h)
+                x, q, q_rows = row_chain.run(a.reshape(R, C), head, nl.training, x_rows=a_rows, last_rows=True)
+            else:
+                a = fused_attention.sdpa_merged(t[3].view(B * rep, K, 3 * C), None, h, None, "add", None, bf16_mma=bf)
+                x, q = row_chain.run(a.reshape(R, C), head, nl.training)
         elif tail:
             tail_out = t[-1]
     return x.view(B * rep, K, C), tail_out

@@ -411,6 +411,22 @@ int vlp3d_sdpa_bwd(const float *q, const float *k, const float *v, const float *
                    int nk, int D, float *dq, float *dk, float *dv, float *dbias, float *delta, int bf16_mma,
                    int ldq, int ldk, int ldv, void *stream);
 
+/* The same cores on operands that already ARE bf16 in memory — SURVEY.md §8(d)'s bytes for the attention cores (q, k, v, out
+ * touched once as bf16).  io bits: 1 = q, 2 = k and v, 4 = out (written by _fwd_io, read by _bwd_io) hold bf16 rows instead of
+ * fp32; strides stay in ELEMENTS (a bf16 operand needs stride % 8 == 0); dout and dq / dk / dv stay fp32 with the strides of
+ * q / k / v.  Built: io = 0, 5 (proposal <-> token cross-attention, mmattention.py:75-80: the 16 384-row q and out as bf16,
+ * k / v from the small fp32 projection of the tokens), 7 (self-attention on a merged bf16 q|k|v, mmattention.py:70-73).
+ * io != 0 requires bf16_mma, the LDS kernels' shapes (nk <= 288, nq <= 512, B*H >= 64) and bias_mode 0 in backward; else
+ * VLP3D_EINVAL.  The bf16-MFMA kernels round q / k / v to bf16 anyway: the forward results are the fp32-row results to the
+ * bit (out rounded once more when stored), the backward differs only through delta = rowsum(dout * out). */
+int vlp3d_sdpa_fwd_io(const void *q, const void *k, const void *v, const float *bias, int bias_mode, const float *mask,
+                      int B, int H, int nq, int nk, int D, void *out, float *lse, int bf16_mma, int ldq, int ldk, int ldv,
+                      int io, void *stream);
+int vlp3d_sdpa_bwd_io(const void *q, const void *k, const void *v, const float *bias, int bias_mode, const float *mask,
+                      const void *out, const float *lse, const float *dout, int B, int H, int nq, int nk, int D, float *dq,
+                      float *dk, float *dv, float *dbias, float *delta, int bf16_mma, int ldq, int ldk, int ldv, int io,
+                      void *stream);
+
 /* ---- exact-fp32 dense stacks on point-major rows (csrc/rows_mlp.hip) -------------------------------------------
  * The 1x1 Conv(+bias) -> BatchNorm -> ReLU chains of PointnetFPModule (pointnet2_modules.py:403-416), VotingModule
  * (voting_module.py:33-60) and StandardROIHeads (roi_heads.py:15-147) as products on ROW-MAJOR matrices with the
@@ -442,11 +458,17 @@ typedef struct vlp3d_rows_wgrad_job {
   int K, N;
   float *partials;
   int max_blocks, with_bias;
+  int x_bf16;  /* plain-linear jobs only (bn5 == a_scale == NULL): X holds bf16 rows, lda in elements */
 } vlp3d_rows_wgrad_job;
 /* Weight gradients of `count` rows-stack layers (Conv1d + BatchNorm1d + ReLU stacks of the FP / voting / ROI / relation heads,
  * pointnet2_modules.py:371-416, voting_module.py:33-60, roi_heads.py:15-147) in a few launches: jobs of one kernel
  * instantiation share a launch (bf16-MFMA configuration).  Slabs as vlp3d_rows_wgrad(..., defer_reduce = 1) writes them. */
 int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int count, void *stream);
+
+/* vlp3d_linear_fwd (bf16_mma = 1) with the result stored as bf16 rows (R x N): the query projection in front of an attention
+ * core that reads bf16 rows (vlp3d_sdpa_fwd_io).  R % 32 == 0, K % 16 == 0, N % 64 == 0. */
+int vlp3d_linear_fwd_rows16(const float *X, const float *W, const float *bias, long long R, int K, int N, void *Y16,
+                            void *stream);
 
 /* One weight-gradient job of vlp3d_linear_wgrad_batch: the arguments of vlp3d_linear_wgrad(dY, X, R, K, N, NULL, partials,
  * max_blocks, with_bias, defer_reduce = 1, bf16_mma = 1). */
@@ -456,6 +478,7 @@ typedef struct vlp3d_linear_wgrad_job {
   float *partials;
   long long R;
   int K, N, max_blocks, with_bias;
+  int x_bf16;  /* X holds bf16 rows (R x K): an attention core's bf16 output as the layer's input (vlp3d_sdpa_fwd_io) */
 } vlp3d_linear_wgrad_job;
 /* The weight gradients of `count` plain linear layers (nn.Linear backward, attention.py / mmattention.py / match_module.py
  * projections and FFNs) in one or a few launches instead of one each: they feed nothing but the optimiser, so the step driver
@@ -655,9 +678,14 @@ typedef struct vlp3d_chain_stage {
   int ln_call;
   float eps;
   float *ln_out, *xhat, *rstd;
+  int v_out_bf16;  /* plain stage (no act, no LayerNorm): v_out receives bf16 rows (R x N) instead of fp32 */
 } vlp3d_chain_stage;
 int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
                      const unsigned long long *seed, void *stream);
+/* The same launch with X given as bf16 rows (x_bf16 != 0: R x K0 bf16, e.g. vlp3d_sdpa_fwd_io's output with io bit 4): the
+ * tile goes to LDS without a conversion — the values the fp32 form would have rounded to. */
+int vlp3d_rows_chain_io(const void *X, int x_bf16, long long R, const vlp3d_chain_stage *stages, int nstages,
+                        const unsigned long long *seed, void *stream);
 
 /* Backward of such a chain's row-local part, again one launch over 32-row tiles (csrc/rows_chain.hip).  The gradient walks
  * `ngemm` input-gradient products with `ngemm + 1` POINTS between them; point 0 sees the incoming gradient G (R x gemms[0].K),

@@ -98,7 +98,8 @@ def test_descriptor_structs_have_the_header_layout(tmp_path):
     import subprocess
     _lib = importlib.import_module("3dvlp_amd._lib")
     pairs = {"vlp3d_copy_desc": _lib.CopyDesc, "vlp3d_transpose_desc": _lib.TransposeDesc, "vlp3d_chain_stage": _lib.ChainStage,
-             "vlp3d_chain_bwd_point": _lib.ChainBwdPoint, "vlp3d_chain_bwd_gemm": _lib.ChainBwdGemm}
+             "vlp3d_chain_bwd_point": _lib.ChainBwdPoint, "vlp3d_chain_bwd_gemm": _lib.ChainBwdGemm,
+             "vlp3d_linear_wgrad_job": _lib.LinearWgradJob, "vlp3d_rows_wgrad_job": _lib.RowsWgradJob}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vlp3d.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

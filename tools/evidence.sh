@@ -24,5 +24,5 @@ cp /tmp/prof_g/g_kernel_stats.csv $out/${tag}_bench_default_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_h -o h -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernels > /dev/null 2>&1
 cp /tmp/prof_h/h_kernel_stats.csv $out/${tag}_bench_steps_only_kernel_stats.csv
 mkdir -p /tmp/pg/x && cp /tmp/prof_h/h_kernel_trace.csv /tmp/pg/x/
-python3 $GRAFT_REPO_ROOT/tools/trace_last_step.py /tmp/pg 400 > $out/${tag}_steady_state_step.txt
+python3 $GRAFT_REPO_ROOT/tools/trace_last_step.py /tmp/pg 400 $out/${tag}_step_launches.txt > $out/${tag}_steady_state_step.txt
 head -3 $out/${tag}_steady_state_step.txt

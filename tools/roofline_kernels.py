@@ -72,12 +72,21 @@ for _ in range(3):
 q = torch.randn(64, 256, 128, device=dev)
 kc = torch.randn(64, 49, 128, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
-for bf in (True, False):
-    for _ in range(3):
-        if mode == "cross":
-            fa.sdpa(q, kc, kc, 4, bf16_mma=bf)
-        else:
-            fa.sdpa(q, q, q, 4, bf16_mma=bf)
+# what the step's match decoder launches since round 4: the cores on bf16 rows (vlp3d_sdpa_fwd_io): q|k|v merged bf16 (self,
+# sdpa_fwd_lds_kernel<7>), q bf16 + k|v fp32 from the tokens' projection (cross, sdpa_fwd_lds_kernel<5>); out bf16
+qkv16 = torch.randn(64, 256, 384, device=dev).bfloat16()
+q16 = qkv16[..., :128].contiguous()
+kvc = torch.randn(64, 49, 256, device=dev)
+for _ in range(3):
+    if mode == "cross":
+        ext.sdpa_fwd_rows(q16, kvc[..., :128], kvc[..., 128:], 4, None, True)
+    else:
+        ext.sdpa_fwd_rows(qkv16[..., :128], qkv16[..., 128:256], qkv16[..., 256:], 4, None, True)
+for _ in range(3):  # the fp32-row form (relation module; exact-fp32 configuration) for comparison
+    if mode == "cross":
+        fa.sdpa(q, kc, kc, 4, bf16_mma=False)
+    else:
+        fa.sdpa(q, q, q, 4, bf16_mma=False)
 # the decoder layer's row chain (fc_o -> add & norm -> FFN -> add & norm -> the next layer's q|k|v) and its backward, R = 16 384
 if mode == "self":
     rc = importlib.import_module("3dvlp_amd.row_chain")
