@@ -76,7 +76,6 @@ struct RowGemmArgs {
   // BNRELU / BNBWD / PLAIN: source matrices (R x ldin)
   const void *Yin, *Gin;
   int ldin;
-  int in_bf16;                           // PLAIN operand of the batched linear weight gradients: Yin holds bf16 rows
   const float *scale, *shift;            // BNRELU: a = relu(y*scale + shift)
   const float *rstd, *nmean_rstd;        // BNBWD: yhat = y*rstd + nmean_rstd
   const float *k1, *k2, *k3;             // BNBWD: dy = k1*(g - k2 - yhat*k3)
@@ -1393,7 +1392,9 @@ struct WgradArgs {
 // POOL (bf16 storage only): dY of the last layer is synthesised from the pooled tensors (w.dy.pool_g / pool_sel)
 // RAWF (fp32 storage, no pooled gradient, no row map: the rows stacks and plain linear layers): like the bf16 loaders, the
 // next tile's operands are only REQUESTED before the products and transformed when they are written to LDS.
-template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false, bool RAWF = false>  // MAXT = output tiles per wave
+// XB16 (RAWF, PLAIN operand): the A rows are bf16 in memory (an attention core's output, vlp3d_sdpa_fwd_io) — its own
+// instantiation: a run-time test in the staging loop made hipcc branch around every load (117 -> 239 us for the batch).
+template <typename T, int COUT, int LOADER, int MAXT, int DYL = BNBWD, bool BFM = false, bool POOL = false, bool RAWF = false, bool XB16 = false>  // MAXT = output tiles per wave
 __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, const int by, const int gx, const int gy) {
   extern __shared__ float lds[];
   constexpr int NCT = COUT / 32;
@@ -1584,7 +1585,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &w, const int bx, con
         if (RAWF) va[j] = y;
         else va[j] = make_float4(fmaxf(0.f, y.x * a_sc.x + a_sh.x), fmaxf(0.f, y.y * a_sc.y + a_sh.y),
                                  fmaxf(0.f, y.z * a_sc.z + a_sh.z), fmaxf(0.f, y.w * a_sc.w + a_sh.w));
-      } else if (RAWF && LOADER == PLAIN && w.src.in_bf16) {  // (job-uniform) bf16 rows: widened here, re-rounded (exactly) at the LDS store
+      } else if (XB16) {  // bf16 rows: widened here, re-rounded (exactly) at the LDS store
         const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const short *>(w.src.Yin) + (long long)rr * w.src.ldin + k0);
         va[j] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
                             __uint_as_float(raw.y & 0xffff0000u));
@@ -1825,14 +1826,13 @@ constexpr int ROWS_WGRAD_BATCH = 40;  // 40 x 88 bytes of kernel arguments
 struct RowsWgradBatch {
   RowsWgradJob j[ROWS_WGRAD_BATCH];
 };
-template <int LOADER, int DYL, int MAXT>
+template <int LOADER, int DYL, int MAXT, bool XB16 = false>
 __global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsWgradBatch t) {
   const RowsWgradJob &jb = t.j[blockIdx.z];
   const int ncb = jb.N / 64;
   if ((int)blockIdx.x >= jb.nblk || (int)blockIdx.y >= ncb) return;
   WgradArgs w = {};
-  w.colsum = jb.colsum & 1;
-  w.src.in_bf16 = jb.colsum >> 1;  // (bit 1 of the job's colsum word: X holds bf16 rows)
+  w.colsum = jb.colsum;
   w.src.K = jb.K; w.src.R = jb.R; w.src.Yin = jb.X; w.src.ldin = jb.lda; w.src.scale = jb.a_scale; w.src.shift = jb.a_shift;
   w.dy.ldin = jb.ldg;
   if (DYL == BNBWD) {
@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsWgradBatch t)
   w.KP = (jb.K + 31) & ~31;
   w.partials = jb.partials;
   w.tiles_per_block = jb.tpb;
-  wgrad_body<float, 64, LOADER, MAXT, DYL, true, false, true>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
+  wgrad_body<float, 64, LOADER, MAXT, DYL, true, false, true, XB16>(w, blockIdx.x, blockIdx.y, jb.nblk, ncb);
 }
 
 // dW[i] = sum_b partials[b][i]: a block sums 64 consecutive elements — 16 threads x float4 — in 16 slab-groups
@@ -1973,11 +1973,10 @@ __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int
     for (int k0 = grp; k0 < nslab; k0 += 64 * 16) {
       double va[16], vb[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int k = k0 + 64 * u;
-        const bool in = k < nslab;
-        va[u] = in ? slabs[(size_t)k * 2 * C + c] : 0.0;
-        vb[u] = in ? slabs[(size_t)k * 2 * C + C + c] : 0.0;
+      for (int u = 0; u < 16; ++u) {  // unconditional loads at clamped addresses (a test per load makes hipcc branch around it)
+        const int k = min(k0 + 64 * u, nslab - 1);
+        va[u] = slabs[(size_t)k * 2 * C + c];
+        vb[u] = slabs[(size_t)k * 2 * C + C + c];
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
@@ -2689,13 +2688,13 @@ extern "C" int vlp3d_linear_wgrad(const float *dY, const float *X, long long R, 
 }
 
 namespace {
-template <int LOADER, int DYL>
+template <int LOADER, int DYL, bool XB16 = false>
 int launch_rows_batch(int maxt, const RowsWgradBatch &t, dim3 grid, size_t lds, hipStream_t s) {
   switch (maxt) {
-    case 1: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 1>), grid, dim3(256), lds, s, t); break;
-    case 3: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 3>), grid, dim3(256), lds, s, t); break;
-    case 4: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 4>), grid, dim3(256), lds, s, t); break;
-    case 6: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 6>), grid, dim3(256), lds, s, t); break;
+    case 1: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 1, XB16>), grid, dim3(256), lds, s, t); break;
+    case 3: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 3, XB16>), grid, dim3(256), lds, s, t); break;
+    case 4: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 4, XB16>), grid, dim3(256), lds, s, t); break;
+    case 6: hipLaunchKernelGGL((rows_wgrad_batch_kernel<LOADER, DYL, 6, XB16>), grid, dim3(256), lds, s, t); break;
     default: return VLP3D_EINVAL;
   }
   VLP3D_LAUNCH_CHECK();
@@ -2728,7 +2727,7 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
     // per step instead of 4, 4.42 -> 4.39 ms; all four loader combinations behind ONE launch — a workgroup-uniform branch
     // over four inlined bodies — was measured too: 4.42 -> 4.43 ms, not kept)
     const int maxt = per_wave <= 1 ? 1 : (per_wave <= 4 ? 4 : 6);
-    key[i] = ((q.a_scale ? 1 : 0) << 8) | ((q.bn5 ? 1 : 0) << 4) | maxt;
+    key[i] = ((q.x_bf16 ? 1 : 0) << 12) | ((q.a_scale ? 1 : 0) << 8) | ((q.bn5 ? 1 : 0) << 4) | maxt;
     done[i] = false;
   }
   for (int i = 0; i < count; ++i) {
@@ -2747,7 +2746,7 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
       j.R = (int)q.R; j.K = q.K; j.N = q.N; j.ldg = q.ldg; j.lda = q.lda;
       j.nblk = (int)((ntiles + tpb - 1) / tpb);
       j.tpb = (int)tpb;
-      j.colsum = (q.with_bias != 0 ? 1 : 0) | (q.x_bf16 ? 2 : 0);
+      j.colsum = q.with_bias != 0;
       const int KP = (q.K + 31) & ~31;
       if (j.nblk > gx) gx = j.nblk;
       if (q.N / 64 > gy) gy = q.N / 64;
@@ -2755,11 +2754,12 @@ extern "C" int vlp3d_rows_wgrad_batch(const vlp3d_rows_wgrad_job *jobs, int coun
       done[k] = true;
       ++n;
     }
-    const int relu = key[i] >> 8, bn = (key[i] >> 4) & 1, maxt = key[i] & 15;
+    const int xb = key[i] >> 12, relu = (key[i] >> 8) & 1, bn = (key[i] >> 4) & 1, maxt = key[i] & 15;
     const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n);
     const size_t lds = (size_t)32 * (64 + kp + 8) * 2;
     int st;
-    if (bn) st = relu ? launch_rows_batch<BNRELU, BNBWD>(maxt, t, grid, lds, s) : launch_rows_batch<PLAIN, BNBWD>(maxt, t, grid, lds, s);
+    if (xb) st = launch_rows_batch<PLAIN, PLAIN, true>(maxt, t, grid, lds, s);  // (host-checked: plain linear jobs only)
+    else if (bn) st = relu ? launch_rows_batch<BNRELU, BNBWD>(maxt, t, grid, lds, s) : launch_rows_batch<PLAIN, BNBWD>(maxt, t, grid, lds, s);
     else st = relu ? launch_rows_batch<BNRELU, PLAIN>(maxt, t, grid, lds, s) : launch_rows_batch<PLAIN, PLAIN>(maxt, t, grid, lds, s);
     if (st != VLP3D_OK) return st;
   }

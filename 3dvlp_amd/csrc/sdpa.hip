@@ -262,6 +262,25 @@ __global__ __launch_bounds__(64) void sdpa_fwd_kernel(const float *__restrict__ 
   }
 }
 
+// Workgroup -> (block along x, head, batch element) for the LDS kernels.  The workgroups of one batch element share memory
+// lines: the query blocks of a head stage the same K / V, and the heads of a row own 64-byte (bf16 rows) or 128-byte pieces of
+// the same lines.  Workgroups go round-robin over the 8 XCDs by linear id, so with the launch's own (x, y, z) the sharers sit on
+// different XCDs and every one of them pulls its lines through its own L2 (PMC: 21 MB fetched for 12.6 MB of bf16 q|k|v).
+// Here the gridDim.x * gridDim.y workgroups of a batch element are given ids that are 8 apart: one XCD, dispatched together.
+__device__ __forceinline__ void xcd_block(int &x, int &h, int &b) {
+  const int nx = gridDim.x, H = gridDim.y, B = gridDim.z;
+  if ((B & 7) == 0) {
+    const int n = blockIdx.x + nx * (blockIdx.y + H * blockIdx.z);  // linear id = dispatch order
+    const int per = nx * H, xcd = n & 7, s = n >> 3;
+    const int local = s % per;
+    b = (s / per) * 8 + xcd;
+    x = local % nx;
+    h = local / nx;
+  } else {
+    x = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward, bf16-MFMA form with the head's K and V shared through LDS: a workgroup = 4 waves = 128 queries of one
 // (b,h).  In the one-wave form every 32-query wave re-reads its head's K and V from L2 (PMC traffic 2.4x the
@@ -283,10 +302,11 @@ __global__ __launch_bounds__(256) void sdpa_fwd_lds_kernel(const void *__restric
   short *sV = sm_kv + nkp * KS;    // [D][VS]
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;
+  xcd_block(bx, h, b);
   const int HD = H * D;
   // the wave's query rows are requested first: their latency runs under the staging of K and V
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (bx * 4 + wave) * 32;
   const int qi = min(q0 + r, nq - 1);
   const long long qrow = (long long)b * nq + qi;
   bf16x8 qa[2];
@@ -499,7 +519,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
   constexpr bool Q16 = (IO & 1) != 0, KV16 = (IO & 2) != 0, O16 = (IO & 4) != 0;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;
+  xcd_block(bx, h, b);
   const int HD = H * D;
   for (int c = threadIdx.x; c < nkp * (D / 4); c += 256) {
     const int key = c / (D / 4), d4 = (c - key * (D / 4)) * 4;
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_lds_kernel(
     sKt[(d4 + 3) * TS + key] = kb.w;
   }
   __syncthreads();
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (bx * 4 + wave) * 32;
   if (q0 >= nq) return;
   const int qi = min(q0 + r, nq - 1);
   const long long qrow = (long long)b * nq + qi;
@@ -705,7 +726,8 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
   float *sDl = sL + nqp;
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;
+  xcd_block(bx, h, b);
   const int HD = H * D, nthr = blockDim.x;
   for (int c = threadIdx.x; c < nqp * (D / 4); c += nthr) {
     const int qi = c / (D / 4), d4 = (c - qi * (D / 4)) * 4;
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv_lds_kernel(
   // (8 key tiles x 8 dependent query iterations) kept 64 workgroups of 4 waves busy, a quarter of the chip at one wave per
   // SIMD.  No wave leaves before the last barrier.
   const int kt = wave % wpb, qs = wave / wpb;
-  const int k0 = (blockIdx.x * wpb + kt) * 32;
+  const int k0 = (bx * wpb + kt) * 32;
   const bool tile_ok = k0 < nk;
   const int ki = min(k0 + r, nk - 1);
   const long long krow = (long long)b * nk + ki;

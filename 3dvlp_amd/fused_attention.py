@@ -127,10 +127,13 @@ class _SDPARows(Function):
         ctx.save_for_backward(a_rows, b_, mask, out_rows, lse)
         ctx.H = H
         ctx.mark_non_differentiable(out_rows)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the rows output's absent gradient)
         return torch.empty(out_rows.shape, dtype=torch.float32, device=out_rows.device), out_rows
 
     @staticmethod
     def backward(ctx, dout, _drows):
+        if dout is None:
+            return None, None, None, None, None
         a_rows, b_, mask, out_rows, lse = ctx.saved_tensors
         HD = ctx.H * 32
         if b_ is None:

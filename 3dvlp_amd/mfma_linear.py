@@ -140,10 +140,13 @@ class _LinearRows16(Function):
         ctx.xshape = x.shape
         rows = rows.view(*x.shape[:-1], N)
         ctx.mark_non_differentiable(rows)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the rows output's absent gradient)
         return torch.empty(rows.shape, dtype=torch.float32, device=x.device), x.view_as(x), rows
 
     @staticmethod
     def backward(ctx, dy, dres, _drows):
+        if dy is None:
+            return dres, None, None
         x2, w = ctx.saved_tensors
         R, K = x2.shape
         N = w.shape[0]
