@@ -802,7 +802,8 @@ class ChainStage(ctypes.Structure):
                 ("v_out", ctypes.c_void_p), ("act_kind", ctypes.c_int), ("act_p", ctypes.c_float), ("act_call", ctypes.c_int),
                 ("h_out", ctypes.c_void_p), ("has_ln", ctypes.c_int), ("res", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
                 ("beta", ctypes.c_void_p), ("ln_p", ctypes.c_float), ("ln_call", ctypes.c_int), ("eps", ctypes.c_float),
-                ("ln_out", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("v_out_bf16", ctypes.c_int)]
+                ("ln_out", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("v_out_bf16", ctypes.c_int),
+                ("h_out_bf16", ctypes.c_int)]
 
 
 def _prod(shape):
@@ -828,7 +829,8 @@ def rows_chain(X, stages, seed):
         for name in ptrs:
             t = st.get(name)
             if t is not None:
-                want = torch.bfloat16 if (name == "v_out" and st.get("v_out_bf16")) else torch.float32
+                want = torch.bfloat16 if ((name == "v_out" and st.get("v_out_bf16")) or
+                                          (name == "h_out" and st.get("h_out_bf16"))) else torch.float32
                 if not (t.is_cuda and t.dtype == want and t.is_contiguous() and t.device == X.device) or \
                         t.numel() != _prod(width[name](st)):
                     raise RuntimeError("rows_chain: %s must be contiguous fp32 on X's device with %s elements"
@@ -839,6 +841,7 @@ def rows_chain(X, stages, seed):
         c.has_ln, c.ln_p, c.ln_call = int(st.get("has_ln", 0)), float(st.get("ln_p", 0.0)), int(st.get("ln_call", 0))
         c.eps = float(st.get("eps", 1e-5))
         c.v_out_bf16 = int(bool(st.get("v_out_bf16", 0)))
+        c.h_out_bf16 = int(bool(st.get("h_out_bf16", 0)))
     if stages[0]["K"] != X.shape[1]:
         raise RuntimeError("rows_chain: X has %d columns, stage 0 reads %d" % (X.shape[1], stages[0]["K"]))
     with torch.cuda.device(X.device):
@@ -852,7 +855,7 @@ class ChainBwdPoint(ctypes.Structure):
     _fields_ = [("base", ctypes.c_void_p), ("add_kept", ctypes.c_int), ("op", ctypes.c_int), ("aux", ctypes.c_void_p),
                 ("rstd", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("p", ctypes.c_float), ("call", ctypes.c_int),
                 ("act_kind", ctypes.c_int), ("g_out", ctypes.c_void_p), ("dres_out", ctypes.c_void_p), ("keep", ctypes.c_int),
-                ("part", ctypes.c_void_p)]
+                ("part", ctypes.c_void_p), ("aux_bf16", ctypes.c_int)]
 
 
 class ChainBwdGemm(ctypes.Structure):
@@ -880,10 +883,12 @@ def rows_chain_bwd(G, points, gemms, seed):
         sizes = {"base": R * N, "aux": R * N, "rstd": R, "gamma": N, "g_out": R * N, "dres_out": R * N, "part": nblk * 2 * N}
         for name, n in sizes.items():
             t = P.get(name)
-            if t is not None and (not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == G.device)
+            want = torch.bfloat16 if (name == "aux" and P.get("aux_bf16")) else torch.float32
+            if t is not None and (not (t.is_cuda and t.dtype == want and t.is_contiguous() and t.device == G.device)
                                   or t.numel() != n):
-                raise RuntimeError("rows_chain_bwd: %s must be contiguous fp32 on G's device with %d elements" % (name, n))
+                raise RuntimeError("rows_chain_bwd: %s must be contiguous %s on G's device with %d elements" % (name, want, n))
             setattr(c, name, None if t is None else t.data_ptr())
+        c.aux_bf16 = int(bool(P.get("aux_bf16", 0)))
         c.add_kept, c.op, c.keep = int(P.get("add_kept", 0)), int(P.get("op", 0)), int(P.get("keep", 0))
         c.p, c.call, c.act_kind = float(P.get("p", 0.0)), int(P.get("call", 0)), int(P.get("act_kind", 0))
     for c, g in zip(ga, gemms):

@@ -272,8 +272,15 @@ __global__ __launch_bounds__(256) void rows_chain_kernel(const ChainArgs a) {
             out[j] = v;
           }
           if (S.h_out && grow < R) {
-            *reinterpret_cast<float4 *>(S.h_out + o) = make_float4(out[0], out[1], out[2], out[3]);
-            *reinterpret_cast<float4 *>(S.h_out + o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+            if (S.h_out_bf16) {  // what the next stage multiplies and the layer's weight gradient reads: the bf16 values themselves
+              bf16x8 hb;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) hb[j] = bf16_bits(out[j]);
+              *reinterpret_cast<bf16x8 *>(reinterpret_cast<short *>(S.h_out) + o) = hb;
+            } else {
+              *reinterpret_cast<float4 *>(S.h_out + o) = make_float4(out[0], out[1], out[2], out[3]);
+              *reinterpret_cast<float4 *>(S.h_out + o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+            }
           }
         }
         if (feed) {
@@ -353,7 +360,12 @@ __device__ __forceinline__ void bwd_point(const vlp3d_chain_bwd_point &P, const 
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[it][j] += b[j];
     }
-    if (P.op != 0) unpack8(ld4(P.aux + o), ld4(P.aux + o + 4), ax[it]);
+    if (P.op == 2 && P.aux_bf16) {  // (kernel-uniform) ReLU stage whose forward kept only h = dropout(relu(z)) as bf16 rows:
+      // h > 0 <=> z > 0 wherever the mask kept the element, and the mask zeroes the rest either way
+      const bf16x8 hb = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const short *>(P.aux) + o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ax[it][j] = __uint_as_float(((unsigned)(unsigned short)hb[j]) << 16);
+    } else if (P.op != 0) unpack8(ld4(P.aux + o), ld4(P.aux + o + 4), ax[it]);
     if (P.op == 1) rs[it] = P.rstd[gr];
   }
 #pragma unroll
@@ -527,6 +539,7 @@ extern "C" int vlp3d_rows_chain_io(const void *X, int x_bf16, long long R, const
     }
     if (R * (long long)S.N >= (1ll << 32)) return VLP3D_EINVAL;  // the dropout hash counts elements in 32 bits
     if (S.v_out_bf16 && (S.has_ln || S.act_kind >= 0 || !S.v_out)) return VLP3D_EINVAL;  // plain projections only
+    if (S.h_out_bf16 && (S.act_kind < 0 || !S.h_out)) return VLP3D_EINVAL;
     a.st[s] = S;
   }
   static const int tr = getenv("VLP3D_CHAIN_TILE_ROWS") ? atoi(getenv("VLP3D_CHAIN_TILE_ROWS")) : 32;
@@ -572,6 +585,7 @@ extern "C" int vlp3d_rows_chain_bwd(const float *G, long long R, const vlp3d_cha
     if (P.op < 0 || P.op > 2 || P.p < 0.f || P.p >= 1.f || (P.p > 0.f && !seed)) return VLP3D_EINVAL;
     if (P.op == 1 && (N != DLN || !P.aux || !P.rstd || !P.gamma)) return VLP3D_EINVAL;
     if (P.op == 2 && (!P.aux || P.act_kind < 0 || P.act_kind > 1)) return VLP3D_EINVAL;
+    if (P.aux_bf16 && (P.op != 2 || P.act_kind != 0)) return VLP3D_EINVAL;  // h in place of z: ReLU only
     if (P.op != 1 && (P.keep || P.dres_out || P.part)) return VLP3D_EINVAL;
     if (P.add_kept && (!kept || N != DLN)) return VLP3D_EINVAL;  // nothing kept yet / kept rows are 128 wide
     if (P.op == 1 && P.keep) kept = true;

@@ -65,18 +65,24 @@ def supported(x, stages, rows=None):
     return True
 
 
-_T0 = 5  # position of the first of `tensors` among _Chain.forward's inputs
+_T0 = 6  # position of the first of `tensors` among _Chain.forward's inputs
 
 
 class _Chain(Function):
     @staticmethod
-    def forward(ctx, spec, seed, X, x_rows, last_rows, *tensors):
+    def forward(ctx, spec, seed, X, x_rows, last_rows, compact_acts, *tensors):
         # spec: per stage (iW, ib, act_kind, act_p, act_call, has_ln, res, ig, ibeta, ln_p, ln_call, eps); indices into
         # `tensors`; res = ("ext", index) | ("tile", j)
         # x_rows (bf16, or None): the VALUES of the input rows — X is then an fp32 shell autograd routes the gradient through,
         # its storage never read (an attention core's bf16 output, fused_attention.sdpa_rows).  last_rows: the last stage (a
         # plain projection) stores bf16 rows, returned as an extra non-differentiable output; its fp32 tile is a shell.
+        # compact_acts: an activation stage that is not the last one and whose output is nobody's residual keeps what backward
+        # reads and nothing else — its output h as bf16 rows (the values the next stage and the weight gradient multiply; the
+        # returned tile is that bf16 tensor, non-differentiable) and, for ReLU, NO pre-activation (h > 0 <=> z > 0 wherever the
+        # dropout mask kept the element): 1.5 KB less per row and 256-wide stage, the launch is bound by its stores.
         R = X.shape[0]
+        res_tiles = {st[6][1] for st in spec if st[5] and st[6][0] == "tile"}
+        nondiff = []
         dev = X.device
         if x_rows is not None:
             X = x_rows
@@ -95,8 +101,16 @@ class _Chain(Function):
                 d.update(res=tensors[res[1]] if res[0] == "ext" else tiles[res[1]], gamma=tensors[ig], beta=tensors[ibeta],
                          ln_out=out, xhat=xh, rstd=rs)
             elif act_kind >= 0:
-                z = torch.empty((R, N), dtype=torch.float32, device=dev)
-                d.update(v_out=z, h_out=out)
+                if compact_acts and si + 1 < len(spec) and (si + 1) not in res_tiles:
+                    out = torch.empty((R, N), dtype=torch.bfloat16, device=dev)
+                    nondiff.append(out)
+                    d.update(h_out=out, h_out_bf16=1)
+                    if act_kind != 0:  # GELU: its derivative needs z itself
+                        z = torch.empty((R, N), dtype=torch.float32, device=dev)
+                        d.update(v_out=z)
+                else:
+                    z = torch.empty((R, N), dtype=torch.float32, device=dev)
+                    d.update(v_out=z, h_out=out)
             elif last_rows and si + 1 == len(spec):
                 out_rows = torch.empty((R, N), dtype=torch.bfloat16, device=dev)
                 d.update(v_out=out_rows, v_out_bf16=1)
@@ -126,7 +140,10 @@ class _Chain(Function):
         ctx.save_for_backward(*keep)
         ctx.set_materialize_grads(False)
         if out_rows is not None:
-            ctx.mark_non_differentiable(out_rows)
+            nondiff.append(out_rows)
+        if nondiff:
+            ctx.mark_non_differentiable(*nondiff)
+        if out_rows is not None:
             return tuple(tiles[1:]) + (out_rows,)
         return tuple(tiles[1:])
 
@@ -167,7 +184,9 @@ class _Chain(Function):
                     pend[res[1]] = accumulate(pend[res[1]], dres)
             elif act_kind >= 0:
                 gz = torch.empty_like(g)
-                _ext.call("vlp3d_act_dropout", zs[s], g, g.numel(), act_kind, act_p, seed, act_call, gz, None)
+                # (compact stash of a ReLU stage: h stands in for z — h > 0 <=> z > 0 where the mask kept the element)
+                zz = zs[s] if zs[s] is not None else tiles[s + 1].float()
+                _ext.call("vlp3d_act_dropout", zz, g, g.numel(), act_kind, act_p, seed, act_call, gz, None)
                 g = gz
             want_db = ib is not None and ctx.needs_input_grad[_T0 + ib]
             if ctx.needs_input_grad[_T0 + iW]:
@@ -219,6 +238,8 @@ class _Chain(Function):
                 elif act_kind >= 0:
                     g = torch.empty((R, N), dtype=torch.float32, device=dev)
                     P.update(op=2, aux=zs[s], act_kind=act_kind, p=act_p, call=act_call, g_out=g)
+                    if zs[s] is None:  # compact stash (ReLU): the stage's bf16 output in place of its pre-activation
+                        P.update(aux=tiles[s + 1], aux_bf16=1)
                 elif j == 0:
                     g = G  # the incoming gradient is what this stage's weight gradient reads
                 else:
@@ -258,13 +279,14 @@ class _Chain(Function):
         for i, t in enumerate(tensors):  # residual tensors keep the caller's shape
             if grads[i] is not None and grads[i].shape != t.shape:
                 grads[i] = grads[i].view(t.shape)
-        return (None, None, gX, None, None) + tuple(grads)
+        return (None, None, gX, None, None, None) + tuple(grads)
 
 
-def run(x, stages, training=True, x_rows=None, last_rows=False):
+def run(x, stages, training=True, x_rows=None, last_rows=False, compact_acts=False):
     """x (..., K0) -> tuple of t_1..t_n, each (R, N_s) with R = rows of x.  Check `supported(x, stages)` first.
     x_rows: the input's values as bf16 rows (x is then an fp32 shell, see _Chain.forward); last_rows: t_n's values come back
-    as bf16 rows in an extra last element of the tuple (t_n itself is then a shell)."""
+    as bf16 rows in an extra last element of the tuple (t_n itself is then a shell).  compact_acts: see _Chain.forward — only
+    for callers that do not differentiate through (or read as fp32) the outputs of the activation stages in the middle."""
     X = x.reshape(-1, x.shape[-1]).contiguous()
     R = X.shape[0]
     if x_rows is not None:
@@ -294,4 +316,4 @@ def run(x, stages, training=True, x_rows=None, last_rows=False):
             spec.append((iW, ib, _ACTS[st["act"]], p, add_norm.next_call(), False, None, None, None, 0.0, 0, 0.0))
         else:
             spec.append((iW, ib, -1, 0.0, 0, False, None, None, None, 0.0, 0, 0.0))
-    return _Chain.apply(tuple(spec), add_norm.state(X.device), X, x_rows, bool(last_rows), *tensors)
+    return _Chain.apply(tuple(spec), add_norm.state(X.device), X, x_rows, bool(last_rows), bool(compact_acts), *tensors)

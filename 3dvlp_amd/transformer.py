@@ -22,6 +22,8 @@ DEFAULT_IMPL = "hip"
 # / the query projection store what the cores read as bf16 and the cores store what the chains read as bf16 — the values the
 # bf16-MFMA kernels round their operands to anyway.  "0": fp32 rows between the launches (round 3's form).
 ATTN_BF16_ROWS = os.environ.get("VLP3D_ATTN_BF16_ROWS", "1") != "0"
+# The decoder chains keep of their FFN stage only its bf16 output rows (row_chain._Chain compact_acts): no pre-activation, no fp32 h
+CHAIN_COMPACT_ACTS = os.environ.get("VLP3D_CHAIN_COMPACT", "1") != "0"
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -276,10 +278,10 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
         st[0]["res"] = x
         if rows:
             a, a_rows = fused_attention.sdpa_rows(q.view(B * rep, K, C), q_rows.view(B * rep, K, C), kv, h)
-            t = row_chain.run(a.reshape(R, C), st, layer.training, x_rows=a_rows, last_rows=more)
+            t = row_chain.run(a.reshape(R, C), st, layer.training, x_rows=a_rows, last_rows=more, compact_acts=CHAIN_COMPACT_ACTS)
         else:
             a = fused_attention.sdpa_merged(q.view(B * rep, K, C), kv, h, None, "add", None, bf16_mma=bf)
-            t = row_chain.run(a.reshape(R, C), st, layer.training)
+            t = row_chain.run(a.reshape(R, C), st, layer.training, compact_acts=CHAIN_COMPACT_ACTS)
         x = t[2]
         if more:
             nl = layers[i + 1]

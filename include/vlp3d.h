@@ -679,6 +679,7 @@ typedef struct vlp3d_chain_stage {
   float eps;
   float *ln_out, *xhat, *rstd;
   int v_out_bf16;  /* plain stage (no act, no LayerNorm): v_out receives bf16 rows (R x N) instead of fp32 */
+  int h_out_bf16;  /* activation stage: h_out receives bf16 rows — the values the next stage and the weight gradient multiply */
 } vlp3d_chain_stage;
 int vlp3d_rows_chain(const float *X, long long R, const vlp3d_chain_stage *stages, int nstages,
                      const unsigned long long *seed, void *stream);
@@ -711,6 +712,8 @@ typedef struct vlp3d_chain_bwd_point {
   float *g_out, *dres_out;
   int keep;
   float *part;
+  int aux_bf16;  /* op 2, ReLU only: aux = the stage's OUTPUT h = dropout(relu(z)) as bf16 rows (vlp3d_chain_stage.h_out_bf16)
+                  * instead of z: the forward pass then need not store the pre-activation at all (v_out NULL) */
 } vlp3d_chain_bwd_point;
 typedef struct vlp3d_chain_bwd_gemm {
   const float *Wt;

@@ -85,11 +85,14 @@ def test_query_projection_stored_as_bf16_rows():
     assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("deferred", [False, True])
-def test_chain_on_bf16_input_rows_and_bf16_last_stage(deferred):
+def test_chain_on_bf16_input_rows_and_bf16_last_stage(deferred, compact):
     """row_chain.run(shell, x_rows=bf16 rows, last_rows=True) == row_chain.run(the same values as fp32): every stored tile, the
     last stage's rows (= its fp32 tile rounded), the input gradient and every parameter gradient bit for bit — also with the
-    stage-0 weight gradient taken by the batched kernel from the bf16 rows (deferred queue)."""
+    stage-0 weight gradient taken by the batched kernel from the bf16 rows (deferred queue).  compact: the FFN stage keeps only
+    its bf16 output (no pre-activation, compact_acts) — the same bits again: h > 0 <=> z > 0 where the dropout mask kept the
+    element, and the products read h rounded to bf16 either way."""
     ext, _, rc, ml, an = _mods()
     torch.manual_seed(11)
     R, p = 64 * 21, 0.1
@@ -111,7 +114,8 @@ def test_chain_on_bf16_input_rows_and_bf16_last_stage(deferred):
             assert rc.supported(a, st)
             if rows:
                 shell = torch.full_like(a0, float("nan")).requires_grad_()   # never read: NaNs would surface anywhere
-                t = rc.run(shell, st, True, x_rows=a0.bfloat16(), last_rows=True)
+                t = rc.run(shell, st, True, x_rows=a0.bfloat16(), last_rows=True, compact_acts=compact)
+                assert t[1].dtype == (torch.bfloat16 if compact else torch.float32)
                 a = shell
             else:
                 t = rc.run(a, st, True)
@@ -127,7 +131,7 @@ def test_chain_on_bf16_input_rows_and_bf16_last_stage(deferred):
     (tf, gf), (tr, gr) = once(False), once(True)
     assert len(tr) == len(tf) + 1 and tr[-1].dtype == torch.bfloat16
     for u, c in zip(tf[:3], tr[:3]):
-        assert torch.equal(u, c)
+        assert torch.equal(u, c) if c.dtype == u.dtype else torch.equal(u.bfloat16(), c)
     assert torch.equal(tr[-1], tf[3].bfloat16())
     for u, c in zip(gf, gr):
         assert torch.equal(u, c)
