@@ -14,6 +14,7 @@
 // -ffp-contract=off like the rest of the library; the dot products use explicit fused multiply-adds (as a BLAS GEMM
 // does) — half the VALU instructions of separate multiplies and adds.
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -192,8 +193,8 @@ __device__ __forceinline__ float column_sum32(const float *__restrict__ A, int r
 // updates run as v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 in registers (16 exact + 8 bf16 matrix instructions per
 // 32-pair tile instead of 80 exact ones: the fp32 MFMAs were a third of the kernel); the recomputed forward (layer 1, the
 // layer-2 product, both LayerNorms) and all sums stay fp32.
-template <bool BF>
-__global__ __launch_bounds__(256, 2) void relation_bias_bwd_kernel(const float *__restrict__ centre,
+template <bool BF, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void relation_bias_bwd_kernel(const float *__restrict__ centre,
                                                                  const float *__restrict__ Pg,
                                                                  const float *__restrict__ dout, int B, int K,
                                                                  float *__restrict__ slabs) {
@@ -475,7 +476,11 @@ extern "C" int vlp3d_relation_bias_bwd(const float *centre, const float *params,
   long long blocks = (ntiles + 3) / 4;
   if (blocks > nblocks) blocks = nblocks;
   const size_t lds = (size_t)(NPARAM + 4 + 2 * HID * HID + 4 * 2 * 32 * LDT) * sizeof(float) + HID * HID * sizeof(short);
-  if (bf16_mma)
+  static const int minb = getenv("VLP3D_RELBIAS_MINB") ? atoi(getenv("VLP3D_RELBIAS_MINB")) : 2;
+  if (bf16_mma && minb == 1)
+    hipLaunchKernelGGL((relation_bias_bwd_kernel<true, 1>), dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
+                       slabs);
+  else if (bf16_mma)
     hipLaunchKernelGGL(relation_bias_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, centre, params, dout, B, K,
                        slabs);
   else

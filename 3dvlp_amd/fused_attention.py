@@ -116,12 +116,13 @@ class _SDPARows(Function):
     `out_rows` out (non-differentiable)."""
 
     @staticmethod
-    def forward(ctx, a_shell, a_rows, b_, H, mask):
+    def forward(ctx, a_shell, a_rows, b_, H, mask, b_rows=None):
         HD = H * 32
         if b_ is None:
             q, k, v = a_rows[..., :HD], a_rows[..., HD:2 * HD], a_rows[..., 2 * HD:]
         else:
-            b_ = b_.contiguous()
+            # b_rows: [k | v] as bf16 rows too (b_ is then their shell): every operand of the core at SURVEY 8(d)'s size
+            b_ = b_.contiguous() if b_rows is None else b_rows.contiguous()
             q, k, v = a_rows, b_[..., :HD], b_[..., HD:]
         out_rows, lse = _ext.sdpa_fwd_rows(q, k, v, H, mask, True)
         ctx.save_for_backward(a_rows, b_, mask, out_rows, lse)
@@ -133,7 +134,7 @@ class _SDPARows(Function):
     @staticmethod
     def backward(ctx, dout, _drows):
         if dout is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         a_rows, b_, mask, out_rows, lse = ctx.saved_tensors
         HD = ctx.H * 32
         if b_ is None:
@@ -142,11 +143,11 @@ class _SDPARows(Function):
             q, k, v = a_rows, b_[..., :HD], b_[..., HD:]
         dq, dk, dv = _ext.sdpa_bwd_rows(q, k, v, ctx.H, mask, out_rows, lse, dout.contiguous())
         if b_ is None:
-            return dq._base, None, None, None, None
-        return dq, None, dk._base, None, None
+            return dq._base, None, None, None, None, None
+        return dq, None, dk._base, None, None, None
 
 
-def sdpa_rows(a_shell, a_rows, b_, h, attention_mask=None):
+def sdpa_rows(a_shell, a_rows, b_, h, attention_mask=None, b_rows=None):
     """-> (out shell fp32, out rows bf16); see _SDPARows.  Check rows_supported() first."""
     nk = a_rows.shape[1] if b_ is None else b_.shape[1]
     mask = _key_mask(attention_mask, a_rows.shape[0], nk)
@@ -154,7 +155,7 @@ def sdpa_rows(a_shell, a_rows, b_, h, attention_mask=None):
         raise RuntimeError("fused sdpa: unsupported attention_mask shape")
     if mask is not None:
         mask = mask.to(torch.float32).contiguous()
-    return _SDPARows.apply(a_shell, a_rows, b_, h, mask)
+    return _SDPARows.apply(a_shell, a_rows, b_, h, mask, b_rows)
 
 
 def sdpa_merged(a, b_, h, attention_weights=None, way="add", attention_mask=None, bf16_mma=None):

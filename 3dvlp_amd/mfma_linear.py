@@ -129,7 +129,7 @@ class _LinearRows16(Function):
     fp32 tensor autograd routes the gradient through, storage untouched —, x_res, y rows bf16 (non-differentiable))."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, with_residual=True):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         R, K = x2.shape
         N = weight.shape[0]
@@ -138,13 +138,20 @@ class _LinearRows16(Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
+        ctx.with_residual = bool(with_residual)
         rows = rows.view(*x.shape[:-1], N)
         ctx.mark_non_differentiable(rows)
         ctx.set_materialize_grads(False)  # (no zero tensor for the rows output's absent gradient)
-        return torch.empty(rows.shape, dtype=torch.float32, device=x.device), x.view_as(x), rows
+        shell = torch.empty(rows.shape, dtype=torch.float32, device=x.device)
+        return (shell, x.view_as(x), rows) if with_residual else (shell, rows)
 
     @staticmethod
-    def backward(ctx, dy, dres, _drows):
+    def backward(ctx, dy, *rest):
+        dres = rest[0] if ctx.with_residual else None
+        return _LinearRows16._backward(ctx, dy, dres) + (None,)
+
+    @staticmethod
+    def _backward(ctx, dy, dres):
         if dy is None:
             return dres, None, None
         x2, w = ctx.saved_tensors
@@ -173,9 +180,10 @@ def rows16_supported(x, weight):
     return supported(x, weight) and K % 32 == 0 and N % 64 == 0 and R % 32 == 0 and not torch.is_autocast_enabled("cuda")
 
 
-def linear_rows16(x, weight, bias=None):
-    """-> (y shell, x_res, y rows bf16); see _LinearRows16.  Check rows16_supported() first."""
-    return _LinearRows16.apply(x, weight, bias)
+def linear_rows16(x, weight, bias=None, with_residual=True):
+    """-> (y shell, x_res, y rows bf16), or (y shell, y rows bf16) without the residual route; see _LinearRows16.  Check
+    rows16_supported() first."""
+    return _LinearRows16.apply(x, weight, bias, with_residual)
 
 
 class bf16_mma:

@@ -273,11 +273,16 @@ def decoder_stack_chained(layers, query, rep, key, tail=()):
     for i, layer in enumerate(layers):
         ca = layer.enc_dec_attention.attention
         more = i + 1 < len(layers)
-        kv = _linear(key, merge_adjacent([ca.fc_k.weight, ca.fc_v.weight]), merge_adjacent([ca.fc_k.bias, ca.fc_v.bias]))
+        wkv, bkv = merge_adjacent([ca.fc_k.weight, ca.fc_v.weight]), merge_adjacent([ca.fc_k.bias, ca.fc_v.bias])
+        kv_rows = None
+        if rows and mfma_linear.rows16_supported(key, wkv):  # the tokens' k | v as bf16 rows too (row count a multiple of 32)
+            kv, kv_rows = mfma_linear.linear_rows16(key, wkv, bkv, with_residual=False)
+        else:
+            kv = _linear(key, wkv, bkv)
         st = plan[i]
         st[0]["res"] = x
         if rows:
-            a, a_rows = fused_attention.sdpa_rows(q.view(B * rep, K, C), q_rows.view(B * rep, K, C), kv, h)
+            a, a_rows = fused_attention.sdpa_rows(q.view(B * rep, K, C), q_rows.view(B * rep, K, C), kv, h, b_rows=kv_rows)
             t = row_chain.run(a.reshape(R, C), st, layer.training, x_rows=a_rows, last_rows=more, compact_acts=CHAIN_COMPACT_ACTS)
         else:
             a = fused_attention.sdpa_merged(q.view(B * rep, K, C), kv, h, None, "add", None, bf16_mma=bf)

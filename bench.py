@@ -251,7 +251,7 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     kc = torch.randn(BL, NUM_TOKENS, 128, device=xyz.device)
     if bf:  # what the step's match decoder launches: the cores on bf16 rows (merged q|k|v; q with the tokens' fp32 k|v)
         qkv16 = torch.randn(BL, 256, 384, device=xyz.device).bfloat16()
-        q16, kvc = qkv16[..., :128].contiguous(), torch.randn(BL, NUM_TOKENS, 256, device=xyz.device)
+        q16, kvc = qkv16[..., :128].contiguous(), torch.randn(BL, NUM_TOKENS, 256, device=xyz.device).bfloat16()
         att_ms = time_kernel(lambda: ext.sdpa_fwd_rows(qkv16[..., :128], qkv16[..., 128:256], qkv16[..., 256:], 4, None, True), reps)
         xat_ms = time_kernel(lambda: ext.sdpa_fwd_rows(q16, kvc[..., :128], kvc[..., 128:], 4, None, True), reps)
     else:
@@ -269,10 +269,10 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     g_bytes_dense = B * n * C * fsz + B * m * 64 * 4 + R * cout * esz + B * n * 12
     g_flops = 2.0 * rows * (C + 3) * cout
     # Q, K, V, O touched once in bf16 = the ALGORITHMIC bytes.  bf16 configuration since round 4: the cores read
-    # and write bf16 rows (self: moved = algorithmic; cross: the tokens' small k|v projection stays fp32); fp32 configuration: fp32
+    # and write bf16 rows — q, the tokens' k|v, the merged q|k|v, out: moved = algorithmic; fp32 configuration: fp32 rows
     att_alg, att_moved = 4 * q.numel() * 2, 4 * q.numel() * (2 if bf else 4)
     xat_alg = (2 * q.numel() + 2 * kc.numel()) * 2
-    xat_moved = 2 * q.numel() * 2 + 2 * kc.numel() * 4 if bf else (2 * q.numel() + 2 * kc.numel()) * 4
+    xat_moved = xat_alg if bf else 2 * xat_alg
     # SA1 layer-1 weight gradient: dW1 = dY1^T A0 over the evaluated rows: features once, G1 and Y1 rows once, the row map
     wg_bytes = B * n * C * fsz + rows * (2 * cout * esz + 16)
     # SA1 layer-3 input gradient (vlp3d_sa_bwd_layer, pooled-gradient loader + mask epilogue): Y3 and Y2 rows once, G2 written,
@@ -361,7 +361,7 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
               "hbm", att_alg, PEAK_HBM_GBS, "GB/s", att_ms,
               in_step(sdpa_entry, lambda a: a[1:5] == (BL, 4, 256, 256)), algorithmic_bytes=att_alg, moved_bytes=att_moved,
               mfma_TFLOPs=round(4.0 * BL * 256 * 256 * 128 / (att_ms * 1e-3) / 1e12, 2)),
-        entry(sdpa_name + " match cross-attention 64x(256x49) h4 d32", "sdpa_fwd_lds_kernel<5>" if bf else None,
+        entry(sdpa_name + " match cross-attention 64x(256x49) h4 d32", "sdpa_fwd_cross: void (anonymous namespace)::sdpa_fwd_lds_kernel<7>" if bf else None,
               "hbm", xat_alg, PEAK_HBM_GBS, "GB/s", xat_ms,
               in_step(sdpa_entry, lambda a: a[1:5] == (BL, 4, 256, NUM_TOKENS)), algorithmic_bytes=xat_alg, moved_bytes=xat_moved,
               mfma_TFLOPs=round(4.0 * BL * 256 * NUM_TOKENS * 128 / (xat_ms * 1e-3) / 1e12, 2)),

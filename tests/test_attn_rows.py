@@ -23,14 +23,14 @@ def _r16(t):
     return t.bfloat16().float()
 
 
-@pytest.mark.parametrize("nk,merged", [(49, False), (256, True), (40, False), (96, True)])
+@pytest.mark.parametrize("nk,merged", [(49, False), (256, True), (40, False), (96, True), (49, "kv16")])
 def test_cores_on_bf16_rows_give_the_bits_of_the_fp32_rows(nk, merged):
     """forward: out rows == bf16(out of the fp32-row core), lse equal; backward with the SAME (rounded) out on both sides:
-    dq / dk / dv bit-equal.  cross (q bf16, k|v fp32 merged) and self (q|k|v bf16 merged)."""
+    dq / dk / dv bit-equal.  cross (q bf16, k|v fp32 merged; "kv16": k|v bf16 rows too) and self (q|k|v bf16 merged)."""
     ext = _mods()[0]
     torch.manual_seed(nk)
-    B, H, nq, HD = 16, 4, 256 if merged else 200, 128
-    if merged:
+    B, H, nq, HD = 16, 4, 256 if merged is True else 200, 128
+    if merged is True:
         nq = nk
         a = _r16(torch.randn(B, nq, 3 * HD, device="cuda"))
         q, k, v = a[..., :HD], a[..., HD:2 * HD], a[..., 2 * HD:]
@@ -39,8 +39,13 @@ def test_cores_on_bf16_rows_give_the_bits_of_the_fp32_rows(nk, merged):
     else:
         q = _r16(torch.randn(B, nq, HD, device="cuda"))
         kv = torch.randn(B, nk, 2 * HD, device="cuda")  # fp32 k | v: rounded by the kernel, as in the fp32-row core
+        if merged == "kv16":
+            kv = _r16(kv)
         k, v = kv[..., :HD], kv[..., HD:]
         q16, k16, v16 = q.bfloat16(), k, v
+        if merged == "kv16":
+            kv16 = kv.bfloat16()
+            k16, v16 = kv16[..., :HD], kv16[..., HD:]
     out, lse = ext.sdpa_fwd(q, k, v, H, None, 0, None, True)
     out16, lse16 = ext.sdpa_fwd_rows(q16, k16, v16, H, None, True)
     assert out16.dtype == torch.bfloat16

@@ -73,10 +73,10 @@ q = torch.randn(64, 256, 128, device=dev)
 kc = torch.randn(64, 49, 128, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else "self"   # the self- and cross-attention launches share kernel names: two passes
 # what the step's match decoder launches since round 4: the cores on bf16 rows (vlp3d_sdpa_fwd_io): q|k|v merged bf16 (self,
-# sdpa_fwd_lds_kernel<7>), q bf16 + k|v fp32 from the tokens' projection (cross, sdpa_fwd_lds_kernel<5>); out bf16
+# sdpa_fwd_lds_kernel<7>), q bf16 + the tokens' k|v bf16 (cross: the same instantiation, the second pass of this script); out bf16
 qkv16 = torch.randn(64, 256, 384, device=dev).bfloat16()
 q16 = qkv16[..., :128].contiguous()
-kvc = torch.randn(64, 49, 256, device=dev)
+kvc = torch.randn(64, 49, 256, device=dev).bfloat16()   # the tokens' k|v: bf16 rows too (linear_rows16)
 for _ in range(3):
     if mode == "cross":
         ext.sdpa_fwd_rows(q16, kvc[..., :128], kvc[..., 128:], 4, None, True)
