@@ -306,9 +306,10 @@ def kernel_rooflines(args, batch, ext, gs, side_stream=None):
     ]
     cands = [c for c in cands if c["ms"] is not None]
     Rm = BL * 256
-    # a (bf16 rows from the core), res | x2, xhat2, z, h, x3, xhat3 (fp32), q|k|v (bf16 rows for the next core)
-    chain_bytes = Rm * (2 * 128 + 4 * (128 + 128 + 128 + 256 + 256 + 128 + 128) + 2 * 384)
-    chain_bwd_bytes = Rm * 4 * (128 + 128 + 256 + 128 + 128 + 128 + 256 + 128 + 128 + 128)  # d x3 (+ base), xhat3, z, xhat2 | dy, dz, dy, d res, d a
+    # a (bf16 rows from the core), res | x2, xhat2, x3, xhat3 (fp32), the FFN stage's h and q|k|v (bf16 rows; no pre-activation)
+    chain_bytes = Rm * (2 * 128 + 4 * (128 + 128 + 128 + 128 + 128) + 2 * 256 + 2 * 384)
+    # d x3 (+ base), xhat3, xhat2 (fp32), h (bf16 rows, in place of z) | dy, dz, dy, d res, d a
+    chain_bwd_bytes = Rm * (4 * (128 + 128 + 128 + 128) + 2 * 256 + 4 * (128 + 256 + 128 + 128 + 128))
     main_head = max(cands, key=lambda c: c["ms"] if c["ms_is"].startswith("in-step") else 0.0)
     cands = [dict(c, kernel=c["kernel"] + ": dominant MAIN-stream kernel by in-step duration") if c is main_head else c for c in cands]
     chain_fwd_ms = in_step("vlp3d_rows_chain_io", lambda a: a[2:4] == (Rm, 4))

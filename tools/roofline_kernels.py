@@ -99,7 +99,10 @@ if mode == "self":
     g3, gq = torch.randn(16384, 128, device=dev), torch.randn(16384, 384, device=dev)
     with ml.bf16_mma(True):
         for _ in range(3):
+            # as the step launches it since round 4: the core's output as bf16 rows in, q|k|v as bf16 rows out, the FFN stage
+            # keeping only its bf16 output (transformer.decoder_stack_chained)
             t = rc.run(a0, [rc.linear_add_norm(fo.weight, fo.bias, n1, x0, 0.1), rc.linear(l1.weight, l1.bias, "relu", 0.1),
-                            rc.linear_add_norm(l2.weight, l2.bias, n2, ("tile", 1), 0.1), rc.linear(nx.weight, nx.bias)])
+                            rc.linear_add_norm(l2.weight, l2.bias, n2, ("tile", 1), 0.1), rc.linear(nx.weight, nx.bias)],
+                       x_rows=a0.detach().bfloat16(), last_rows=True, compact_acts=True)
             torch.autograd.backward([t[2], t[3]], [g3, gq])
 torch.cuda.synchronize()
