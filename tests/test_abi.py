@@ -129,3 +129,20 @@ def test_row_chain_declines_what_its_kernels_do_not_cover():
     with ml.bf16_mma(True):
         assert not rc.supported(torch.zeros(64, 128), st)            # CPU
     assert not rc.supported(torch.zeros(64, 128), st)                # exact-fp32 configuration
+
+
+def test_bf16_row_operand_combinations_are_checked_on_the_host():
+    """vlp3d_sdpa_fwd_io / _bwd_io are built for io = 0, 5, 7 (include/vlp3d.h); the binding refuses every other mix of fp32 /
+    bf16 operands before anything is launched, and the shapes the LDS kernels cover are a host-side rule (no GPU needed)."""
+    import torch
+    _lib = importlib.import_module("3dvlp_amd._lib")
+    fa = importlib.import_module("3dvlp_amd.fused_attention")
+    f, h = torch.zeros(1, 4, 128), torch.zeros(1, 4, 128, dtype=torch.bfloat16)
+    assert _lib._sdpa_io(f, f, f, False) == 0
+    assert _lib._sdpa_io(h, f, f, True) == 5
+    assert _lib._sdpa_io(h, h, h, True) == 7
+    for q, k, v, o in ((f, h, h, False), (h, f, f, False), (h, h, f, True), (f, f, f, True)):
+        with pytest.raises(RuntimeError):
+            _lib._sdpa_io(q, k, v, o)
+    assert fa.rows_supported(256, 256, 256) and fa.rows_supported(256, 49, 64)
+    assert not fa.rows_supported(256, 300, 256) and not fa.rows_supported(600, 49, 256) and not fa.rows_supported(256, 49, 32)

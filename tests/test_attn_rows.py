@@ -23,13 +23,14 @@ def _r16(t):
     return t.bfloat16().float()
 
 
+@pytest.mark.parametrize("B", [16, 20])   # 16: a batch element's workgroups share an XCD (xcd_block); 20: the plain mapping
 @pytest.mark.parametrize("nk,merged", [(49, False), (256, True), (40, False), (96, True), (49, "kv16")])
-def test_cores_on_bf16_rows_give_the_bits_of_the_fp32_rows(nk, merged):
+def test_cores_on_bf16_rows_give_the_bits_of_the_fp32_rows(nk, merged, B):
     """forward: out rows == bf16(out of the fp32-row core), lse equal; backward with the SAME (rounded) out on both sides:
     dq / dk / dv bit-equal.  cross (q bf16, k|v fp32 merged; "kv16": k|v bf16 rows too) and self (q|k|v bf16 merged)."""
     ext = _mods()[0]
     torch.manual_seed(nk)
-    B, H, nq, HD = 16, 4, 256 if merged is True else 200, 128
+    H, nq, HD = 4, 256 if merged is True else 200, 128
     if merged is True:
         nq = nk
         a = _r16(torch.randn(B, nq, 3 * HD, device="cuda"))
