@@ -1963,7 +1963,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(SlabBatch t) {
 // Returns (sum of [0][c], sum of [1][c]) to the threads of group 0 (threadIdx.x < SUMC); c = blockIdx.x*SUMC + col.
 constexpr int SUMC = 4;
 __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int nslab, int C, double &s0, double &s1) {
-  __shared__ double red[2][64][SUMC];
+  __shared__ double red[2][4][SUMC];
   const int col = threadIdx.x & (SUMC - 1), grp = threadIdx.x / SUMC;
   const int c = blockIdx.x * SUMC + col;
   double a = 0.0, b = 0.0;
@@ -1986,18 +1986,21 @@ __device__ __forceinline__ void slab_sum16(const double *__restrict__ slabs, int
         }
     }
   }
-  red[0][grp][col] = a;
-  red[1][grp][col] = b;
-  __syncthreads();
-  for (int off = 32; off >= 1; off >>= 1) {  // tree over the 64 groups
-    if (grp < off) {
-      red[0][grp][col] += red[0][grp + off][col];
-      red[1][grp][col] += red[1][grp + off][col];
-    }
-    __syncthreads();
+  // the 16 groups of a wave meet through shuffles (lanes 4 apart share a column), the four waves through LDS: one barrier
+  // instead of the seven of a 64-leaf tree in LDS; a fixed order either way
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
   }
-  s0 = red[0][0][col];
-  s1 = red[1][0][col];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < SUMC) {
+    red[0][wave][col] = a;
+    red[1][wave][col] = b;
+  }
+  __syncthreads();
+  s0 = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+  s1 = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
 }
 
 // bn_fold: batch statistics (fp64 sums) -> vec[4][C] = [scale | shift | rstd | -mean*rstd], running-stat update.
@@ -2006,9 +2009,15 @@ __global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, cons
                                float *__restrict__ running_var, int C, double R, float eps, float momentum,
                                int training, float *__restrict__ vec, const float *__restrict__ mean_shift) {
   double s = 0.0, q = 0.0;
-  if (training) slab_sum16(stats, nslab, C, s, q);
+  // the per-channel operands of the tail are requested BEFORE the slab sum (they used to cost a second memory round trip behind it)
   const int c = blockIdx.x * SUMC + (threadIdx.x & (SUMC - 1));
-  if (threadIdx.x >= SUMC || c >= C) return;
+  const bool tail = threadIdx.x < SUMC && c < C;
+  const int cc = min(c, C - 1);
+  const float g_c = gamma[cc], b_c = beta[cc];
+  const float rm_c = running_mean != nullptr ? running_mean[cc] : 0.f, rv_c = running_var != nullptr ? running_var[cc] : 0.f;
+  const float ms_c = mean_shift != nullptr ? mean_shift[cc] : 0.f;
+  if (training) slab_sum16(stats, nslab, C, s, q);
+  if (!tail) return;
   double mean, var;
   if (training) {
     mean = s / R;
@@ -2016,17 +2025,17 @@ __global__ void bn_fold_kernel(const double *__restrict__ stats, int nslab, cons
     if (var < 0.0) var = 0.0;
     if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
       // mean_shift: a conv bias in front of the BatchNorm shifts the batch mean the running estimate tracks (and nothing else)
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + (mean_shift ? mean_shift[c] : 0.f));
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (R / (R > 1.0 ? R - 1.0 : 1.0)));
+      running_mean[c] = (1.f - momentum) * rm_c + momentum * ((float)mean + ms_c);
+      running_var[c] = (1.f - momentum) * rv_c + momentum * (float)(var * (R / (R > 1.0 ? R - 1.0 : 1.0)));
     }
   } else {
-    mean = running_mean[c];
-    var = running_var[c];
+    mean = rm_c;
+    var = rv_c;
   }
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  const double scale = (double)gamma[c] * rstd;
+  const double scale = (double)g_c * rstd;
   vec[c] = (float)scale;
-  vec[C + c] = (float)((double)beta[c] - mean * scale);
+  vec[C + c] = (float)((double)b_c - mean * scale);
   vec[2 * C + c] = (float)rstd;
   vec[3 * C + c] = (float)(-mean * rstd);
 }
@@ -2036,13 +2045,14 @@ __global__ void bn5_kernel(const float *__restrict__ vec, const float *__restric
                            const double *__restrict__ tslabs, int nslab, int C, double R, int training,
                            float *__restrict__ bn5, float *__restrict__ dgamma, float *__restrict__ dbeta) {
   double t[2];
-  slab_sum16(tslabs, nslab, C, t[0], t[1]);
   const int c = blockIdx.x * SUMC + (threadIdx.x & (SUMC - 1));
+  const int cc = min(c, C - 1);
+  const float rstd = vec[2 * C + cc], nmr = vec[3 * C + cc], g_c = gamma[cc];  // requested before the slab sum, not behind it
+  slab_sum16(tslabs, nslab, C, t[0], t[1]);
   if (threadIdx.x >= SUMC || c >= C) return;
-  const float rstd = vec[2 * C + c];
   bn5[c] = rstd;
-  bn5[C + c] = vec[3 * C + c];
-  bn5[2 * C + c] = gamma[c] * rstd;
+  bn5[C + c] = nmr;
+  bn5[2 * C + c] = g_c * rstd;
   bn5[3 * C + c] = training ? (float)(t[0] / R) : 0.f;
   bn5[4 * C + c] = training ? (float)(t[1] / R) : 0.f;
   dbeta[c] = (float)t[0];
