@@ -143,6 +143,42 @@ def test_chain_on_bf16_input_rows_and_bf16_last_stage(deferred, compact):
         assert torch.equal(u, c)
 
 
+def test_compact_chain_backward_on_the_unfused_entry_points():
+    """The same chain with the one-launch backward switched off (row_chain.FUSED_BACKWARD = False: vlp3d_act_dropout /
+    vlp3d_linear_dgrad per stage): the compact form hands the FFN stage's bf16 output to vlp3d_act_dropout in place of the
+    pre-activation it no longer stores — the same gradients bit for bit."""
+    ext, _, rc, ml, an = _mods()
+    torch.manual_seed(13)
+    R, p = 64 * 9, 0.1
+    mk = lambda n, k: torch.nn.Linear(k, n).cuda()
+    fo, l1, l2 = mk(128, 128), mk(256, 128), mk(128, 256)
+    n1, n2 = torch.nn.LayerNorm(128).cuda(), torch.nn.LayerNorm(128).cuda()
+    params = [q for m in (fo, l1, l2, n1, n2) for q in m.parameters()]
+    a0, x0, g2 = torch.randn(R, 128, device="cuda"), torch.randn(R, 128, device="cuda"), torch.randn(R, 128, device="cuda")
+
+    def once(compact):
+        an._CALLS[0] = 900
+        a, x = a0.clone().requires_grad_(), x0.clone().requires_grad_()
+        for q in params:
+            q.grad = None
+        st = [rc.linear_add_norm(fo.weight, fo.bias, n1, x, p), rc.linear(l1.weight, l1.bias, "relu", p),
+              rc.linear_add_norm(l2.weight, l2.bias, n2, ("tile", 1), p)]
+        with ml.bf16_mma(True):
+            t = rc.run(a, st, True, compact_acts=compact)
+            t[2].backward(g2)
+        torch.cuda.synchronize()
+        return [a.grad, x.grad] + [q.grad for q in params]
+
+    old = rc.FUSED_BACKWARD
+    rc.FUSED_BACKWARD = False
+    try:
+        plain, compact = once(False), once(True)
+    finally:
+        rc.FUSED_BACKWARD = old
+    for u, c in zip(plain, compact):
+        assert torch.equal(u, c)
+
+
 def test_match_module_decoder_on_bf16_rows_equals_the_fp32_rows():
     """MatchModule.forward (chained decoder stack, dropout off) with transformer.ATTN_BF16_ROWS on and off: the forward is the
     same up to the query projection's launch shape, the gradients differ through delta only — bounded by a fraction of what
