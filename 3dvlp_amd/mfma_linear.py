@@ -22,6 +22,7 @@ BATCH_WGRAD_BLOCKS = int(os.environ.get("VLP3D_LINEAR_WGRAD_BATCH_BLOCKS", 32)) 
 _FWD_N = (32, 64, 128, 160, 256, 288)
 _WGRAD_N = (64, 128, 256, 384, 512)  # > 256: 128-column workgroup blocks (merged q/k/v projections)
 _WGRAD_K = (32, 64, 128, 256)  # K/4 a power of two (the weight-gradient staging indexes rows by shifts)
+_SLICED_K = (512,)             # wider inputs (the captioner's w_2, transformer_captioner.py:95-104): the weight gradient as 256-column slices
 
 
 # Library (rocBLAS / hipBLASLt) GEMMs taken for shapes the MFMA kernels do not cover, keyed "R x K -> N".  Nothing falls back
@@ -41,6 +42,8 @@ def supported(x, weight):
 
 def shape_supported(R, K, N):
     """R rows of K columns through a weight (N, K): shapes the forward, input-gradient and weight-gradient kernels all cover."""
+    if K in _SLICED_K:  # forward / input gradient take any K % 32 == 0; the weight gradient runs per 256-column slice of X
+        return N % 64 == 0 and N <= 512 and shape_supported(R, 256, N)
     if not (R % 32 == 0 and R >= 32 and K % 8 == 0 and N in _WGRAD_N and K in _WGRAD_K):
         return False
     kt = (K + 31) // 32
@@ -54,6 +57,8 @@ def weight_grad(dy2, x2, N, K, want_db, bf):
     slab-reduce queue is open (one batched launch for all queued layers at the end of backward)."""
     R = x2.shape[0]
     q = _ext.slab_queue()
+    if K in _SLICED_K:
+        return _weight_grad_sliced(dy2, x2, N, K, want_db, bf, q)
     batched = q is not None and bf and BATCH_WGRAD and N % 64 == 0 and N <= 512 and K <= 256
     if x2.dtype == torch.bfloat16 and not batched:
         x2 = x2.float()  # bf16 rows (an attention core's output) are an operand form of the batched kernel only
@@ -73,6 +78,29 @@ def weight_grad(dy2, x2, N, K, want_db, bf):
             q.add(part, _ext.wgrad_slabs(R, nblk), dwb, N * K, K, K, dwb[N * K:] if want_db else None,
                   N if want_db else 0)
     return dwb[:N * K].view(N, K), (dwb[N * K:] if want_db else None)
+
+
+def _weight_grad_sliced(dy2, x2, N, K, want_db, bf, q):
+    """dW (N, K) for K > 256 as K / 256 jobs of the batched rows weight gradient (vlp3d_rows_wgrad_batch: X + offset with row
+    stride K, dW[:, offset:] with row stride K) when the step's deferred queue is open; outside it (eager unit tests) a counted
+    library product."""
+    R = x2.shape[0]
+    dev = dy2.device
+    if q is None or not (bf and BATCH_WGRAD):
+        note_fallback(R, K, N, "linear weight gradient")
+        return dy2.t() @ x2.float(), (dy2.sum(0) if want_db else None)
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if want_db else None
+    x2 = x2.float() if x2.dtype != torch.float32 else x2
+    ks = 256
+    nblk = max(8, min(BATCH_WGRAD_BLOCKS, R // _ROWS_PER_BLOCK))
+    for off in range(0, K, ks):
+        part = torch.empty((nblk, N * ks + N), dtype=torch.float32, device=dev)
+        db_ = db if off == 0 else None
+        q.add_rows_wgrad(dict(G=dy2, Ypre=None, ldg=N, bn5=None, X=(x2, off), lda=K, a_scale=None, a_shift=None, R=R, K=ks, N=N,
+                              partials=part, max_blocks=nblk, with_bias=int(db_ is not None)),
+                         (dW, db), (part, _ext.wgrad_slabs(R, nblk), dW[:, off:], N * ks, ks, K, db_, N if db_ is not None else 0))
+    return dW, db
 
 
 class _Linear(Function):
