@@ -248,7 +248,9 @@ class GroundingStep:
         self.pipeline = pipeline
         # (side_stream: reuse another step's stream — every new HIP stream takes one of the few hardware queues, and a side
         # stream that lands on the main stream's queue serialises the two: a THIRD step object in one process ran 9.8 ms)
-        self._side = (side_stream or torch.cuda.Stream(device=device)) if pipeline else None
+        # (VLP3D_SIDE_PRIORITY: experiment knob — stream priority of the geometry / deferred-work stream; default 0 = normal)
+        self._side = (side_stream or torch.cuda.Stream(device=device, priority=int(os.environ.get("VLP3D_SIDE_PRIORITY", 0)))) \
+            if pipeline else None
         self._geom_cur = self._geom_next = None
         self._geom_tag = None      # eager pipeline: the batch _geom_next was prepared for
         self._geom_for = None      # graph pipeline: the batch _geom_next was prepared for
