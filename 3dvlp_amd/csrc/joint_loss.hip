@@ -113,11 +113,25 @@ __device__ __forceinline__ float nearest_gt(const JL &a, int b, int k, int &g) {
   const float *p = a.agg_xyz + ((long long)b * a.K + k) * 3;
   float best = 0.f;
   g = 0;
-  for (int i = 0; i < a.G; ++i) {
-    const float *c = a.center_label + ((long long)b * a.G + i) * 3;
-    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    if (i == 0 || d < best) { best = d; g = i; }
+  const float px = p[0], py = p[1], pz = p[2];
+  const float *cl = a.center_label + (long long)b * a.G * 3;
+  // eight centres requested before the first compare (clamped addresses, no branch around a load): as a plain loop every
+  // iteration waited for its own three loads — 256 dependent round trips, the longest chain of the launch; the compares keep
+  // their order (first minimum)
+  for (int i0 = 0; i0 < a.G; i0 += 8) {
+    float cx[8], cy[8], cz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float *c = cl + (long long)min(i0 + u, a.G - 1) * 3;
+      cx[u] = c[0]; cy[u] = c[1]; cz[u] = c[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u;
+      const float dx = px - cx[u], dy = py - cy[u], dz = pz - cz[u];
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (i < a.G && (i == 0 || d < best)) { best = d; g = i; }
+    }
   }
   return best;
 }
@@ -341,10 +355,20 @@ __global__ __launch_bounds__(256) void jl_fwd_kernel(JL a, double *__restrict__ 
       }
     }
   }
+  // the sixteen sums: wave shuffles first, then ONE exchange through LDS (sixteen block reductions were 32 barriers); the same
+  // order of additions as bsum
+  __shared__ float redq[4][NSUMS];
 #pragma unroll
-  for (int q = 0; q < NSUMS; ++q) {
-    const float s = bsum(acc[q], red);
-    if (threadIdx.x == 0) sums[q] = (double)s;
+  for (int q = 0; q < NSUMS; ++q) acc[q] = wsum(acc[q]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < NSUMS; ++q) redq[threadIdx.x >> 6][q] = acc[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < NSUMS) {
+    const int q = threadIdx.x;
+    sums[q] = (double)((redq[0][q] + redq[1][q]) + (redq[2][q] + redq[3][q]));
   }
 }
 
