@@ -55,19 +55,25 @@ __global__ __launch_bounds__(256) void roi_split_bwd_kernel(const float *__restr
                                                             const float *__restrict__ d_obj, const float *__restrict__ d_sem,
                                                             const float *__restrict__ rois, long long R, int NH, int NC,
                                                             float res_scale, float *__restrict__ d_out, int ld) {
-  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (r >= R) return;
-  float *o = d_out + r * ld;
-  for (int c = 0; c < NH; ++c) {
-    o[c] = (d_hreg ? d_hreg[r * NH + c] : 0.f) + (d_hres ? d_hres[r * NH + c] * res_scale : 0.f);
-    o[NH + c] = d_hcls ? d_hcls[r * NH + c] : 0.f;
+  // a thread per ELEMENT of d_out (a thread per row walked ~50 dependent, uncoalesced loads on 8 workgroups: 13.8 us in-step)
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * ld) return;
+  const long long r = e / ld;
+  const int c = (int)(e - r * ld);
+  float v = 0.f;
+  if (c < NH) {
+    v = (d_hreg ? d_hreg[r * NH + c] : 0.f) + (d_hres ? d_hres[r * NH + c] * res_scale : 0.f);
+  } else if (c < 2 * NH) {
+    v = d_hcls ? d_hcls[r * NH + (c - NH)] : 0.f;
+  } else if (c < 2 * NH + 6) {
+    const int q = c - 2 * NH;
+    v = d_rois ? d_rois[r * 6 + q] * rois[r * 6 + q] : 0.f;
+  } else if (c < 2 * NH + 8) {
+    v = d_obj ? d_obj[r * 2 + (c - 2 * NH - 6)] : 0.f;
+  } else if (c < 2 * NH + 8 + NC) {
+    v = d_sem ? d_sem[r * NC + (c - 2 * NH - 8)] : 0.f;
   }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) o[2 * NH + c] = d_rois ? d_rois[r * 6 + c] * rois[r * 6 + c] : 0.f;
-  o[2 * NH + 6] = d_obj ? d_obj[r * 2] : 0.f;
-  o[2 * NH + 7] = d_obj ? d_obj[r * 2 + 1] : 0.f;
-  for (int c = 0; c < NC; ++c) o[2 * NH + 8 + c] = d_sem ? d_sem[r * NC + c] : 0.f;
-  for (int c = 2 * NH + 8 + NC; c < ld; ++c) o[c] = 0.f;
+  d_out[e] = v;
 }
 
 // ---- vote_epilogue: one wave per seed ---------------------------------------------------------------------------------
@@ -353,7 +359,7 @@ extern "C" int vlp3d_roi_split_bwd(const float *d_hreg, const float *d_hres, con
                                    const float *d_obj, const float *d_sem, const float *rois, long long R, int NH, int NC,
                                    float res_scale, float *d_out, int ld, void *stream) {
   if (!rois || !d_out || R < 1 || NH < 1 || NC < 1 || ld < 2 * NH + 8 + NC) return VLP3D_EINVAL;
-  hipLaunchKernelGGL(roi_split_bwd_kernel, dim3(blocks_of(R, 256)), dim3(256), 0, (hipStream_t)stream, d_hreg, d_hres, d_hcls,
+  hipLaunchKernelGGL(roi_split_bwd_kernel, dim3(blocks_of(R * ld, 256)), dim3(256), 0, (hipStream_t)stream, d_hreg, d_hres, d_hcls,
                      d_rois, d_obj, d_sem, rois, R, NH, NC, res_scale, d_out, ld);
   VLP3D_LAUNCH_CHECK();
   return VLP3D_OK;
