@@ -235,7 +235,15 @@ __global__ __launch_bounds__(256) void contrast_bwd_rows_kernel(Args a, const fl
   const float *keys = (c.occ ? a.box : a.boxi) + (long long)c.b * a.K * a.D;
   for (int d = threadIdx.x; d < a.D; d += 256) {
     float acc = 0.f;
-    for (int j = 0; j < a.K; ++j) acc += sd[j] * keys[(long long)j * a.D + d];
+    int j = 0;
+    for (; j + 8 <= a.K; j += 8) {  // eight key rows in flight (one row per iteration is a chain of 256 load latencies)
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = keys[(long long)(j + u) * a.D + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += sd[j + u] * x[u];
+    }
+    for (; j < a.K; ++j) acc += sd[j] * keys[(long long)j * a.D + d];
     dq[d] = acc;
   }
 }

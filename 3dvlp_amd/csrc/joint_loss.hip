@@ -480,18 +480,32 @@ __global__ __launch_bounds__(256) void jl_bwd_kernel(JL a, const double *__restr
       const float *pc = a.pred_center + t * 3, *ps = a.pred_size + t * 3;
       const int ln = a.lang_num[b];
       const float c = -g * a.w_diou / (float)a.B;
-      for (int j = 0; j < a.L && j < ln; ++j) {
-        const int *info = rowinfo + ((long long)b * a.L + j) * 4;
-        if (!info[0]) continue;
-        const float *gc = a.ref_center + ((long long)b * a.L + j) * 3, *gs = a.ref_size + ((long long)b * a.L + j) * 3;
-        float iou, diou;
-        diou_pair(pc, ps, gc, gs, iou, diou);
-        const float tk = row_label(a, 1, info[2], info[3], k, gate ? iou * objm : iou);
-        if (tk == 0.f) continue;
-        float gcn[3], gsz[3];
-        diou_grad(pc, ps, gc, gs, gcn, gsz);
+      const float pcr[3] = {pc[0], pc[1], pc[2]}, psr[3] = {ps[0], ps[1], ps[2]};
+      const int nj = min(a.L, ln);
+      // the sentences' rows (decisions + reference box) of four sentences requested before the first is used: as a plain loop
+      // every sentence waited for its own three dependent loads; the order of the additions is unchanged
+      for (int j0 = 0; j0 < nj; j0 += 4) {
+        int4 inf[4];
+        float gcr[4][3], gsr[4][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { dcen[q] += c * tk * gcn[q]; dsz[q] += c * tk * gsz[q]; }
+        for (int u = 0; u < 4; ++u) {
+          const long long row = (long long)b * a.L + min(j0 + u, nj - 1);
+          inf[u] = *reinterpret_cast<const int4 *>(rowinfo + row * 4);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { gcr[u][q] = a.ref_center[row * 3 + q]; gsr[u][q] = a.ref_size[row * 3 + q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j0 + u >= nj || !inf[u].x) continue;
+          float iou, diou;
+          diou_pair(pcr, psr, gcr[u], gsr[u], iou, diou);
+          const float tk = row_label(a, 1, inf[u].z, inf[u].w, k, gate ? iou * objm : iou);
+          if (tk == 0.f) continue;
+          float gcn[3], gsz[3];
+          diou_grad(pcr, psr, gcr[u], gsr[u], gcn, gsz);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { dcen[q] += c * tk * gcn[q]; dsz[q] += c * tk * gsz[q]; }
+        }
       }
     }
 #pragma unroll
